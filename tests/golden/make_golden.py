@@ -1,0 +1,196 @@
+#!/usr/bin/env python3
+"""Extract the reference's literal known-answer vectors into JSON fixtures.
+
+Run in the build container only (``/root/reference`` does not exist on the GPU
+box).  The output ``tests/golden/reference_kats.json`` is DATA: the decimal
+literals the reference's own unit tests compare against (inputs and expected
+outputs) and the constant tables those tests check.  No reference source text is
+kept.  Every entry records the file:line range it was read from.
+
+Sources:
+  goldilocks/ntt.rs  test_crt / test_crt2 / test_icrt / test_icrt_2, ROOTS_OF_UNITY_24, KAPPA, EIGHT_INV, FOUR_INV
+  stark_prime/ntt.rs test_crt / test_crt2 / test_icrt / test_icrt_2, ROOTS_OF_UNITY_32, SIXTEEN_INV*
+  babybear/ntt.rs    test_babybear_icrt_hardcoded, ROOTS_OF_UNITY_24, KAPPA, EIGHT_INV, FOUR_INV
+"""
+import json
+import os
+import re
+import sys
+
+REF = os.environ.get("SR_REFERENCE", "/root/reference")
+MODELS = os.path.join(REF, "crates/ring/src/cyclotomic_ring/models")
+OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "reference_kats.json")
+
+LIT = re.compile(
+    r'MontFp!\("(\d+)"\)|Fq::from\((\d+)\)|Fq::new\(BigInt\(\[(\d+)(?:u64)?\]\)\)'
+    r"|Fq::(zero)\(\)|Fq::(one)\(\)|Fq::(ZERO)|Fq::(ONE)"
+)
+
+
+def lit_values(text):
+    vals = []
+    for m in LIT.finditer(text):
+        a, b, c, z, o, zz, oo = m.groups()
+        if a is not None:
+            vals.append(int(a))
+        elif b is not None:
+            vals.append(int(b))
+        elif c is not None:
+            vals.append(int(c))
+        elif z or zz:
+            vals.append(0)
+        else:
+            vals.append(1)
+    return vals
+
+
+def read(path):
+    with open(path) as f:
+        return f.read().split("\n")
+
+
+def fn_span(lines, name):
+    """Return (first, last) 1-based line numbers of ``fn name`` body."""
+    start = None
+    for i, l in enumerate(lines):
+        if re.search(r"\bfn %s\(" % re.escape(name), l):
+            start = i
+            break
+    if start is None:
+        raise KeyError(name)
+    depth = 0
+    seen = False
+    for j in range(start, len(lines)):
+        depth += lines[j].count("{") - lines[j].count("}")
+        if "{" in lines[j]:
+            seen = True
+        if seen and depth == 0:
+            return start + 1, j + 1
+    raise ValueError("unterminated fn " + name)
+
+
+def vec_blocks(lines, first, last):
+    """All ``vec![ ... ];`` literal blocks inside the span, in order."""
+    text = "\n".join(lines[first - 1 : last])
+    blocks = []
+    for m in re.finditer(r"vec!\[(.*?)\];", text, flags=re.S):
+        blocks.append(lit_values(m.group(1)))
+    return blocks
+
+
+def const_table(lines, name):
+    for i, l in enumerate(lines):
+        if re.search(r"const %s\b" % name, l):
+            depth = 0
+            buf = []
+            for j in range(i, len(lines)):
+                buf.append(lines[j].split("//")[0])
+                depth += lines[j].count("[") - lines[j].count("]")
+                if ";" in lines[j] and depth <= 0:
+                    body = "\n".join(buf).split("=", 1)[1]
+                    return lit_values(body), (i + 1, j + 1)
+    raise KeyError(name)
+
+
+def pad(v, n):
+    return v + [0] * (n - len(v))
+
+
+def S(vals):
+    return [str(v) for v in vals]
+
+
+def main():
+    if not os.path.isdir(MODELS):
+        sys.exit("reference not present at %s (fixtures are pre-generated; nothing to do)" % REF)
+    out = {"_about": "literal KAT vectors of NethermindEth/stark-rings unit tests; standard-form decimal integers",
+           "rings": {}}
+
+    # ---------------- goldilocks (X^24 - X^12 + 1) ----------------
+    rel = "goldilocks/ntt.rs"
+    L = read(os.path.join(MODELS, rel))
+    g = {"modulus": str(2**64 - 2**32 + 1), "degree": 24, "source": rel, "kats": []}
+    roots, span = const_table(L, "ROOTS_OF_UNITY_24")
+    g["roots_of_unity_24"] = {"values": S(roots), "lines": span}
+    for cname in ("KAPPA", "EIGHT_INV", "FOUR_INV"):
+        v, span = const_table(L, cname)
+        g[cname.lower()] = {"value": str(v[0]), "lines": span}
+    # test_crt / test_crt2: input poly -> expected residues BEFORE homogenize
+    # (the tests call dehomogenize_fq3 on the crt output before comparing)
+    for name in ("test_crt", "test_crt2"):
+        a, b = fn_span(L, name)
+        blocks = vec_blocks(L, a, b)
+        g["kats"].append({"name": name, "kind": "crt_then_dehomogenize", "lines": [a, b],
+                          "coeffs": S(pad(blocks[0], 24)), "residues": S(blocks[1])})
+    # test_icrt / test_icrt_2: residues --homogenize--> icrt -> coefficients
+    for name in ("test_icrt", "test_icrt_2"):
+        a, b = fn_span(L, name)
+        blocks = vec_blocks(L, a, b)
+        g["kats"].append({"name": name, "kind": "homogenize_then_icrt", "lines": [a, b],
+                          "coeffs": S(pad(blocks[0], 24)), "residues": S(blocks[1])})
+    out["rings"]["goldilocks24"] = g
+
+    # ---------------- stark prime (X^16 + 1) ----------------
+    rel = "stark_prime/ntt.rs"
+    L = read(os.path.join(MODELS, rel))
+    s = {"modulus": str(2**251 + 17 * 2**192 + 1), "degree": 16, "source": rel, "kats": []}
+    roots, span = const_table(L, "ROOTS_OF_UNITY_32")
+    s["roots_of_unity_32"] = {"values": S(roots), "lines": span}
+    for cname in ("SIXTEEN_INV", "SIXTEEN_INV_TIMES_ROOT_OF_UNITY_32_24"):
+        v, span = const_table(L, cname)
+        s[cname.lower()] = {"value": str(v[0]), "lines": span}
+    for name in ("test_crt", "test_crt2"):
+        a, b = fn_span(L, name)
+        blocks = vec_blocks(L, a, b)
+        s["kats"].append({"name": name, "kind": "crt", "lines": [a, b],
+                          "coeffs": S(pad(blocks[0], 16)), "evals": S(blocks[1])})
+    for name in ("test_icrt", "test_icrt_2"):
+        a, b = fn_span(L, name)
+        blocks = vec_blocks(L, a, b)
+        s["kats"].append({"name": name, "kind": "icrt", "lines": [a, b],
+                          "coeffs": S(pad(blocks[0], 16)), "evals": S(blocks[1])})
+    out["rings"]["stark16"] = s
+
+    # ---------------- babybear (X^72 - X^36 + 1) ----------------
+    rel = "babybear/ntt.rs"
+    L = read(os.path.join(MODELS, rel))
+    bb = {"modulus": "2013265921", "degree": 72, "source": rel, "kats": []}
+    roots, span = const_table(L, "ROOTS_OF_UNITY_24")
+    bb["roots_of_unity_24"] = {"values": S(roots), "lines": span}
+    for cname in ("KAPPA", "EIGHT_INV", "FOUR_INV"):
+        v, span = const_table(L, cname)
+        bb[cname.lower()] = {"value": str(v[0]), "lines": span}
+    a, b = fn_span(L, "test_babybear_icrt_hardcoded")
+    text = "\n".join(L[a - 1 : b])
+    ntt = [0] * 72
+    exp = [0] * 72
+    for m in re.finditer(r'initial_ntt\[(\d+)\] = MontFp!\("(\d+)"\)', text):
+        ntt[int(m.group(1))] = int(m.group(2))
+    for m in re.finditer(r'expected\[(\d+)\] = MontFp!\("(\d+)"\)', text):
+        exp[int(m.group(1))] = int(m.group(2))
+    bb["kats"].append({"name": "test_babybear_icrt_hardcoded", "kind": "homogenize_then_icrt",
+                       "lines": [a, b], "residues": S(ntt), "coeffs": S(exp)})
+    out["rings"]["babybear72"] = bb
+
+    # ---------------- frog (X^16 + 1 over a 64-bit prime; "next" row) ----------------
+    rel = "frog_ring/ntt.rs"
+    L = read(os.path.join(MODELS, rel))
+    fr = {"modulus": "15912092521325583641", "degree": 16, "source": rel, "kats": []}
+    roots, span = const_table(L, "ROOTS_OF_UNITY_8")
+    fr["roots_of_unity_8"] = {"values": S(roots), "lines": span}
+    for name, kind in (("test_crt", "crt_then_dehomogenize"), ("test_crt2", "crt_then_dehomogenize"),
+                       ("test_icrt", "homogenize_then_icrt"), ("test_icrt_2", "homogenize_then_icrt")):
+        a, b = fn_span(L, name)
+        blocks = vec_blocks(L, a, b)
+        fr["kats"].append({"name": name, "kind": kind, "lines": [a, b],
+                           "coeffs": S(pad(blocks[0], 16)), "residues": S(blocks[1])})
+    out["rings"]["frog16"] = fr
+
+    with open(OUT, "w") as f:
+        json.dump(out, f, indent=1)
+    n = sum(len(r["kats"]) for r in out["rings"].values())
+    print("wrote %s (%d KATs)" % (OUT, n))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,192 @@
+"""Pin the oracle (pure-Python model AND the C restatement) to the reference's literal KATs.
+
+Mirrors goldilocks/ntt.rs:563-787, stark_prime/ntt.rs:377-545, babybear/ntt.rs:866-1019 and the
+root-table sanity tests (goldilocks/ntt.rs:449-467 etc.).  CPU only.
+"""
+import random
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+import pyref as P
+
+I = lambda v: [int(x) for x in v]
+
+
+# ----------------------------------------------------------------------------- constant tables
+def test_root_tables_match_generator_convention(kats):
+    g, b, s = kats["goldilocks24"], kats["babybear72"], kats["stark16"]
+    assert I(g["roots_of_unity_24"]["values"]) == P.roots24("goldilocks")
+    assert I(b["roots_of_unity_24"]["values"]) == P.roots24("babybear")
+    ps = P.psi("stark", 4)
+    assert I(s["roots_of_unity_32"]["values"]) == [pow(ps, i, P.STARK_P) for i in range(32)]
+    for ring, name in ((g, "goldilocks"), (b, "babybear")):
+        p = P.PRIMES[name][0]
+        R = P.roots24(name)
+        assert int(ring["kappa"]["value"]) == pow(2 * R[4] - 1, -1, p)
+        assert int(ring["eight_inv"]["value"]) == pow(8, -1, p)
+        assert int(ring["four_inv"]["value"]) == pow(4, -1, p)
+    assert int(s["sixteen_inv"]["value"]) == pow(16, -1, P.STARK_P)
+    assert int(s["sixteen_inv_times_root_of_unity_32_24"]["value"]) == pow(16, -1, P.STARK_P) * pow(ps, 24, P.STARK_P) % P.STARK_P
+
+
+def test_roots_are_roots_of_unity(kats):
+    # goldilocks/ntt.rs:449-467
+    for ring, name, m, key in (("goldilocks24", "goldilocks", 24, "roots_of_unity_24"),
+                               ("babybear72", "babybear", 24, "roots_of_unity_24"),
+                               ("stark16", "stark", 32, "roots_of_unity_32")):
+        p = P.PRIMES[name][0]
+        r = I(kats[ring][key]["values"])
+        assert all(pow(x, m, p) == 1 for x in r)
+        assert len(set(r)) == m
+        assert all(r[i] == pow(r[1], i, p) for i in range(m))
+
+
+# ----------------------------------------------------------------------------- pure-python model vs KATs
+def test_pyref_goldilocks24_kats(kats):
+    for k in kats["goldilocks24"]["kats"]:
+        c, r = I(k["coeffs"]), I(k["residues"])
+        assert P.g24_dehomogenize(P.g24_crt(c)) == r, k["name"]
+        assert P.g24_icrt(P.g24_homogenize(r)) == c, k["name"]
+
+
+def test_pyref_stark16_kats(kats):
+    for k in kats["stark16"]["kats"]:
+        c, e = I(k["coeffs"]), I(k["evals"])
+        assert P.pow2_fwd("stark", c, 4) == e, k["name"]
+        assert P.pow2_inv("stark", e, 4) == c, k["name"]
+
+
+def test_pyref_babybear72_kat(kats):
+    for k in kats["babybear72"]["kats"]:
+        c, r = I(k["coeffs"]), I(k["residues"])
+        assert P.bb72_icrt(P.bb72_homogenize(r)) == c
+        assert P.bb72_dehomogenize(P.bb72_crt(c)) == r
+
+
+# ----------------------------------------------------------------------------- C restatement vs KATs
+def test_c_goldilocks24_kats(kats):
+    F = O.GOLDILOCKS
+    for k in kats["goldilocks24"]["kats"]:
+        c, r = I(k["coeffs"]), I(k["residues"])
+        got = O.from_mont(F, O.small("sro_g24_dehomogenize", O.small("sro_g24_crt", O.to_mont(F, c))))
+        assert got == r, k["name"]
+        got = O.from_mont(F, O.small("sro_g24_icrt", O.small("sro_g24_homogenize", O.to_mont(F, r))))
+        assert got == c, k["name"]
+
+
+def test_c_stark16_kats(kats):
+    F = O.STARK
+    for k in kats["stark16"]["kats"]:
+        c, e = I(k["coeffs"]), I(k["evals"])
+        assert O.from_mont(F, O.pow2_fwd(F, O.to_mont(F, c), 4)) == e, k["name"]
+        assert O.from_mont(F, O.pow2_inv(F, O.to_mont(F, e), 4)) == c, k["name"]
+
+
+def test_c_babybear72_kat(kats):
+    F = O.BABYBEAR
+    for k in kats["babybear72"]["kats"]:
+        c, r = I(k["coeffs"]), I(k["residues"])
+        got = O.from_mont(F, O.small("sro_bb72_icrt", O.small("sro_bb72_homogenize", O.to_mont(F, r))))
+        assert got == c
+        got = O.from_mont(F, O.small("sro_bb72_dehomogenize", O.small("sro_bb72_crt", O.to_mont(F, c))))
+        assert got == r
+
+
+# ----------------------------------------------------------------------------- Montgomery image convention
+@pytest.mark.parametrize("name", ["goldilocks", "babybear", "stark"])
+def test_montgomery_image_is_a_times_R(name):
+    """ark-ff in-memory value = a * 2^(64N) mod p.  Unpinned by the reference
+    at byte level; this checks the oracle implements exactly that convention."""
+    F = O.FIELD_ID[name]
+    p = P.PRIMES[name][0]
+    rng = random.Random(7)
+    vals = [0, 1, p - 1, 2, 15] + [rng.randrange(p) for _ in range(50)]
+    m = O.limbs_to_ints(O.to_mont(F, vals), O.LIMBS[F])
+    assert m == [P.to_mont(name, v) for v in vals]
+    assert O.from_mont(F, O.to_mont(F, vals)) == vals
+
+
+# ----------------------------------------------------------------------------- C vs pure python, random
+@pytest.mark.parametrize("name", ["goldilocks", "babybear", "stark"])
+@pytest.mark.parametrize("k", [0, 1, 3, 6, 8])
+def test_c_pow2_matches_pyref(name, k):
+    F = O.FIELD_ID[name]
+    p = P.PRIMES[name][0]
+    rng = random.Random(100 + k)
+    d = 1 << k
+    a = [rng.randrange(p) for _ in range(d)]
+    b = [rng.randrange(p) for _ in range(d)]
+    fa = P.pow2_fwd(name, a, k)
+    assert O.from_mont(F, O.pow2_fwd(F, O.to_mont(F, a), k)) == fa
+    assert O.from_mont(F, O.pow2_inv(F, O.to_mont(F, fa), k)) == a
+    prod = P.pow2_ring_mul(name, a, b, k)
+    assert O.from_mont(F, O.pow2_ring_mul(F, O.to_mont(F, a), O.to_mont(F, b), k)) == prod
+    # NTT mul == schoolbook mul (stark_prime/mod.rs:161-177)
+    if k >= 1:
+        sb = O.schoolbook(F, O.to_mont(F, a), O.to_mont(F, b), d)
+        assert O.from_mont(F, O.pow2_reduce(F, sb, 2 * d - 1, k)) == prod
+        assert O.from_mont(F, sb) == P.schoolbook(name, a, b)
+
+
+def test_c_small_rings_match_pyref_and_mul_identity():
+    rng = random.Random(5)
+    for name, D, crt, icrt, mul, red, pcrt, pmul, pred in (
+        ("goldilocks", 24, "sro_g24_crt", "sro_g24_icrt", "sro_g24_ntt_mul", "sro_g24_reduce", P.g24_crt, P.g24_ntt_mul, P.g24_reduce),
+        ("babybear", 72, "sro_bb72_crt", "sro_bb72_icrt", "sro_bb72_ntt_mul", "sro_bb72_reduce", P.bb72_crt, P.bb72_ntt_mul, P.bb72_reduce),
+    ):
+        F = O.FIELD_ID[name]
+        p = P.PRIMES[name][0]
+        for _ in range(20):
+            a = [rng.randrange(p) for _ in range(D)]
+            b = [rng.randrange(p) for _ in range(D)]
+            ca = O.small(crt, O.to_mont(F, a))
+            cb = O.small(crt, O.to_mont(F, b))
+            assert O.from_mont(F, ca) == pcrt(a)
+            assert O.from_mont(F, O.small(icrt, ca)) == a
+            prod = O.small(mul, ca, cb)
+            assert O.from_mont(F, prod) == pmul(pcrt(a), pcrt(b))
+            # test_mul_crt: goldilocks/mod.rs:231-247, babybear/mod.rs:242-257
+            sb = O.schoolbook(F, O.to_mont(F, a), O.to_mont(F, b), D)
+            out = np.empty(D, dtype=np.uint64)
+            getattr(O.lib(), red)(O.ptr(sb), 2 * D - 1, O.ptr(out))
+            assert O.from_mont(F, out) == pred(P.schoolbook(name, a, b))
+            assert O.from_mont(F, O.small(icrt, prod)) == O.from_mont(F, out)
+
+
+def test_crt_of_one_is_one():
+    # goldilocks/mod.rs:179-191, stark_prime/mod.rs:125-137
+    for name, D, crt in (("goldilocks", 24, "sro_g24_crt"), ("babybear", 72, "sro_bb72_crt")):
+        F = O.FIELD_ID[name]
+        one = [1] + [0] * (D - 1)
+        w = 3 if D == 24 else 9
+        exp = ([1] + [0] * (w - 1)) * 8
+        assert O.from_mont(F, O.small(crt, O.to_mont(F, one))) == exp
+    for name in ("goldilocks", "babybear", "stark"):
+        F = O.FIELD_ID[name]
+        assert O.from_mont(F, O.pow2_fwd(F, O.to_mont(F, [1] + [0] * 15), 4)) == [1] * 16
+
+
+def test_batch_threads_equals_serial():
+    F = O.GOLDILOCKS
+    k, batch = 8, 13
+    a = O.fill_uniform(F, 0x5EED0001, 0, batch << k)
+    b = O.fill_uniform(F, 0x5EED0002, 0, batch << k)
+    s = O.pow2_ring_mul(F, a, b, k, batch, 1)
+    t = O.pow2_ring_mul(F, a, b, k, batch, 4)
+    assert np.array_equal(s, t)
+    one = O.pow2_ring_mul(F, a[3 << k:4 << k], b[3 << k:4 << k], k)
+    assert np.array_equal(one, s[3 << k:4 << k])
+
+
+def test_fill_uniform_is_in_range_and_reproducible():
+    for name in ("goldilocks", "babybear", "stark"):
+        F = O.FIELD_ID[name]
+        p = P.PRIMES[name][0]
+        x = O.fill_uniform(F, 42, 1000, 4096)
+        vals = O.limbs_to_ints(x, O.LIMBS[F])
+        assert all(0 <= v < p for v in vals)
+        assert len(set(vals)) > 4000
+        y = O.fill_uniform(F, 42, 1000 + 17, 100)
+        assert np.array_equal(y, x[17 * O.LIMBS[F]:117 * O.LIMBS[F]])
