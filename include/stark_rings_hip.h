@@ -1,0 +1,131 @@
+/* stark_rings_hip.h -- C ABI of the MI355X (gfx950) backend for stark-rings' CRT/NTT hot path.
+ *
+ * Drop-in boundary: these entry points are what a Rust `extern "C"` block in crates/ring would
+ * bind to replace the CPU implementations behind `CyclotomicConfig<N>`
+ * (crates/ring/src/cyclotomic_ring/ring_config.rs:11-35) at BATCH granularity, i.e. at the seam
+ * the reference itself exposes through `CRT::elementwise_crt` / `ICRT::elementwise_icrt`
+ * (crt.rs:10-25, 34-49), `Flatten` (flatten.rs:10-34) and `into_raw_parts` (utils.rs:3-6).
+ * INTEGRATION.md shows the Rust-side shim.
+ *
+ * Data layout (identical to the reference's, no padding, 8-byte aligned):
+ *   a batch is `batch` ring elements, element-major; each element is D coefficients (or CRT
+ *   slots, same bytes); each coefficient is N little-endian u64 limbs holding the ark-ff 0.4.2
+ *   Montgomery residue a * 2^(64N) mod p, canonical in [0, p).  N = 1 (Goldilocks, BabyBear --
+ *   BabyBear really is an Fp64 in the reference: babybear/mod.rs:25), N = 4 (Starknet prime).
+ *
+ * Ownership: the caller owns every buffer; transforms are in place; the library never frees or
+ * reallocates caller memory.  A context owns twiddle tables, constants and staging scratch.
+ *
+ * Errors: every call returns 0 on success, non-zero otherwise (SR_E_*).  The reference panics on
+ * a wrong length (goldilocks/ntt.rs:136, stark_prime/ntt.rs:122, coeff_form.rs:39); the Rust shim
+ * turns a non-zero status into panic! to match.  `sr_last_error_string()` gives the reason.
+ *
+ * Threading: a context is bound to one HIP device and serialises its own calls with a mutex;
+ * use one context per thread (or per stream) for concurrency.  `*_dev` calls are asynchronous
+ * on the given stream.
+ *
+ * There is NO CPU fallback: if no HIP device is present every compute call fails with
+ * SR_E_NO_DEVICE.
+ */
+#ifndef STARK_RINGS_HIP_H
+#define STARK_RINGS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ring identifiers */
+enum sr_ring {
+    /* generalised power-of-two configs  Fp[X]/(X^D+1), D = 2^log2_degree, fully split
+     * (BaseCRTField = Fq, CRT_FIELD_EXTENSION_DEGREE = 1); algorithm and slot order of
+     * stark_prime/ntt.rs:121-346 with psi = generator^((p-1)/2D).  SR_RING_STARK_POW2 with
+     * log2_degree = 4 IS the reference's stark_prime ring (StarkRingConfig, stark_prime/mod.rs:34-68). */
+    SR_RING_GOLDILOCKS_POW2 = 0,
+    SR_RING_BABYBEAR_POW2 = 1,
+    SR_RING_STARK_POW2 = 2,
+    /* reference-native partially-splitting rings (log2_degree ignored) */
+    SR_RING_GOLDILOCKS_24 = 3, /* X^24-X^12+1, 8 x Fq3: GoldilocksRingConfig, goldilocks/mod.rs:69-119 */
+    SR_RING_BABYBEAR_72 = 4    /* X^72-X^36+1, 8 x Fq9: BabyBearRingConfig,  babybear/mod.rs:81-131 */
+};
+
+enum sr_status {
+    SR_OK = 0,
+    SR_E_INVALID = 1,   /* null pointer, bad ring id, bad degree, bad length */
+    SR_E_NO_DEVICE = 2, /* no HIP device / device index out of range */
+    SR_E_HIP = 3,       /* a HIP runtime call failed */
+    SR_E_ALLOC = 4
+};
+
+typedef struct sr_ctx sr_ctx;
+
+/* ---- context -------------------------------------------------------------------------- */
+/* Creates a context on HIP device `device` and builds its twiddle tables there. */
+int sr_ctx_create(int ring, int log2_degree, int device, sr_ctx **out);
+int sr_ctx_destroy(sr_ctx *ctx);
+/* D, u64 limbs per coefficient, u64 words per ring element */
+int sr_ctx_degree(const sr_ctx *ctx, size_t *degree);
+int sr_ctx_limbs(const sr_ctx *ctx, int *limbs);
+/* Twiddle block (forward + inverse tables, device memory) for sharing across the GPUs of a node:
+ * rank 0 builds it, broadcasts the bytes (RCCL over xGMI), the other ranks adopt them. */
+int sr_ctx_twiddle_block(sr_ctx *ctx, void **dev_ptr, size_t *bytes);
+/* Tell the context its twiddle block was overwritten (e.g. by a broadcast). */
+int sr_ctx_twiddles_updated(sr_ctx *ctx);
+
+/* ---- host-buffer entry points (stage through device memory; PCIe-inclusive) ------------- */
+/* CRT::elementwise_crt  (crt.rs:10-25): coefficient form -> CRT/NTT form, in place.       */
+int sr_ntt_fwd_batch(sr_ctx *ctx, uint64_t *data, size_t batch);
+/* ICRT::elementwise_icrt (crt.rs:34-49): inverse, in place.                               */
+int sr_ntt_inv_batch(sr_ctx *ctx, uint64_t *data, size_t batch);
+/* RqNTT MulAssign<&Self> per element (ntt_form.rs:213-225; values of mul_unchecked :177-189) */
+int sr_pointwise_mul_batch(sr_ctx *ctx, uint64_t *lhs_inout, const uint64_t *rhs, size_t batch);
+/* RqPoly * RqPoly == icrt(crt(a) * crt(b)) (coeff_form.rs:250-258; identity tested at
+ * stark_prime/mod.rs:161-177).  out may alias a.                                          */
+int sr_ring_mul_batch(sr_ctx *ctx, uint64_t *out, const uint64_t *a, const uint64_t *b, size_t batch);
+/* CyclotomicConfig::reduce_in_place (stark_prime/mod.rs:40-47, goldilocks/mod.rs:75-98,
+ * babybear/mod.rs:87-110): each element has in_len_per_elem <= 2D coefficients -> D.      */
+int sr_reduce_batch(sr_ctx *ctx, const uint64_t *in, size_t in_len_per_elem, uint64_t *out, size_t batch);
+
+/* ---- device-resident entry points (pointers are HIP device pointers; `stream` is a
+ *      hipStream_t passed as void*; asynchronous) ----------------------------------------- */
+int sr_ntt_fwd_batch_dev(sr_ctx *ctx, uint64_t *d_data, size_t batch, void *stream);
+int sr_ntt_inv_batch_dev(sr_ctx *ctx, uint64_t *d_data, size_t batch, void *stream);
+int sr_pointwise_mul_batch_dev(sr_ctx *ctx, uint64_t *d_lhs_inout, const uint64_t *d_rhs, size_t batch, void *stream);
+/* d_b is used as scratch and holds crt(b) afterwards when D exceeds one LDS tile; d_out may alias d_a. */
+int sr_ring_mul_batch_dev(sr_ctx *ctx, uint64_t *d_out, const uint64_t *d_a, uint64_t *d_b, size_t batch, void *stream);
+int sr_reduce_batch_dev(sr_ctx *ctx, const uint64_t *d_in, size_t in_len_per_elem, uint64_t *d_out, size_t batch, void *stream);
+/* Synthetic coefficients, uniform in [0,p), counter-based (same definition as the oracle's
+ * sro_fill_uniform): fills n_coeffs coefficients starting at flat coefficient index first_coeff. */
+int sr_fill_uniform_dev(sr_ctx *ctx, uint64_t seed, uint64_t first_coeff, size_t n_coeffs, uint64_t *d_out, void *stream);
+/* Counts coefficients that are not canonical (>= p); used by validation code. */
+int sr_count_noncanonical_dev(sr_ctx *ctx, const uint64_t *d_data, size_t n_coeffs, uint64_t *host_count, void *stream);
+
+/* ---- per-kernel timing for the bench harness: when enabled, every kernel launch is bracketed by
+ *      HIP events recorded on the stream it is launched on.  sr_ctx_profile_read drains them into
+ *      SR_PROF_NTAGS accumulated-milliseconds / launch-count slots and resets the accumulators. ---- */
+enum sr_prof_tag {
+    SR_PROF_FWD_COLS = 0,  /* strided forward stages (D > one LDS tile)                      */
+    SR_PROF_ROWS = 1,      /* in-tile stages; for ring_mul the fused fwd(a),fwd(b),mul,inv kernel */
+    SR_PROF_INV_COLS = 2,  /* strided inverse stages                                          */
+    SR_PROF_POINTWISE = 3,
+    SR_PROF_OTHER = 4,
+    SR_PROF_NTAGS = 5
+};
+int sr_ctx_profile_enable(sr_ctx *ctx, int on);
+int sr_ctx_profile_read(sr_ctx *ctx, double ms_total[SR_PROF_NTAGS], uint64_t launches[SR_PROF_NTAGS]);
+
+/* Host-side self-test hook for the CPU test-suite: one scalar field operation computed by the same
+ * source the kernels compile (fields.hpp).  field: 0 Goldilocks, 1 BabyBear, 2 Stark.
+ * op: 0 add, 1 sub, 2 in-memory (Montgomery) product, 3 twiddle product, 4 table form of a[0].
+ * Not a compute path. */
+int sr_selftest_field_op(int field, int op, const uint64_t *a, const uint64_t *b, uint64_t *out);
+
+const char *sr_last_error_string(void);
+const char *sr_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* STARK_RINGS_HIP_H */

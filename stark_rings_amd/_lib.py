@@ -1,0 +1,68 @@
+"""ctypes binding of libstarkrings_hip.so (C ABI declared in include/stark_rings_hip.h).
+
+The library is the product; this module only loads it.  There is no CPU fallback: if the shared
+object is missing, or no HIP device is present, callers get an exception.
+"""
+import ctypes
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libstarkrings_hip.so")
+
+u64p = ctypes.POINTER(ctypes.c_uint64)
+_c = ctypes
+
+# every symbol include/stark_rings_hip.h declares: name -> (restype, argtypes)
+SYMBOLS = {
+    "sr_ctx_create": (_c.c_int, [_c.c_int, _c.c_int, _c.c_int, _c.POINTER(_c.c_void_p)]),
+    "sr_ctx_destroy": (_c.c_int, [_c.c_void_p]),
+    "sr_ctx_degree": (_c.c_int, [_c.c_void_p, _c.POINTER(_c.c_size_t)]),
+    "sr_ctx_limbs": (_c.c_int, [_c.c_void_p, _c.POINTER(_c.c_int)]),
+    "sr_ctx_twiddle_block": (_c.c_int, [_c.c_void_p, _c.POINTER(_c.c_void_p), _c.POINTER(_c.c_size_t)]),
+    "sr_ctx_twiddles_updated": (_c.c_int, [_c.c_void_p]),
+    "sr_ntt_fwd_batch": (_c.c_int, [_c.c_void_p, u64p, _c.c_size_t]),
+    "sr_ntt_inv_batch": (_c.c_int, [_c.c_void_p, u64p, _c.c_size_t]),
+    "sr_pointwise_mul_batch": (_c.c_int, [_c.c_void_p, u64p, u64p, _c.c_size_t]),
+    "sr_ring_mul_batch": (_c.c_int, [_c.c_void_p, u64p, u64p, u64p, _c.c_size_t]),
+    "sr_reduce_batch": (_c.c_int, [_c.c_void_p, u64p, _c.c_size_t, u64p, _c.c_size_t]),
+    "sr_ntt_fwd_batch_dev": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_size_t, _c.c_void_p]),
+    "sr_ntt_inv_batch_dev": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_size_t, _c.c_void_p]),
+    "sr_pointwise_mul_batch_dev": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_size_t, _c.c_void_p]),
+    "sr_ring_mul_batch_dev": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_size_t, _c.c_void_p]),
+    "sr_reduce_batch_dev": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_size_t, _c.c_void_p, _c.c_size_t, _c.c_void_p]),
+    "sr_fill_uniform_dev": (_c.c_int, [_c.c_void_p, _c.c_uint64, _c.c_uint64, _c.c_size_t, _c.c_void_p, _c.c_void_p]),
+    "sr_count_noncanonical_dev": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_size_t, _c.POINTER(_c.c_uint64), _c.c_void_p]),
+    "sr_ctx_profile_enable": (_c.c_int, [_c.c_void_p, _c.c_int]),
+    "sr_ctx_profile_read": (_c.c_int, [_c.c_void_p, _c.POINTER(_c.c_double), _c.POINTER(_c.c_uint64)]),
+    "sr_selftest_field_op": (_c.c_int, [_c.c_int, _c.c_int, u64p, u64p, u64p]),
+    "sr_last_error_string": (_c.c_char_p, []),
+    "sr_version": (_c.c_char_p, []),
+}
+
+_lib = None
+
+
+class BackendMissing(RuntimeError):
+    pass
+
+
+def load():
+    """Load the HIP shared object; raises BackendMissing (loudly) if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise BackendMissing(
+                "%s not found: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950).  There is no CPU fallback." % LIB_PATH
+            )
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(lib, name)  # AttributeError if the header and the library ever diverge
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def last_error():
+    return load().sr_last_error_string().decode()

@@ -1,0 +1,716 @@
+// C ABI of the MI355X backend (include/stark_rings_hip.h).  Host-side set-up and launch logic only;
+// kernels live in ntt_generic.hpp / ntt_goldilocks.hpp / small_rings.hpp.
+//
+// No CPU fallback exists on purpose: without a HIP device every compute entry point fails.
+#include "../../include/stark_rings_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <type_traits>
+#include <vector>
+
+#include "fields.hpp"
+#include "ntt_generic.hpp"
+#include "ntt_goldilocks.hpp"
+#include "small_rings.hpp"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string &msg) {
+    g_err = msg;
+    return code;
+}
+#define HIP_TRY(expr)                                                                          \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess)                                                                  \
+            return fail(SR_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));          \
+    } while (0)
+
+enum KernelTag { K_FWD_COLS = 0, K_ROWS = 1, K_INV_COLS = 2, K_POINTWISE = 3, K_OTHER = 4, K_NTAGS = 5 };
+
+struct Prof {
+    bool on = false;
+    struct Pair {
+        hipEvent_t a, b;
+        int tag;
+    };
+    std::vector<Pair> pending;
+    double ms[K_NTAGS] = {0, 0, 0, 0, 0};
+    uint64_t launches[K_NTAGS] = {0, 0, 0, 0, 0};
+};
+
+}  // namespace
+
+struct sr_ctx {
+    int ring = 0;
+    int k = 0;          // log2 D (pow2 rings)
+    size_t degree = 0;  // D
+    int limbs = 1;      // u64 limbs per coefficient
+    int device = 0;
+    int log_tile = 12;
+    bool fast_goldilocks = true;
+    void *tables = nullptr;  // [tw (D elems) | itw (D elems)] in table form
+    size_t table_bytes = 0;
+    // inverse stage-0 constants (table form): plain inverse, and fused ring-mul (with boundary correction)
+    unsigned char inv_scale0[32], inv_scale1[32], mul_scale0[32], mul_scale1[32];
+    // staging for host-pointer entry points
+    void *stage[2] = {nullptr, nullptr};
+    size_t stage_bytes[2] = {0, 0};
+    hipStream_t stream = nullptr;
+    unsigned long long *d_counter = nullptr;
+    std::mutex mu;
+    Prof prof;
+    sr::SmallRingConsts small{};
+    sr::GoldilocksFastTables gl_fast{};
+};
+
+namespace {
+
+struct DeviceGuard {
+    int prev = -1;
+    bool ok = true;
+    explicit DeviceGuard(int dev) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != dev) ok = hipSetDevice(dev) == hipSuccess;
+    }
+    ~DeviceGuard() {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+};
+
+// RAII for optional per-kernel event timing on the launch stream
+struct ProfScope {
+    sr_ctx *c;
+    hipStream_t s;
+    int tag;
+    hipEvent_t a = nullptr, b = nullptr;
+    ProfScope(sr_ctx *ctx, hipStream_t st, int t) : c(ctx), s(st), tag(t) {
+        if (c->prof.on) {
+            (void)hipEventCreate(&a);
+            (void)hipEventCreate(&b);
+            (void)hipEventRecord(a, s);
+        }
+    }
+    ~ProfScope() {
+        if (c->prof.on) {
+            (void)hipEventRecord(b, s);
+            c->prof.pending.push_back({a, b, tag});
+        }
+    }
+};
+
+template <class F>
+void exponent_pm1_shift(int shift, uint64_t out[4]);  // (p-1) >> shift
+template <>
+void exponent_pm1_shift<sr::Goldilocks>(int shift, uint64_t out[4]) {
+    out[0] = shift < 64 ? (sr::Goldilocks::P - 1) >> shift : 0;
+    out[1] = out[2] = out[3] = 0;
+}
+template <>
+void exponent_pm1_shift<sr::BabyBear>(int shift, uint64_t out[4]) {
+    out[0] = shift < 64 ? ((uint64_t)sr::BabyBear::P - 1) >> shift : 0;
+    out[1] = out[2] = out[3] = 0;
+}
+template <>
+void exponent_pm1_shift<sr::Stark>(int shift, uint64_t out[4]) {
+    const uint64_t pm1[4] = {0, 0, 0, 0x0800000000000011ull};
+    int ws = shift / 64, bs = shift % 64;
+    for (int i = 0; i < 4; i++) {
+        uint64_t lo = i + ws < 4 ? pm1[i + ws] : 0, hi = i + ws + 1 < 4 ? pm1[i + ws + 1] : 0;
+        out[i] = bs ? (lo >> bs) | (hi << (64 - bs)) : lo;
+    }
+}
+template <class F>
+void exponent_pm2(uint64_t out[4]);  // p - 2
+template <>
+void exponent_pm2<sr::Goldilocks>(uint64_t out[4]) {
+    out[0] = sr::Goldilocks::P - 2;
+    out[1] = out[2] = out[3] = 0;
+}
+template <>
+void exponent_pm2<sr::BabyBear>(uint64_t out[4]) {
+    out[0] = (uint64_t)sr::BabyBear::P - 2;
+    out[1] = out[2] = out[3] = 0;
+}
+template <>
+void exponent_pm2<sr::Stark>(uint64_t out[4]) {
+    out[0] = out[1] = out[2] = ~0ull;
+    out[3] = 0x0800000000000010ull;
+}
+template <class F>
+constexpr int kappa_bits() {  // mul_tw(x, y) = x * y * 2^-kappa_bits
+    return std::is_same<F, sr::Goldilocks>::value ? 0 : (std::is_same<F, sr::BabyBear>::value ? 32 : 256);
+}
+template <class F>
+constexpr int default_log_tile() {
+    return std::is_same<F, sr::Stark>::value ? 10 : 12;
+}
+
+template <class F>
+typename F::elem inv_tw(typename F::elem x) {
+    uint64_t e[4];
+    exponent_pm2<F>(e);
+    return sr::pow_tw<F>(x, e, 4);
+}
+template <class F>
+typename F::elem pow_small(typename F::elem x, uint64_t e) {
+    uint64_t w[1] = {e};
+    return sr::pow_tw<F>(x, w, 1);
+}
+
+template <class F>
+int init_pow2(sr_ctx *c) {
+    using E = typename F::elem;
+    const int k = c->k;
+    if (k > F::kTwoAdicity - 1) return fail(SR_E_INVALID, "log2_degree exceeds the field's 2-adicity");
+    c->log_tile = default_log_tile<F>();
+    if (k > 2 * c->log_tile) return fail(SR_E_INVALID, "log2_degree too large for the two-level kernels");
+    const size_t d = c->degree;
+    c->table_bytes = 2 * d * sizeof(E);
+    HIP_TRY(hipMalloc(&c->tables, c->table_bytes));
+
+    // psi = g^((p-1)/2D)  (equals ROOTS_OF_UNITY_32[1] for Stark, D = 16)
+    uint64_t e[4];
+    exponent_pm1_shift<F>(k + 1, e);
+    E psi = sr::pow_tw<F>(F::tw_from_u64(F::kGenerator), e, 4);
+    E psi_inv = inv_tw<F>(psi);
+    std::vector<E> pows(k + 1), ipows(k + 1);
+    pows[0] = psi;
+    ipows[0] = psi_inv;
+    for (int j = 1; j <= k; j++) {
+        pows[j] = F::mul_tw(pows[j - 1], pows[j - 1]);
+        ipows[j] = F::mul_tw(ipows[j - 1], ipows[j - 1]);
+    }
+    E *d_pows = nullptr;
+    HIP_TRY(hipMalloc(&d_pows, 2 * (k + 1) * sizeof(E)));
+    HIP_TRY(hipMemcpy(d_pows, pows.data(), (k + 1) * sizeof(E), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d_pows + (k + 1), ipows.data(), (k + 1) * sizeof(E), hipMemcpyHostToDevice));
+    E *tw = (E *)c->tables, *itw = tw + d;
+    unsigned blocks = (unsigned)((d + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(sr::build_tables_kernel<F>, dim3(blocks), dim3(256), 0, c->stream, tw, itw, k, d_pows,
+                       d_pows + (k + 1));
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipFree(d_pows));
+
+    // inverse stage-0 constants.  D^-1, and for the fused product D^-1 * kappa / R_b so that
+    // mul_tw(A~, B~) (= A B R_b^2 / kappa) comes out as (A B) R_b, the in-memory image of the product.
+    E dinv = inv_tw<F>(F::tw_from_u64((uint64_t)d));
+    E two = F::tw_from_u64(2);
+    E kappa = pow_small<F>(two, kappa_bits<F>());
+    E rb_inv = inv_tw<F>(pow_small<F>(two, F::kBoundaryBits));
+    E fused = F::mul_tw(dinv, F::mul_tw(kappa, rb_inv));
+    E half_turn_inv = k >= 1 ? ipows[k - 1] : F::tw_one();  // psi^-(D/2) = itw[1]
+    E s0 = dinv, s1 = F::mul_tw(dinv, half_turn_inv);
+    E m0 = fused, m1 = F::mul_tw(fused, half_turn_inv);
+    memcpy(c->inv_scale0, &s0, sizeof(E));
+    memcpy(c->inv_scale1, &s1, sizeof(E));
+    memcpy(c->mul_scale0, &m0, sizeof(E));
+    memcpy(c->mul_scale1, &m1, sizeof(E));
+    return SR_OK;
+}
+
+template <class F>
+sr::NttParams<F> make_params(const sr_ctx *c, bool fused) {
+    using E = typename F::elem;
+    sr::NttParams<F> p;
+    p.k = c->k;
+    p.log_tile = c->log_tile;
+    p.s_rows = c->k > c->log_tile ? c->k - c->log_tile : 0;
+    p.tw = (const E *)c->tables;
+    p.itw = p.tw + c->degree;
+    memcpy(&p.scale0, fused ? c->mul_scale0 : c->inv_scale0, sizeof(E));
+    memcpy(&p.scale1, fused ? c->mul_scale1 : c->inv_scale1, sizeof(E));
+    return p;
+}
+
+template <class F>
+size_t lds_bytes(const sr_ctx *c, bool two_buffers) {
+    return ((size_t)F::kLdsWords * 4u << c->log_tile) * (two_buffers ? 2 : 1);
+}
+
+template <class F, int MODE>
+int launch_rows(sr_ctx *c, typename F::storage *a, const typename F::storage *b, typename F::storage *out,
+                size_t batch, bool fused_scale, hipStream_t st) {
+    const size_t n = batch << c->k;
+    const size_t tiles = (n + ((size_t)1 << c->log_tile) - 1) >> c->log_tile;
+    if (tiles > 0x7FFFFFFFull) return fail(SR_E_INVALID, "batch too large for one launch");
+    auto p = make_params<F>(c, fused_scale);
+    ProfScope ps(c, st, K_ROWS);
+    hipLaunchKernelGGL((sr::rows_kernel<F, MODE>), dim3((unsigned)tiles), dim3(sr::kThreads),
+                       lds_bytes<F>(c, MODE == sr::MODE_MUL), st, a, b, out, n, p);
+    HIP_TRY(hipGetLastError());
+    return SR_OK;
+}
+template <class F, int MODE>
+int launch_cols(sr_ctx *c, typename F::storage *a, size_t batch, bool fused_scale, hipStream_t st) {
+    const size_t blocks = batch << (c->k - c->log_tile);
+    if (blocks > 0x7FFFFFFFull) return fail(SR_E_INVALID, "batch too large for one launch");
+    auto p = make_params<F>(c, fused_scale);
+    ProfScope ps(c, st, MODE == sr::MODE_FWD ? K_FWD_COLS : K_INV_COLS);
+    hipLaunchKernelGGL((sr::cols_kernel<F, MODE>), dim3((unsigned)blocks), dim3(sr::kThreads), lds_bytes<F>(c, false),
+                       st, a, batch, p);
+    HIP_TRY(hipGetLastError());
+    return SR_OK;
+}
+
+template <class F>
+int fwd_dev(sr_ctx *c, uint64_t *d, size_t batch, hipStream_t st) {
+    auto *a = reinterpret_cast<typename F::storage *>(d);
+    if (c->k == 0 || batch == 0) return SR_OK;
+    if (c->k > c->log_tile) {
+        int rc = launch_cols<F, sr::MODE_FWD>(c, a, batch, false, st);
+        if (rc) return rc;
+    }
+    return launch_rows<F, sr::MODE_FWD>(c, a, nullptr, a, batch, false, st);
+}
+template <class F>
+int inv_dev(sr_ctx *c, uint64_t *d, size_t batch, hipStream_t st) {
+    auto *a = reinterpret_cast<typename F::storage *>(d);
+    if (c->k == 0 || batch == 0) return SR_OK;
+    int rc = launch_rows<F, sr::MODE_INV>(c, a, nullptr, a, batch, false, st);
+    if (rc) return rc;
+    if (c->k > c->log_tile) return launch_cols<F, sr::MODE_INV>(c, a, batch, false, st);
+    return SR_OK;
+}
+template <class F>
+int pointwise_dev(sr_ctx *c, uint64_t *lhs, const uint64_t *rhs, size_t n_coeffs, hipStream_t st) {
+    if (n_coeffs == 0) return SR_OK;
+    size_t blocks = (n_coeffs + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    ProfScope ps(c, st, K_POINTWISE);
+    hipLaunchKernelGGL(sr::pointwise_kernel<F>, dim3((unsigned)blocks), dim3(256), 0, st,
+                       reinterpret_cast<typename F::storage *>(lhs),
+                       reinterpret_cast<const typename F::storage *>(rhs), n_coeffs);
+    HIP_TRY(hipGetLastError());
+    return SR_OK;
+}
+template <class F>
+int ring_mul_dev(sr_ctx *c, uint64_t *out, const uint64_t *a, uint64_t *b, size_t batch, hipStream_t st) {
+    using S = typename F::storage;
+    if (batch == 0) return SR_OK;
+    if (c->k == 0) {  // D = 1: the ring is Fp itself
+        if (out != a) HIP_TRY(hipMemcpyAsync(out, a, batch * sizeof(S), hipMemcpyDeviceToDevice, st));
+        return pointwise_dev<F>(c, out, b, batch, st);
+    }
+    if (c->k > c->log_tile) {
+        // first (strided) forward stages of both operands; a's go to out so that a stays intact
+        if (out != a) HIP_TRY(hipMemcpyAsync(out, a, (batch << c->k) * sizeof(S), hipMemcpyDeviceToDevice, st));
+        int rc = launch_cols<F, sr::MODE_FWD>(c, reinterpret_cast<S *>(out), batch, true, st);
+        if (rc) return rc;
+        rc = launch_cols<F, sr::MODE_FWD>(c, reinterpret_cast<S *>(b), batch, true, st);
+        if (rc) return rc;
+        rc = launch_rows<F, sr::MODE_MUL>(c, reinterpret_cast<S *>(out), reinterpret_cast<const S *>(b),
+                                          reinterpret_cast<S *>(out), batch, true, st);
+        if (rc) return rc;
+        return launch_cols<F, sr::MODE_INV>(c, reinterpret_cast<S *>(out), batch, true, st);
+    }
+    return launch_rows<F, sr::MODE_MUL>(c, reinterpret_cast<S *>(const_cast<uint64_t *>(a)),
+                                        reinterpret_cast<const S *>(b), reinterpret_cast<S *>(out), batch, true, st);
+}
+template <class F>
+int reduce_dev(sr_ctx *c, const uint64_t *in, size_t in_len, uint64_t *out, size_t batch, hipStream_t st) {
+    if (in_len > 2 * c->degree) return fail(SR_E_INVALID, "reduce: in_len_per_elem > 2D");
+    if (batch == 0) return SR_OK;
+    size_t n = batch << c->k;
+    size_t blocks = (n + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    ProfScope ps(c, st, K_OTHER);
+    hipLaunchKernelGGL(sr::reduce_pow2_kernel<F>, dim3((unsigned)blocks), dim3(256), 0, st,
+                       reinterpret_cast<const typename F::storage *>(in), in_len,
+                       reinterpret_cast<typename F::storage *>(out), c->k, batch);
+    HIP_TRY(hipGetLastError());
+    return SR_OK;
+}
+template <class F>
+int fill_dev(sr_ctx *c, uint64_t seed, uint64_t first, size_t n, uint64_t *out, hipStream_t st) {
+    if (n == 0) return SR_OK;
+    size_t blocks = (n + 255) / 256;
+    if (blocks > 16384) blocks = 16384;
+    ProfScope ps(c, st, K_OTHER);
+    hipLaunchKernelGGL(sr::fill_uniform_kernel<F>, dim3((unsigned)blocks), dim3(256), 0, st, seed, first, n, out);
+    HIP_TRY(hipGetLastError());
+    return SR_OK;
+}
+template <class F>
+int count_dev(sr_ctx *c, const uint64_t *d, size_t n, uint64_t *host_count, hipStream_t st) {
+    HIP_TRY(hipMemsetAsync(c->d_counter, 0, sizeof(unsigned long long), st));
+    if (n) {
+        size_t blocks = (n + 255) / 256;
+        if (blocks > 8192) blocks = 8192;
+        hipLaunchKernelGGL(sr::count_noncanonical_kernel<F>, dim3((unsigned)blocks), dim3(256), 0, st,
+                           reinterpret_cast<const typename F::storage *>(d), n, c->d_counter);
+        HIP_TRY(hipGetLastError());
+    }
+    unsigned long long v = 0;
+    HIP_TRY(hipMemcpyAsync(&v, c->d_counter, sizeof v, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    *host_count = v;
+    return SR_OK;
+}
+
+bool is_pow2_ring(int ring) { return ring >= SR_RING_GOLDILOCKS_POW2 && ring <= SR_RING_STARK_POW2; }
+
+// dispatch over the field of a pow2 ring
+#define DISPATCH_POW2(c, CALL)                                                      \
+    switch ((c)->ring) {                                                            \
+        case SR_RING_GOLDILOCKS_POW2: { using F = sr::Goldilocks; return CALL; }    \
+        case SR_RING_BABYBEAR_POW2: { using F = sr::BabyBear; return CALL; }        \
+        case SR_RING_STARK_POW2: { using F = sr::Stark; return CALL; }              \
+        default: return fail(SR_E_INVALID, "not a power-of-two ring");              \
+    }
+
+int ensure_stage(sr_ctx *c, int which, size_t bytes) {
+    if (c->stage_bytes[which] >= bytes) return SR_OK;
+    if (c->stage[which]) HIP_TRY(hipFree(c->stage[which]));
+    c->stage[which] = nullptr;
+    c->stage_bytes[which] = 0;
+    hipError_t e = hipMalloc(&c->stage[which], bytes);
+    if (e != hipSuccess) return fail(SR_E_ALLOC, std::string("hipMalloc staging: ") + hipGetErrorString(e));
+    c->stage_bytes[which] = bytes;
+    return SR_OK;
+}
+
+int check(sr_ctx *c, const void *p0, const void *p1 = (const void *)1, const void *p2 = (const void *)1) {
+    if (!c) return fail(SR_E_INVALID, "null context");
+    if (!p0 || !p1 || !p2) return fail(SR_E_INVALID, "null buffer");
+    return SR_OK;
+}
+
+// ---- per-ring device dispatch (pow2 rings and the reference-native small rings) --------------
+int dev_fwd(sr_ctx *c, uint64_t *d, size_t batch, hipStream_t st) {
+    if (c->ring == SR_RING_GOLDILOCKS_24) return sr::small_launch(c->small, sr::SMALL_G24_CRT, d, nullptr, 0, d, batch, st) ? fail(SR_E_HIP, "small-ring launch failed") : SR_OK;
+    if (c->ring == SR_RING_BABYBEAR_72) return sr::small_launch(c->small, sr::SMALL_B72_CRT, d, nullptr, 0, d, batch, st) ? fail(SR_E_HIP, "small-ring launch failed") : SR_OK;
+    if (c->ring == SR_RING_GOLDILOCKS_POW2 && c->fast_goldilocks && sr::gl_fast_supported(c->gl_fast)) {
+        ProfScope ps(c, st, K_ROWS);
+        return sr::gl_fast_fwd(c->gl_fast, d, batch, st) ? fail(SR_E_HIP, "goldilocks fast-path launch failed") : SR_OK;
+    }
+    DISPATCH_POW2(c, (fwd_dev<F>(c, d, batch, st)));
+}
+int dev_inv(sr_ctx *c, uint64_t *d, size_t batch, hipStream_t st) {
+    if (c->ring == SR_RING_GOLDILOCKS_24) return sr::small_launch(c->small, sr::SMALL_G24_ICRT, d, nullptr, 0, d, batch, st) ? fail(SR_E_HIP, "small-ring launch failed") : SR_OK;
+    if (c->ring == SR_RING_BABYBEAR_72) return sr::small_launch(c->small, sr::SMALL_B72_ICRT, d, nullptr, 0, d, batch, st) ? fail(SR_E_HIP, "small-ring launch failed") : SR_OK;
+    if (c->ring == SR_RING_GOLDILOCKS_POW2 && c->fast_goldilocks && sr::gl_fast_supported(c->gl_fast)) {
+        ProfScope ps(c, st, K_ROWS);
+        return sr::gl_fast_inv(c->gl_fast, d, batch, st) ? fail(SR_E_HIP, "goldilocks fast-path launch failed") : SR_OK;
+    }
+    DISPATCH_POW2(c, (inv_dev<F>(c, d, batch, st)));
+}
+int dev_pointwise(sr_ctx *c, uint64_t *l, const uint64_t *r, size_t batch, hipStream_t st) {
+    if (c->ring == SR_RING_GOLDILOCKS_24) return sr::small_launch(c->small, sr::SMALL_G24_MUL, l, r, 0, l, batch, st) ? fail(SR_E_HIP, "small-ring launch failed") : SR_OK;
+    if (c->ring == SR_RING_BABYBEAR_72) return sr::small_launch(c->small, sr::SMALL_B72_MUL, l, r, 0, l, batch, st) ? fail(SR_E_HIP, "small-ring launch failed") : SR_OK;
+    DISPATCH_POW2(c, (pointwise_dev<F>(c, l, r, batch << c->k, st)));
+}
+int dev_ring_mul(sr_ctx *c, uint64_t *out, const uint64_t *a, uint64_t *b, size_t batch, hipStream_t st) {
+    if (c->ring == SR_RING_GOLDILOCKS_24) return sr::small_launch(c->small, sr::SMALL_G24_RINGMUL, a, b, 0, out, batch, st) ? fail(SR_E_HIP, "small-ring launch failed") : SR_OK;
+    if (c->ring == SR_RING_BABYBEAR_72) return sr::small_launch(c->small, sr::SMALL_B72_RINGMUL, a, b, 0, out, batch, st) ? fail(SR_E_HIP, "small-ring launch failed") : SR_OK;
+    if (c->ring == SR_RING_GOLDILOCKS_POW2 && c->fast_goldilocks && sr::gl_fast_supported(c->gl_fast)) {
+        ProfScope ps(c, st, K_ROWS);
+        return sr::gl_fast_ring_mul(c->gl_fast, out, a, b, batch, st) ? fail(SR_E_HIP, "goldilocks fast-path launch failed") : SR_OK;
+    }
+    DISPATCH_POW2(c, (ring_mul_dev<F>(c, out, a, b, batch, st)));
+}
+int dev_reduce(sr_ctx *c, const uint64_t *in, size_t in_len, uint64_t *out, size_t batch, hipStream_t st) {
+    if (c->ring == SR_RING_GOLDILOCKS_24 || c->ring == SR_RING_BABYBEAR_72) {
+        if (in_len > 2 * c->degree) return fail(SR_E_INVALID, "reduce: in_len_per_elem > 2D");
+        int op = c->ring == SR_RING_GOLDILOCKS_24 ? sr::SMALL_G24_REDUCE : sr::SMALL_B72_REDUCE;
+        return sr::small_launch(c->small, op, in, nullptr, in_len, out, batch, st) ? fail(SR_E_HIP, "small-ring launch failed") : SR_OK;
+    }
+    DISPATCH_POW2(c, (reduce_dev<F>(c, in, in_len, out, batch, st)));
+}
+
+}  // namespace
+
+// ===============================================================================================
+extern "C" {
+
+const char *sr_last_error_string(void) { return g_err.c_str(); }
+const char *sr_version(void) { return "stark-rings-amd 0.1 (gfx950)"; }
+
+int sr_ctx_create(int ring, int log2_degree, int device, sr_ctx **out) {
+    if (!out) return fail(SR_E_INVALID, "null out pointer");
+    *out = nullptr;
+    if (ring < SR_RING_GOLDILOCKS_POW2 || ring > SR_RING_BABYBEAR_72) return fail(SR_E_INVALID, "unknown ring id");
+    if (is_pow2_ring(ring) && (log2_degree < 0 || log2_degree > 24)) return fail(SR_E_INVALID, "log2_degree out of range");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(SR_E_NO_DEVICE, "no HIP device available (this backend has no CPU fallback)");
+    if (device < 0 || device >= ndev) return fail(SR_E_NO_DEVICE, "device index out of range");
+    DeviceGuard g(device);
+    if (!g.ok) return fail(SR_E_HIP, "hipSetDevice failed");
+    sr_ctx *c = new sr_ctx();
+    c->ring = ring;
+    c->device = device;
+    int rc = SR_OK;
+    auto bail = [&](int code) {
+        sr_ctx_destroy(c);
+        return code;
+    };
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) return bail(fail(SR_E_HIP, "hipStreamCreate failed"));
+    if (hipMalloc(&c->d_counter, sizeof(unsigned long long)) != hipSuccess) return bail(fail(SR_E_ALLOC, "hipMalloc counter failed"));
+    if (is_pow2_ring(ring)) {
+        c->k = log2_degree;
+        c->degree = (size_t)1 << log2_degree;
+        c->limbs = ring == SR_RING_STARK_POW2 ? 4 : 1;
+        switch (ring) {
+            case SR_RING_GOLDILOCKS_POW2: rc = init_pow2<sr::Goldilocks>(c); break;
+            case SR_RING_BABYBEAR_POW2: rc = init_pow2<sr::BabyBear>(c); break;
+            default: rc = init_pow2<sr::Stark>(c); break;
+        }
+        if (rc) return bail(rc);
+        if (ring == SR_RING_GOLDILOCKS_POW2) {
+            if (sr::gl_fast_init(c->gl_fast, c->k, (const uint64_t *)c->tables, c->stream)) return bail(fail(SR_E_HIP, "goldilocks fast-path init failed"));
+            const char *env = getenv("SR_GOLDILOCKS_GENERIC");
+            c->fast_goldilocks = !(env && env[0] == '1');
+        }
+    } else {
+        c->k = 0;
+        c->degree = ring == SR_RING_GOLDILOCKS_24 ? 24 : 72;
+        c->limbs = 1;
+        if (sr::small_init(c->small, ring == SR_RING_GOLDILOCKS_24)) return bail(fail(SR_E_HIP, "small-ring init failed"));
+    }
+    *out = c;
+    return SR_OK;
+}
+
+int sr_ctx_destroy(sr_ctx *c) {
+    if (!c) return SR_OK;
+    DeviceGuard g(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    for (auto &p : c->prof.pending) {
+        (void)hipEventDestroy(p.a);
+        (void)hipEventDestroy(p.b);
+    }
+    sr::gl_fast_destroy(c->gl_fast);
+    sr::small_destroy(c->small);
+    if (c->tables) (void)hipFree(c->tables);
+    for (int i = 0; i < 2; i++)
+        if (c->stage[i]) (void)hipFree(c->stage[i]);
+    if (c->d_counter) (void)hipFree(c->d_counter);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+    return SR_OK;
+}
+
+int sr_ctx_degree(const sr_ctx *c, size_t *degree) {
+    if (!c || !degree) return fail(SR_E_INVALID, "null argument");
+    *degree = c->degree;
+    return SR_OK;
+}
+int sr_ctx_limbs(const sr_ctx *c, int *limbs) {
+    if (!c || !limbs) return fail(SR_E_INVALID, "null argument");
+    *limbs = c->limbs;
+    return SR_OK;
+}
+int sr_ctx_twiddle_block(sr_ctx *c, void **dev_ptr, size_t *bytes) {
+    if (!c || !dev_ptr || !bytes) return fail(SR_E_INVALID, "null argument");
+    if (!is_pow2_ring(c->ring)) return fail(SR_E_INVALID, "small rings keep their constants in kernel arguments");
+    *dev_ptr = c->tables;
+    *bytes = c->table_bytes;
+    return SR_OK;
+}
+int sr_ctx_twiddles_updated(sr_ctx *c) {
+    if (!c) return fail(SR_E_INVALID, "null context");
+    std::lock_guard<std::mutex> lk(c->mu);
+    DeviceGuard g(c->device);
+    if (c->ring == SR_RING_GOLDILOCKS_POW2) {
+        HIP_TRY(hipDeviceSynchronize());
+        sr::gl_fast_destroy(c->gl_fast);
+        if (sr::gl_fast_init(c->gl_fast, c->k, (const uint64_t *)c->tables, c->stream)) return fail(SR_E_HIP, "goldilocks fast-path re-init failed");
+    }
+    return SR_OK;
+}
+
+// ---- device-resident entry points ----
+int sr_ntt_fwd_batch_dev(sr_ctx *c, uint64_t *d, size_t batch, void *stream) {
+    if (int rc = check(c, d)) return rc;
+    std::lock_guard<std::mutex> lk(c->mu);
+    DeviceGuard g(c->device);
+    return dev_fwd(c, d, batch, (hipStream_t)stream);
+}
+int sr_ntt_inv_batch_dev(sr_ctx *c, uint64_t *d, size_t batch, void *stream) {
+    if (int rc = check(c, d)) return rc;
+    std::lock_guard<std::mutex> lk(c->mu);
+    DeviceGuard g(c->device);
+    return dev_inv(c, d, batch, (hipStream_t)stream);
+}
+int sr_pointwise_mul_batch_dev(sr_ctx *c, uint64_t *l, const uint64_t *r, size_t batch, void *stream) {
+    if (int rc = check(c, l, r)) return rc;
+    std::lock_guard<std::mutex> lk(c->mu);
+    DeviceGuard g(c->device);
+    return dev_pointwise(c, l, r, batch, (hipStream_t)stream);
+}
+int sr_ring_mul_batch_dev(sr_ctx *c, uint64_t *out, const uint64_t *a, uint64_t *b, size_t batch, void *stream) {
+    if (int rc = check(c, out, a, b)) return rc;
+    if ((const uint64_t *)b == a || b == out) return fail(SR_E_INVALID, "ring_mul: b must not alias a or out");
+    std::lock_guard<std::mutex> lk(c->mu);
+    DeviceGuard g(c->device);
+    return dev_ring_mul(c, out, a, b, batch, (hipStream_t)stream);
+}
+int sr_reduce_batch_dev(sr_ctx *c, const uint64_t *in, size_t in_len, uint64_t *out, size_t batch, void *stream) {
+    if (int rc = check(c, in, out)) return rc;
+    std::lock_guard<std::mutex> lk(c->mu);
+    DeviceGuard g(c->device);
+    return dev_reduce(c, in, in_len, out, batch, (hipStream_t)stream);
+}
+int sr_fill_uniform_dev(sr_ctx *c, uint64_t seed, uint64_t first, size_t n, uint64_t *out, void *stream) {
+    if (int rc = check(c, out)) return rc;
+    std::lock_guard<std::mutex> lk(c->mu);
+    DeviceGuard g(c->device);
+    hipStream_t st = (hipStream_t)stream;
+    switch (c->ring) {
+        case SR_RING_GOLDILOCKS_POW2:
+        case SR_RING_GOLDILOCKS_24: return fill_dev<sr::Goldilocks>(c, seed, first, n, out, st);
+        case SR_RING_BABYBEAR_POW2:
+        case SR_RING_BABYBEAR_72: return fill_dev<sr::BabyBear>(c, seed, first, n, out, st);
+        default: return fill_dev<sr::Stark>(c, seed, first, n, out, st);
+    }
+}
+int sr_count_noncanonical_dev(sr_ctx *c, const uint64_t *d, size_t n, uint64_t *host_count, void *stream) {
+    if (int rc = check(c, d, host_count)) return rc;
+    std::lock_guard<std::mutex> lk(c->mu);
+    DeviceGuard g(c->device);
+    hipStream_t st = (hipStream_t)stream;
+    switch (c->ring) {
+        case SR_RING_GOLDILOCKS_POW2:
+        case SR_RING_GOLDILOCKS_24: return count_dev<sr::Goldilocks>(c, d, n, host_count, st);
+        case SR_RING_BABYBEAR_POW2:
+        case SR_RING_BABYBEAR_72: return count_dev<sr::BabyBear>(c, d, n, host_count, st);
+        default: return count_dev<sr::Stark>(c, d, n, host_count, st);
+    }
+}
+
+// ---- host-buffer entry points: stage, run, copy back ----
+static int host_inplace(sr_ctx *c, uint64_t *data, size_t batch, bool fwd) {
+    if (int rc = check(c, data)) return rc;
+    std::lock_guard<std::mutex> lk(c->mu);
+    DeviceGuard g(c->device);
+    size_t bytes = batch * c->degree * c->limbs * 8;
+    if (bytes == 0) return SR_OK;
+    if (int rc = ensure_stage(c, 0, bytes)) return rc;
+    HIP_TRY(hipMemcpyAsync(c->stage[0], data, bytes, hipMemcpyHostToDevice, c->stream));
+    int rc = fwd ? dev_fwd(c, (uint64_t *)c->stage[0], batch, c->stream) : dev_inv(c, (uint64_t *)c->stage[0], batch, c->stream);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(data, c->stage[0], bytes, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return SR_OK;
+}
+int sr_ntt_fwd_batch(sr_ctx *c, uint64_t *data, size_t batch) { return host_inplace(c, data, batch, true); }
+int sr_ntt_inv_batch(sr_ctx *c, uint64_t *data, size_t batch) { return host_inplace(c, data, batch, false); }
+
+static int host_binary(sr_ctx *c, uint64_t *out, const uint64_t *a, const uint64_t *b, size_t batch, bool ring_mul) {
+    if (int rc = check(c, out, a, b)) return rc;
+    std::lock_guard<std::mutex> lk(c->mu);
+    DeviceGuard g(c->device);
+    size_t bytes = batch * c->degree * c->limbs * 8;
+    if (bytes == 0) return SR_OK;
+    if (int rc = ensure_stage(c, 0, bytes)) return rc;
+    if (int rc = ensure_stage(c, 1, bytes)) return rc;
+    HIP_TRY(hipMemcpyAsync(c->stage[0], a, bytes, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->stage[1], b, bytes, hipMemcpyHostToDevice, c->stream));
+    int rc = ring_mul ? dev_ring_mul(c, (uint64_t *)c->stage[0], (uint64_t *)c->stage[0], (uint64_t *)c->stage[1], batch, c->stream)
+                      : dev_pointwise(c, (uint64_t *)c->stage[0], (uint64_t *)c->stage[1], batch, c->stream);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(out, c->stage[0], bytes, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return SR_OK;
+}
+int sr_pointwise_mul_batch(sr_ctx *c, uint64_t *lhs, const uint64_t *rhs, size_t batch) {
+    return host_binary(c, lhs, lhs, rhs, batch, false);
+}
+int sr_ring_mul_batch(sr_ctx *c, uint64_t *out, const uint64_t *a, const uint64_t *b, size_t batch) {
+    return host_binary(c, out, a, b, batch, true);
+}
+int sr_reduce_batch(sr_ctx *c, const uint64_t *in, size_t in_len, uint64_t *out, size_t batch) {
+    if (int rc = check(c, in, out)) return rc;
+    if (in_len > 2 * c->degree) return fail(SR_E_INVALID, "reduce: in_len_per_elem > 2D");
+    std::lock_guard<std::mutex> lk(c->mu);
+    DeviceGuard g(c->device);
+    size_t in_bytes = batch * in_len * c->limbs * 8, out_bytes = batch * c->degree * c->limbs * 8;
+    if (out_bytes == 0) return SR_OK;
+    if (int rc = ensure_stage(c, 0, in_bytes ? in_bytes : 8)) return rc;
+    if (int rc = ensure_stage(c, 1, out_bytes)) return rc;
+    if (in_bytes) HIP_TRY(hipMemcpyAsync(c->stage[0], in, in_bytes, hipMemcpyHostToDevice, c->stream));
+    if (int rc = dev_reduce(c, (const uint64_t *)c->stage[0], in_len, (uint64_t *)c->stage[1], batch, c->stream)) return rc;
+    HIP_TRY(hipMemcpyAsync(out, c->stage[1], out_bytes, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return SR_OK;
+}
+
+// ---- host-side self-test hook: runs the SAME __host__ __device__ field routines the kernels use,
+// on the host, one scalar operation per call.  Lets the CPU test-suite check fields.hpp without a
+// GPU.  Not a compute path: no batch entry point routes through it.
+// op: 0 add, 1 sub, 2 mul_boundary (a*b*R_b^-1 on in-memory images), 3 mul_tw, 4 tw_from_u64(a[0])
+extern "C++" {
+template <class F>
+static int selftest_op(int op, const uint64_t *a, const uint64_t *b, uint64_t *out) {
+    using S = typename F::storage;
+    typename F::elem x = F::load(reinterpret_cast<const S *>(a)), y = F::load(reinterpret_cast<const S *>(b)), r;
+    switch (op) {
+        case 0: r = F::add(x, y); break;
+        case 1: r = F::sub(x, y); break;
+        case 2: r = F::mul_boundary(x, y); break;
+        case 3: r = F::mul_tw(x, y); break;
+        case 4: r = F::tw_from_u64(a[0]); break;
+        default: return fail(SR_E_INVALID, "selftest: unknown op");
+    }
+    F::store(reinterpret_cast<S *>(out), r);
+    return SR_OK;
+}
+}  // extern "C++"
+int sr_selftest_field_op(int field, int op, const uint64_t *a, const uint64_t *b, uint64_t *out) {
+    if (!a || !b || !out) return fail(SR_E_INVALID, "null argument");
+    alignas(16) uint64_t ta[4] = {0, 0, 0, 0}, tb[4] = {0, 0, 0, 0}, to[4] = {0, 0, 0, 0};
+    int words = field == 2 ? 4 : 1;
+    memcpy(ta, a, words * 8);
+    memcpy(tb, b, words * 8);
+    int rc;
+    switch (field) {
+        case 0: rc = selftest_op<sr::Goldilocks>(op, ta, tb, to); break;
+        case 1: rc = selftest_op<sr::BabyBear>(op, ta, tb, to); break;
+        case 2: rc = selftest_op<sr::Stark>(op, ta, tb, to); break;
+        default: return fail(SR_E_INVALID, "selftest: unknown field");
+    }
+    memcpy(out, to, words * 8);
+    return rc;
+}
+
+// ---- profiling ----
+int sr_ctx_profile_enable(sr_ctx *c, int on) {
+    if (!c) return fail(SR_E_INVALID, "null context");
+    std::lock_guard<std::mutex> lk(c->mu);
+    c->prof.on = on != 0;
+    return SR_OK;
+}
+int sr_ctx_profile_read(sr_ctx *c, double *ms_total, uint64_t *launches) {
+    if (!c || !ms_total || !launches) return fail(SR_E_INVALID, "null argument");
+    std::lock_guard<std::mutex> lk(c->mu);
+    DeviceGuard g(c->device);
+    for (auto &p : c->prof.pending) {
+        HIP_TRY(hipEventSynchronize(p.b));
+        float ms = 0;
+        HIP_TRY(hipEventElapsedTime(&ms, p.a, p.b));
+        c->prof.ms[p.tag] += ms;
+        c->prof.launches[p.tag]++;
+        (void)hipEventDestroy(p.a);
+        (void)hipEventDestroy(p.b);
+    }
+    c->prof.pending.clear();
+    for (int t = 0; t < K_NTAGS; t++) {
+        ms_total[t] = c->prof.ms[t];
+        launches[t] = c->prof.launches[t];
+        c->prof.ms[t] = 0;
+        c->prof.launches[t] = 0;
+    }
+    return SR_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,312 @@
+// Field arithmetic for the three base primes of the hot path, written for gfx950 VALU
+// (32-bit lanes, v_mad_u64_u32 as the only wide multiply) and usable on the host for
+// context set-up (twiddle roots, scale constants).
+//
+// Reference semantics restated: ark-ff 0.4.2 Fp<MontBackend<C,N>,N> (Cargo.lock:59-62), whose
+// in-memory image of a is a * 2^(64N) mod p, canonical.  Configured at
+//   crates/ring/src/cyclotomic_ring/models/goldilocks/mod.rs:20-24   (Fp64, p = 2^64-2^32+1, g = 7)
+//   crates/ring/src/cyclotomic_ring/models/babybear/mod.rs:21-25     (Fp64!, p = 15*2^27+1, g = 31)
+//   crates/ring/src/cyclotomic_ring/models/stark_prime/mod.rs:20-24  (Fp256, p = 2^251+17*2^192+1, g = 3)
+//
+// Device-side convention ("table form"): a transform is linear, so boundary words are treated
+// as plain residues and multiplied by twiddles kept in whatever form makes the product cheapest:
+//   mul_tw(x, w_tab) = x * w  where  w_tab = w * kappa,  kappa = 1 (Goldilocks, direct 2^64 = 2^32-1
+//   folding), 2^32 (BabyBear, 32-bit Montgomery), 2^256 (Stark, 8x32-bit CIOS Montgomery).
+// mul_boundary(a, b) = a * b * R_b^-1 with R_b = 2^64 / 2^64 / 2^256 is the reference's Fp product on
+// the in-memory images (ntt_form.rs:177-189).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define SR_HD __host__ __device__ __forceinline__
+
+namespace sr {
+
+// ------------------------------------------------------------------------------------------
+// Goldilocks  p = 2^64 - 2^32 + 1
+// ------------------------------------------------------------------------------------------
+struct Goldilocks {
+    using elem = uint64_t;      // register / LDS form, canonical in [0, p)
+    using storage = uint64_t;   // global-memory form (reference layout: one u64 limb)
+    static constexpr int kStorageWords64 = 1;
+    static constexpr int kLdsWords = 2;  // 32-bit words per element in LDS
+    static constexpr uint64_t P = 0xFFFFFFFF00000001ull;
+    static constexpr uint64_t EPS = 0xFFFFFFFFull;  // 2^64 mod p
+    static constexpr uint32_t kGenerator = 7;
+    static constexpr int kBoundaryBits = 64;  // R_b = 2^64
+    static constexpr int kTwoAdicity = 32;
+
+    SR_HD static elem zero() { return 0; }
+    SR_HD static elem load(const storage *p) { return *p; }
+    SR_HD static void store(storage *p, elem v) { *p = v; }
+    SR_HD static bool valid(elem v) { return v < P; }
+
+    SR_HD static elem add(elem a, elem b) {
+        uint64_t s = a + b;
+        bool fix = (s < a) | (s >= P);  // s - p == s + EPS (mod 2^64) in both cases
+        return fix ? s + EPS : s;
+    }
+    SR_HD static elem sub(elem a, elem b) {
+        uint64_t d = a - b;
+        return (a < b) ? d - EPS : d;  // + p == - EPS (mod 2^64)
+    }
+    SR_HD static elem neg(elem a) { return a ? P - a : 0; }
+
+    // (hi * 2^64 + lo) mod p, using 2^64 = EPS and 2^96 = -1
+    SR_HD static elem reduce128(uint64_t lo, uint64_t hi) {
+        uint32_t hh = (uint32_t)(hi >> 32), hl = (uint32_t)hi;
+        uint64_t t0 = lo - hh;
+        if (lo < hh) t0 -= EPS;
+        uint64_t t1 = ((uint64_t)hl << 32) - hl;  // hl * EPS
+        uint64_t r = t0 + t1;
+        if (r < t1) r += EPS;
+        return r >= P ? r - P : r;
+    }
+    SR_HD static elem mul(elem a, elem b) {
+        unsigned __int128 x = (unsigned __int128)a * b;
+        return reduce128((uint64_t)x, (uint64_t)(x >> 64));
+    }
+    SR_HD static elem mul_tw(elem a, elem w) { return mul(a, w); }
+    // a * b * 2^-64: 2^-64 = -2^32 (mod p), so (hi, lo) -> hi - lo * 2^32
+    SR_HD static elem mul_boundary(elem a, elem b) {
+        unsigned __int128 x = (unsigned __int128)a * b;
+        uint64_t lo = (uint64_t)x, hi = (uint64_t)(x >> 64);  // hi < p because a, b < p
+        uint64_t m = reduce128(lo << 32, lo >> 32);
+        return sub(hi, m);
+    }
+    SR_HD static elem tw_from_u64(uint64_t x) { return x % P; }
+    SR_HD static elem tw_one() { return 1; }
+
+    // LDS accessors: array of u64
+    SR_HD static elem lds_get(const uint32_t *lds, int idx, int) {
+        return *reinterpret_cast<const uint64_t *>(lds + 2 * idx);
+    }
+    SR_HD static void lds_put(uint32_t *lds, int idx, int, elem v) {
+        *reinterpret_cast<uint64_t *>(lds + 2 * idx) = v;
+    }
+};
+
+// ------------------------------------------------------------------------------------------
+// BabyBear  p = 15 * 2^27 + 1 (31 bits).  The reference stores it in a u64 limb (R_b = 2^64);
+// on device we keep 32-bit residues and use 32-bit Montgomery (kappa = 2^32) for twiddle products.
+// ------------------------------------------------------------------------------------------
+struct BabyBear {
+    using elem = uint32_t;
+    using storage = uint64_t;  // reference layout: Fp64, upper word always zero
+    static constexpr int kStorageWords64 = 1;
+    static constexpr int kLdsWords = 1;
+    static constexpr uint32_t P = 2013265921u;       // 0x78000001
+    static constexpr uint32_t PINV = 2013265919u;    // -p^-1 mod 2^32  (p * 0x88000001 = 1 mod 2^32)
+    static constexpr uint32_t R2 = 1172168163u;      // 2^64 mod p
+    static constexpr uint32_t kGenerator = 31;
+    static constexpr int kBoundaryBits = 64;
+    static constexpr int kTwoAdicity = 27;
+
+    SR_HD static elem zero() { return 0; }
+    SR_HD static elem load(const storage *p) { return (uint32_t)*p; }
+    SR_HD static void store(storage *p, elem v) { *p = (uint64_t)v; }
+    SR_HD static bool valid(elem v) { return v < P; }
+
+    SR_HD static elem add(elem a, elem b) {
+        uint32_t s = a + b;  // < 2^32
+        return s >= P ? s - P : s;
+    }
+    SR_HD static elem sub(elem a, elem b) {
+        uint32_t d = a - b;
+        return a < b ? d + P : d;
+    }
+    SR_HD static elem neg(elem a) { return a ? P - a : 0; }
+    // a * b * 2^-32 mod p
+    SR_HD static elem mont32(elem a, elem b) {
+        uint64_t t = (uint64_t)a * b;
+        uint32_t m = (uint32_t)t * PINV;
+        uint32_t u = (uint32_t)((t + (uint64_t)m * P) >> 32);
+        return u >= P ? u - P : u;
+    }
+    SR_HD static elem mul_tw(elem a, elem w) { return mont32(a, w); }
+    SR_HD static elem mul_boundary(elem a, elem b) { return mont32(mont32(a, b), 1u); }
+    SR_HD static elem tw_from_u64(uint64_t x) { return mont32((uint32_t)(x % P), R2); }
+    SR_HD static elem tw_one() { return tw_from_u64(1); }
+
+    SR_HD static elem lds_get(const uint32_t *lds, int idx, int) { return lds[idx]; }
+    SR_HD static void lds_put(uint32_t *lds, int idx, int, elem v) { lds[idx] = v; }
+};
+
+// ------------------------------------------------------------------------------------------
+// Starknet prime  p = 2^251 + 17 * 2^192 + 1, eight 32-bit limbs, CIOS Montgomery R = 2^256.
+// p = 1 (mod 2^32) so -p^-1 mod 2^32 = 0xFFFFFFFF and the reduction word is m = -t0.
+// ------------------------------------------------------------------------------------------
+struct U256 {
+    uint32_t l[8];
+};
+struct alignas(16) U256Storage {
+    uint64_t q[4];  // reference layout: 4 little-endian u64 limbs
+};
+
+struct Stark {
+    using elem = U256;
+    using storage = U256Storage;
+    static constexpr int kStorageWords64 = 4;
+    static constexpr int kLdsWords = 8;
+    static constexpr uint32_t kGenerator = 3;
+    static constexpr int kBoundaryBits = 256;
+    static constexpr int kTwoAdicity = 192;
+
+    SR_HD static uint32_t pl(int i) {  // modulus limbs
+        return i == 0 ? 1u : (i == 6 ? 0x11u : (i == 7 ? 0x08000000u : 0u));
+    }
+    SR_HD static elem zero() {
+        elem z;
+#pragma unroll
+        for (int i = 0; i < 8; i++) z.l[i] = 0;
+        return z;
+    }
+    SR_HD static elem load(const storage *p) {
+        elem e;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            uint64_t q = p->q[i];
+            e.l[2 * i] = (uint32_t)q;
+            e.l[2 * i + 1] = (uint32_t)(q >> 32);
+        }
+        return e;
+    }
+    SR_HD static void store(storage *p, const elem &e) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) p->q[i] = (uint64_t)e.l[2 * i] | ((uint64_t)e.l[2 * i + 1] << 32);
+    }
+    SR_HD static bool geq_p(const elem &a) {
+        // a >= p ?  compare from the top limb
+        bool gt = false, lt = false;
+#pragma unroll
+        for (int i = 7; i >= 0; i--) {
+            uint32_t pi = pl(i);
+            bool undecided = !(gt | lt);
+            gt |= undecided & (a.l[i] > pi);
+            lt |= undecided & (a.l[i] < pi);
+        }
+        return !lt;
+    }
+    SR_HD static bool valid(const elem &a) { return !geq_p(a); }
+    SR_HD static uint32_t add_raw(elem &r, const elem &a, const elem &b) {
+        uint64_t c = 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            c += (uint64_t)a.l[i] + b.l[i];
+            r.l[i] = (uint32_t)c;
+            c >>= 32;
+        }
+        return (uint32_t)c;
+    }
+    SR_HD static uint32_t sub_raw(elem &r, const elem &a, const elem &b) {
+        uint32_t borrow = 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            uint64_t d = (uint64_t)a.l[i] - b.l[i] - borrow;
+            r.l[i] = (uint32_t)d;
+            borrow = (uint32_t)(d >> 32) & 1u;
+        }
+        return borrow;
+    }
+    SR_HD static elem modulus() {
+        elem p;
+#pragma unroll
+        for (int i = 0; i < 8; i++) p.l[i] = pl(i);
+        return p;
+    }
+    SR_HD static elem add(const elem &a, const elem &b) {
+        elem s, t;
+        add_raw(s, a, b);  // a + b < 2p < 2^253: no carry out
+        uint32_t borrow = sub_raw(t, s, modulus());
+        return borrow ? s : t;
+    }
+    SR_HD static elem sub(const elem &a, const elem &b) {
+        elem d, t;
+        uint32_t borrow = sub_raw(d, a, b);
+        add_raw(t, d, modulus());
+        return borrow ? t : d;
+    }
+    SR_HD static elem neg(const elem &a) { return sub(zero(), a); }
+    // a * b * 2^-256 mod p
+    SR_HD static elem mont_mul(const elem &a, const elem &b) {
+        uint32_t t[10];
+#pragma unroll
+        for (int i = 0; i < 10; i++) t[i] = 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            uint64_t c = 0;
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                c += (uint64_t)a.l[j] * b.l[i] + t[j];
+                t[j] = (uint32_t)c;
+                c >>= 32;
+            }
+            c += t[8];
+            t[8] = (uint32_t)c;
+            t[9] = (uint32_t)(c >> 32);
+            uint32_t m = 0u - t[0];
+            c = ((uint64_t)m * pl(0) + t[0]) >> 32;
+#pragma unroll
+            for (int j = 1; j < 8; j++) {
+                c += (uint64_t)m * pl(j) + t[j];
+                t[j - 1] = (uint32_t)c;
+                c >>= 32;
+            }
+            c += t[8];
+            t[7] = (uint32_t)c;
+            t[8] = t[9] + (uint32_t)(c >> 32);
+        }
+        elem s, u;
+#pragma unroll
+        for (int i = 0; i < 8; i++) s.l[i] = t[i];
+        uint32_t borrow = sub_raw(u, s, modulus());
+        return (t[8] | !borrow) ? u : s;
+    }
+    SR_HD static elem mul_tw(const elem &a, const elem &w) { return mont_mul(a, w); }
+    SR_HD static elem mul_boundary(const elem &a, const elem &b) { return mont_mul(a, b); }
+    SR_HD static elem r2() {  // 2^512 mod p
+        elem e;
+        e.l[0] = 0x7E000401u; e.l[1] = 0xFFFFFD73u; e.l[2] = 0x330FFFFFu; e.l[3] = 0x00000001u;
+        e.l[4] = 0xFF6F8000u; e.l[5] = 0xFFFFFFFFu; e.l[6] = 0x5E008810u; e.l[7] = 0x07FFD4ABu;
+        return e;
+    }
+    SR_HD static elem tw_from_u64(uint64_t x) {
+        elem e = zero();
+        e.l[0] = (uint32_t)x;
+        e.l[1] = (uint32_t)(x >> 32);
+        return mont_mul(e, r2());
+    }
+    SR_HD static elem tw_one() { return tw_from_u64(1); }
+
+    // LDS accessors: limb-major (SoA) so that consecutive lanes hit consecutive banks
+    SR_HD static elem lds_get(const uint32_t *lds, int idx, int n) {
+        elem e;
+#pragma unroll
+        for (int i = 0; i < 8; i++) e.l[i] = lds[i * n + idx];
+        return e;
+    }
+    SR_HD static void lds_put(uint32_t *lds, int idx, int n, const elem &v) {
+#pragma unroll
+        for (int i = 0; i < 8; i++) lds[i * n + idx] = v.l[i];
+    }
+};
+
+// ------------------------------------------------------------------------------------------
+// helpers shared by host set-up code and device table builders
+// ------------------------------------------------------------------------------------------
+template <class F>
+SR_HD typename F::elem pow_tw(typename F::elem base, const uint64_t *e, int e_words) {
+    typename F::elem acc = F::tw_one();
+    for (int i = 0; i < e_words; i++) {
+        uint64_t w = e[i];
+        for (int b = 0; b < 64; b++) {
+            if ((w >> b) & 1) acc = F::mul_tw(acc, base);
+            base = F::mul_tw(base, base);
+        }
+    }
+    return acc;
+}
+
+SR_HD uint32_t bitrev(uint32_t x, int bits) { return bits ? (__builtin_bitreverse32(x) >> (32 - bits)) : 0u; }
+
+}  // namespace sr

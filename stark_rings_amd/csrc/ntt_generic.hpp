@@ -1,0 +1,301 @@
+// Generic (any field F from fields.hpp) negacyclic NTT kernels for Fp[X]/(X^D+1), D = 2^k.
+//
+// Algorithm and slot order: the reference's stark_prime CRT generalised to D = 2^k
+// (crates/ring/src/cyclotomic_ring/models/stark_prime/ntt.rs:121-235 forward, :245-346 inverse):
+//   forward  stage s = 0..k-1, half = D >> (s+1), block b: w = psi^brv_k(2^s + b)
+//            (u, v) -> (u + w v, u - w v)                                   [Cooley-Tukey]
+//   inverse  stage s = k-1..0: (u, v) -> (u + v, w^-1 (u - v)); D^-1 folded into stage 0
+//            exactly like SIXTEEN_INV / SIXTEEN_INV_TIMES_ROOT (ntt.rs:51-55, 339-345).
+//
+// Two kernel shapes cover every degree:
+//   rows_kernel  -- a workgroup owns TILE contiguous coefficients of the flat batch in LDS and runs
+//                   the stages whose butterflies stay inside the tile (half < TILE).  For D <= TILE a
+//                   tile holds TILE/D whole ring elements.  MODE_MUL fuses fwd(a), fwd(b), the slot
+//                   product (ntt_form.rs:177-189) and the inverse stages in one pass over HBM.
+//   cols_kernel  -- the stages with half >= TILE: a workgroup gathers C = D/TILE strided rows of W
+//                   contiguous coefficients into LDS and runs log2(C) stages across the rows.
+// These are the correctness-first, field-agnostic kernels (radix-2 butterflies through LDS, one
+// barrier per stage); ntt_goldilocks.hpp holds the tuned Goldilocks path.
+#pragma once
+#include "fields.hpp"
+
+namespace sr {
+
+enum { MODE_FWD = 0, MODE_INV = 1, MODE_MUL = 2 };
+constexpr int kThreads = 256;
+
+template <class F>
+struct NttParams {
+    int k;          // log2 D
+    int s_rows;     // first stage handled by rows_kernel (0 when D <= TILE)
+    int log_tile;   // log2 TILE
+    const typename F::elem *tw;   // tw[2^s + b]  = psi^ brv_k(2^s+b)   (table form)
+    const typename F::elem *itw;  // itw[2^s + b] = psi^-brv_k(2^s+b)
+    typename F::elem scale0;      // inverse stage 0, sum leg   (D^-1 [* fused correction])
+    typename F::elem scale1;      // inverse stage 0, diff leg  (scale0 * psi^-(D/2))
+};
+
+template <class F>
+__device__ __forceinline__ void fwd_stage_lds(uint32_t *lds, int n_tile, int n_loc, size_t off, int k, int s,
+                                              const typename F::elem *tw) {
+    const int lh = k - s - 1;
+    const int half = 1 << lh;
+    for (int j = threadIdx.x; j < (n_tile >> 1); j += kThreads) {
+        int i = j & (half - 1);
+        int lo = ((j >> lh) << (lh + 1)) + i;
+        int hi = lo + half;
+        if (hi < n_loc) {
+            size_t g = off + lo;
+            uint32_t b = (uint32_t)(g >> (lh + 1)) & ((1u << s) - 1u);
+            typename F::elem w = tw[(1u << s) + b];
+            typename F::elem u = F::lds_get(lds, lo, n_tile);
+            typename F::elem v = F::mul_tw(F::lds_get(lds, hi, n_tile), w);
+            F::lds_put(lds, lo, n_tile, F::add(u, v));
+            F::lds_put(lds, hi, n_tile, F::sub(u, v));
+        }
+    }
+}
+
+template <class F>
+__device__ __forceinline__ void inv_stage_lds(uint32_t *lds, int n_tile, int n_loc, size_t off, int k, int s,
+                                              const NttParams<F> &p) {
+    const int lh = k - s - 1;
+    const int half = 1 << lh;
+    for (int j = threadIdx.x; j < (n_tile >> 1); j += kThreads) {
+        int i = j & (half - 1);
+        int lo = ((j >> lh) << (lh + 1)) + i;
+        int hi = lo + half;
+        if (hi < n_loc) {
+            typename F::elem u = F::lds_get(lds, lo, n_tile);
+            typename F::elem v = F::lds_get(lds, hi, n_tile);
+            typename F::elem sum = F::add(u, v), dif = F::sub(u, v);
+            if (s == 0) {
+                F::lds_put(lds, lo, n_tile, F::mul_tw(sum, p.scale0));
+                F::lds_put(lds, hi, n_tile, F::mul_tw(dif, p.scale1));
+            } else {
+                size_t g = off + lo;
+                uint32_t b = (uint32_t)(g >> (lh + 1)) & ((1u << s) - 1u);
+                F::lds_put(lds, lo, n_tile, sum);
+                F::lds_put(lds, hi, n_tile, F::mul_tw(dif, p.itw[(1u << s) + b]));
+            }
+        }
+    }
+}
+
+// n_total = batch * D flat coefficients.  grid.x = ceil(n_total / TILE).
+template <class F, int MODE>
+__global__ __launch_bounds__(kThreads) void rows_kernel(typename F::storage *a, const typename F::storage *b,
+                                                        typename F::storage *out, size_t n_total, NttParams<F> p) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    const int n_tile = 1 << p.log_tile;
+    const size_t off = (size_t)blockIdx.x << p.log_tile;
+    const size_t rem = n_total - off;
+    const int n_loc = rem < (size_t)n_tile ? (int)rem : n_tile;
+    uint32_t *la = smem;
+    uint32_t *lb = smem + n_tile * F::kLdsWords;
+
+    for (int i = threadIdx.x; i < n_loc; i += kThreads) {
+        F::lds_put(la, i, n_tile, F::load(a + off + i));
+        if (MODE == MODE_MUL) F::lds_put(lb, i, n_tile, F::load(b + off + i));
+    }
+    __syncthreads();
+
+    if (MODE == MODE_FWD || MODE == MODE_MUL) {
+        for (int s = p.s_rows; s < p.k; s++) {
+            fwd_stage_lds<F>(la, n_tile, n_loc, off, p.k, s, p.tw);
+            if (MODE == MODE_MUL) fwd_stage_lds<F>(lb, n_tile, n_loc, off, p.k, s, p.tw);
+            __syncthreads();
+        }
+    }
+    if (MODE == MODE_MUL) {
+        for (int i = threadIdx.x; i < n_loc; i += kThreads)
+            F::lds_put(la, i, n_tile, F::mul_tw(F::lds_get(la, i, n_tile), F::lds_get(lb, i, n_tile)));
+        __syncthreads();
+    }
+    if (MODE == MODE_INV || MODE == MODE_MUL) {
+        for (int s = p.k - 1; s >= p.s_rows; s--) {
+            inv_stage_lds<F>(la, n_tile, n_loc, off, p.k, s, p);
+            __syncthreads();
+        }
+    }
+    for (int i = threadIdx.x; i < n_loc; i += kThreads) F::store(out + off + i, F::lds_get(la, i, n_tile));
+}
+
+// Stages [0, s_rows): C = 2^s_rows rows of length Tr = D / C; a workgroup owns W = TILE / C
+// consecutive columns of one ring element.  grid.x = batch * (Tr / W) = batch * D / TILE.
+template <class F, int MODE>
+__global__ __launch_bounds__(kThreads) void cols_kernel(typename F::storage *a, size_t batch, NttParams<F> p) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    const int n_tile = 1 << p.log_tile;
+    const int lc = p.s_rows;              // log2 C
+    const int lw = p.log_tile - lc;       // log2 W
+    const int W = 1 << lw;
+    const int ltr = p.k - lc;             // log2 row length
+    const size_t chunks = (size_t)1 << (ltr - lw);
+    const size_t poly = blockIdx.x / chunks;
+    const size_t chunk = blockIdx.x % chunks;
+    if (poly >= batch) return;
+    typename F::storage *base = a + (poly << p.k) + (chunk << lw);
+
+    for (int idx = threadIdx.x; idx < n_tile; idx += kThreads) {
+        int c = idx >> lw, w = idx & (W - 1);
+        F::lds_put(smem, idx, n_tile, F::load(base + ((size_t)c << ltr) + w));
+    }
+    __syncthreads();
+
+    if (MODE == MODE_FWD) {
+        for (int s = 0; s < lc; s++) {
+            const int lhc = lc - s - 1;  // log2 of half, in rows
+            for (int j = threadIdx.x; j < (n_tile >> 1); j += kThreads) {
+                int w = j & (W - 1), r = j >> lw;
+                int i = r & ((1 << lhc) - 1), grp = r >> lhc;
+                int lo = (((grp << (lhc + 1)) + i) << lw) + w;
+                int hi = lo + (1 << (lhc + lw));
+                typename F::elem tw = p.tw[(1u << s) + grp];
+                typename F::elem u = F::lds_get(smem, lo, n_tile);
+                typename F::elem v = F::mul_tw(F::lds_get(smem, hi, n_tile), tw);
+                F::lds_put(smem, lo, n_tile, F::add(u, v));
+                F::lds_put(smem, hi, n_tile, F::sub(u, v));
+            }
+            __syncthreads();
+        }
+    } else {
+        for (int s = lc - 1; s >= 0; s--) {
+            const int lhc = lc - s - 1;
+            for (int j = threadIdx.x; j < (n_tile >> 1); j += kThreads) {
+                int w = j & (W - 1), r = j >> lw;
+                int i = r & ((1 << lhc) - 1), grp = r >> lhc;
+                int lo = (((grp << (lhc + 1)) + i) << lw) + w;
+                int hi = lo + (1 << (lhc + lw));
+                typename F::elem u = F::lds_get(smem, lo, n_tile);
+                typename F::elem v = F::lds_get(smem, hi, n_tile);
+                typename F::elem sum = F::add(u, v), dif = F::sub(u, v);
+                if (s == 0) {
+                    F::lds_put(smem, lo, n_tile, F::mul_tw(sum, p.scale0));
+                    F::lds_put(smem, hi, n_tile, F::mul_tw(dif, p.scale1));
+                } else {
+                    F::lds_put(smem, lo, n_tile, sum);
+                    F::lds_put(smem, hi, n_tile, F::mul_tw(dif, p.itw[(1u << s) + grp]));
+                }
+            }
+            __syncthreads();
+        }
+    }
+    for (int idx = threadIdx.x; idx < n_tile; idx += kThreads) {
+        int c = idx >> lw, w = idx & (W - 1);
+        F::store(base + ((size_t)c << ltr) + w, F::lds_get(smem, idx, n_tile));
+    }
+}
+
+// ---- element-wise kernels ----------------------------------------------------------------
+// lhs[i] = lhs[i] * rhs[i] on the in-memory images (ntt_form.rs:177-189)
+template <class F>
+__global__ void pointwise_kernel(typename F::storage *lhs, const typename F::storage *rhs, size_t n) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        F::store(lhs + i, F::mul_boundary(F::load(lhs + i), F::load(rhs + i)));
+}
+
+// out[e][i] = in[e][i] - in[e][D + i]   (stark_prime/mod.rs:40-47); in_len <= 2D per element
+template <class F>
+__global__ void reduce_pow2_kernel(const typename F::storage *in, size_t in_len, typename F::storage *out, int k,
+                                   size_t batch) {
+    const size_t d = (size_t)1 << k;
+    const size_t n = batch << k;
+    for (size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x; t < n; t += (size_t)gridDim.x * blockDim.x) {
+        size_t e = t >> k, i = t & (d - 1);
+        const typename F::storage *src = in + e * in_len;
+        typename F::elem lo = i < in_len ? F::load(src + i) : F::zero();
+        if (d + i < in_len) lo = F::sub(lo, F::load(src + d + i));
+        F::store(out + t, lo);
+    }
+}
+
+// tw[i] = psi^brv_k(i), itw[i] = psi^-brv_k(i) from psi^(2^j), psi^-(2^j)
+template <class F>
+__global__ void build_tables_kernel(typename F::elem *tw, typename F::elem *itw, int k,
+                                    const typename F::elem *pows, const typename F::elem *ipows) {
+    size_t d = (size_t)1 << k;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < d; i += (size_t)gridDim.x * blockDim.x) {
+        uint32_t r = bitrev((uint32_t)i, k);
+        typename F::elem acc = F::tw_one(), iacc = F::tw_one();
+        for (int j = 0; j < k; j++)
+            if ((r >> j) & 1u) {
+                acc = F::mul_tw(acc, pows[j]);
+                iacc = F::mul_tw(iacc, ipows[j]);
+            }
+        tw[i] = acc;
+        itw[i] = iacc;
+    }
+}
+
+// ---- synthetic inputs: same counter-based definition as oracle/sr_oracle.c sro_fill_uniform ----
+SR_HD uint64_t mix64(uint64_t z) {
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+SR_HD uint64_t prng_word(uint64_t seed, uint64_t idx, unsigned limb, unsigned retry) {
+    uint64_t x = mix64(seed + 0x9E3779B97F4A7C15ull * (idx + 1));
+    return mix64(x ^ (0xD1B54A32D192ED03ull * (uint64_t)(limb + 4 * retry + 1)));
+}
+template <class F>
+SR_HD void uniform_words(uint64_t seed, uint64_t idx, uint64_t *out);
+template <>
+SR_HD void uniform_words<Goldilocks>(uint64_t seed, uint64_t idx, uint64_t *out) {
+    uint64_t v = 0;
+    for (unsigned r = 0; r < 64; r++) {
+        v = prng_word(seed, idx, 0, r);
+        if (v < Goldilocks::P) break;
+        v = 0;
+    }
+    out[0] = v;
+}
+template <>
+SR_HD void uniform_words<BabyBear>(uint64_t seed, uint64_t idx, uint64_t *out) {
+    uint64_t v = 0;
+    for (unsigned r = 0; r < 64; r++) {
+        v = prng_word(seed, idx, 0, r) & 0x7FFFFFFFull;
+        if (v < BabyBear::P) break;
+        v = 0;
+    }
+    out[0] = v;
+}
+template <>
+SR_HD void uniform_words<Stark>(uint64_t seed, uint64_t idx, uint64_t *out) {
+    for (unsigned r = 0; r < 64; r++) {
+        uint64_t q[4];
+        for (unsigned l = 0; l < 4; l++) q[l] = prng_word(seed, idx, l, r);
+        q[3] &= 0x0FFFFFFFFFFFFFFFull;
+        // q < p ?  p = {1, 0, 0, 0x0800000000000011}
+        bool lt = q[3] < 0x0800000000000011ull ||
+                  (q[3] == 0x0800000000000011ull && q[2] == 0 && q[1] == 0 && q[0] < 1);
+        if (lt) {
+            for (int l = 0; l < 4; l++) out[l] = q[l];
+            return;
+        }
+    }
+    for (int l = 0; l < 4; l++) out[l] = 0;
+}
+template <class F>
+__global__ void fill_uniform_kernel(uint64_t seed, uint64_t first, size_t n, uint64_t *out) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        uint64_t w[4];
+        uniform_words<F>(seed, first + i, w);
+        for (int l = 0; l < F::kStorageWords64; l++) out[i * F::kStorageWords64 + l] = w[l];
+    }
+}
+template <class F>
+__global__ void count_noncanonical_kernel(const typename F::storage *d, size_t n, unsigned long long *count) {
+    unsigned long long bad = 0;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        if constexpr (std::is_same<F, BabyBear>::value) {
+            uint64_t raw = d[i];
+            bad += (raw >= BabyBear::P);
+        } else {
+            bad += !F::valid(F::load(d + i));
+        }
+    }
+    if (bad) atomicAdd(count, bad);
+}
+
+}  // namespace sr

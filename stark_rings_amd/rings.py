@@ -1,0 +1,224 @@
+"""Host-side mirror of the reference's ring interface, at batch granularity, over the C ABI.
+
+Reference surface mirrored (crates/ring/src/cyclotomic_ring/):
+  CyclotomicConfig<N>                      ring_config.rs:11-35   -> CyclotomicRing (one per ring + degree)
+    reduce_in_place                        ring_config.rs:23      -> CyclotomicRing.reduce
+    crt_in_place / crt                     ring_config.rs:27,29   -> CyclotomicRing.elementwise_crt
+    icrt_in_place / icrt                   ring_config.rs:30,34   -> CyclotomicRing.elementwise_icrt
+  CRT::elementwise_crt / ICRT::elementwise_icrt   crt.rs:10-25, 34-49 (in place, same allocation)
+  RqNTT * RqNTT (MulAssign)                ntt_form.rs:159-225    -> CyclotomicRing.ntt_mul
+  RqPoly * RqPoly                          coeff_form.rs:250-258  -> CyclotomicRing.mul
+  Flatten::flatten_to_coeffs / promote_from_coeffs   flatten.rs:10-34 -> same names
+
+Buffers are numpy uint64 arrays (host entry points) or torch uint64/int64 CUDA tensors (device
+entry points), in the reference's in-memory layout: element-major, D coefficients per element,
+N little-endian u64 limbs per coefficient, Montgomery residues.
+
+Errors: the reference panics on wrong lengths (e.g. goldilocks/ntt.rs:136); here RingError is raised.
+"""
+import ctypes
+
+import numpy as np
+
+from . import _lib
+
+GOLDILOCKS_POW2, BABYBEAR_POW2, STARK_POW2, GOLDILOCKS_24, BABYBEAR_72 = 0, 1, 2, 3, 4
+PROF_TAGS = ("fwd_cols", "rows", "inv_cols", "pointwise", "other")
+
+_RING_NAMES = {
+    "goldilocks": GOLDILOCKS_POW2,
+    "babybear": BABYBEAR_POW2,
+    "stark": STARK_POW2,
+    "goldilocks24": GOLDILOCKS_24,
+    "babybear72": BABYBEAR_72,
+}
+
+
+class RingError(RuntimeError):
+    pass
+
+
+def _np_ptr(a):
+    if not (isinstance(a, np.ndarray) and a.dtype == np.uint64 and a.flags["C_CONTIGUOUS"]):
+        raise RingError("expected a C-contiguous numpy uint64 array")
+    return a.ctypes.data_as(_lib.u64p)
+
+
+class CyclotomicRing:
+    """One ring configuration bound to one HIP device (the analogue of a `CyclotomicConfig` impl)."""
+
+    def __init__(self, ring, log2_degree=0, device=0):
+        if isinstance(ring, str):
+            ring = _RING_NAMES[ring]
+        self._lib = _lib.load()
+        self._ctx = ctypes.c_void_p()
+        rc = self._lib.sr_ctx_create(int(ring), int(log2_degree), int(device), ctypes.byref(self._ctx))
+        if rc != 0:
+            self._ctx = None
+            raise RingError("sr_ctx_create failed (%d): %s" % (rc, _lib.last_error()))
+        self.ring = int(ring)
+        self.device = int(device)
+        d = ctypes.c_size_t()
+        l = ctypes.c_int()
+        self._check(self._lib.sr_ctx_degree(self._ctx, ctypes.byref(d)))
+        self._check(self._lib.sr_ctx_limbs(self._ctx, ctypes.byref(l)))
+        self.degree = d.value          # PolyRing::dimension()
+        self.limbs = l.value           # N
+        self.words_per_elem = self.degree * self.limbs
+
+    # -- lifetime --------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_ctx", None):
+            self._lib.sr_ctx_destroy(self._ctx)
+            self._ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc != 0:
+            raise RingError("stark_rings_hip call failed (%d): %s" % (rc, _lib.last_error()))
+
+    def _batch_of(self, arr_words):
+        if arr_words % self.words_per_elem != 0:
+            # promote_from_coeffs returns None in the reference (flatten.rs:22-24); transforms panic
+            raise RingError("buffer length %d is not a multiple of D*N = %d" % (arr_words, self.words_per_elem))
+        return arr_words // self.words_per_elem
+
+    # -- Flatten (flatten.rs:10-34): zero-copy views ---------------------------------------------
+    def flatten_to_coeffs(self, elems):
+        """(batch, D[, N]) -> flat view of batch*D coefficients."""
+        return elems.reshape(-1, self.limbs) if self.limbs > 1 else elems.reshape(-1)
+
+    def promote_from_coeffs(self, flat):
+        """flat coefficients -> (batch, D[, N]) view, or None if the length is not a multiple of D."""
+        n = flat.size if isinstance(flat, np.ndarray) else flat.numel()
+        if n % self.words_per_elem != 0:
+            return None
+        shape = (n // self.words_per_elem, self.degree) + ((self.limbs,) if self.limbs > 1 else ())
+        return flat.reshape(shape)
+
+    # -- host-buffer API (numpy) -----------------------------------------------------------
+    def elementwise_crt(self, data):
+        """CRT::elementwise_crt (crt.rs:10-25): in place on a numpy uint64 buffer."""
+        self._check(self._lib.sr_ntt_fwd_batch(self._ctx, _np_ptr(data), self._batch_of(data.size)))
+        return data
+
+    def elementwise_icrt(self, data):
+        """ICRT::elementwise_icrt (crt.rs:34-49): in place."""
+        self._check(self._lib.sr_ntt_inv_batch(self._ctx, _np_ptr(data), self._batch_of(data.size)))
+        return data
+
+    def ntt_mul(self, lhs, rhs):
+        """lhs *= rhs slot-wise in CRT form (ntt_form.rs:213-225), in place on lhs."""
+        if lhs.size != rhs.size:
+            raise RingError("operand lengths differ")
+        self._check(self._lib.sr_pointwise_mul_batch(self._ctx, _np_ptr(lhs), _np_ptr(rhs), self._batch_of(lhs.size)))
+        return lhs
+
+    def mul(self, a, b, out=None):
+        """Coefficient-form product a * b (coeff_form.rs:250-258) via icrt(crt(a) * crt(b))."""
+        if a.size != b.size:
+            raise RingError("operand lengths differ")
+        if out is None:
+            out = np.empty_like(a)
+        self._check(self._lib.sr_ring_mul_batch(self._ctx, _np_ptr(out), _np_ptr(a), _np_ptr(b), self._batch_of(a.size)))
+        return out
+
+    def reduce(self, coeffs, in_len_per_elem, batch):
+        """CyclotomicConfig::reduce_in_place (ring_config.rs:23): (batch, in_len) -> (batch, D)."""
+        if coeffs.size != batch * in_len_per_elem * self.limbs:
+            raise RingError("reduce: buffer length does not match batch * in_len")
+        out = np.empty(batch * self.words_per_elem, dtype=np.uint64)
+        src = coeffs if coeffs.size else np.zeros(1, dtype=np.uint64)
+        self._check(self._lib.sr_reduce_batch(self._ctx, _np_ptr(src), in_len_per_elem, _np_ptr(out), batch))
+        return out
+
+    # -- device-resident API (torch CUDA tensors of 8-byte integers) --------------------------
+    @staticmethod
+    def _dev(t):
+        import torch
+
+        if not (t.is_cuda and t.is_contiguous() and t.element_size() == 8):
+            raise RingError("expected a contiguous CUDA tensor of 8-byte integers")
+        return ctypes.c_void_p(t.data_ptr()), t.numel()
+
+    @staticmethod
+    def _stream(stream):
+        import torch
+
+        s = stream if stream is not None else torch.cuda.current_stream()
+        return ctypes.c_void_p(s.cuda_stream)
+
+    def elementwise_crt_dev(self, t, stream=None):
+        p, n = self._dev(t)
+        self._check(self._lib.sr_ntt_fwd_batch_dev(self._ctx, p, self._batch_of(n), self._stream(stream)))
+        return t
+
+    def elementwise_icrt_dev(self, t, stream=None):
+        p, n = self._dev(t)
+        self._check(self._lib.sr_ntt_inv_batch_dev(self._ctx, p, self._batch_of(n), self._stream(stream)))
+        return t
+
+    def ntt_mul_dev(self, lhs, rhs, stream=None):
+        pl, n = self._dev(lhs)
+        pr, m = self._dev(rhs)
+        if n != m:
+            raise RingError("operand lengths differ")
+        self._check(self._lib.sr_pointwise_mul_batch_dev(self._ctx, pl, pr, self._batch_of(n), self._stream(stream)))
+        return lhs
+
+    def mul_dev(self, out, a, b, stream=None):
+        """out = a * b; b is clobbered (holds crt(b)) when D exceeds one LDS tile; out may be a."""
+        po, n = self._dev(out)
+        pa, m = self._dev(a)
+        pb, q = self._dev(b)
+        if not (n == m == q):
+            raise RingError("operand lengths differ")
+        self._check(self._lib.sr_ring_mul_batch_dev(self._ctx, po, pa, pb, self._batch_of(n), self._stream(stream)))
+        return out
+
+    def reduce_dev(self, out, coeffs, in_len_per_elem, stream=None):
+        po, n = self._dev(out)
+        pi, m = self._dev(coeffs)
+        batch = self._batch_of(n)
+        if m != batch * in_len_per_elem * self.limbs:
+            raise RingError("reduce: buffer length does not match batch * in_len")
+        self._check(self._lib.sr_reduce_batch_dev(self._ctx, pi, in_len_per_elem, po, batch, self._stream(stream)))
+        return out
+
+    def fill_uniform_dev(self, t, seed, first_coeff=0, stream=None):
+        p, n = self._dev(t)
+        if n % self.limbs:
+            raise RingError("buffer is not a whole number of coefficients")
+        self._check(self._lib.sr_fill_uniform_dev(self._ctx, seed, first_coeff, n // self.limbs, p, self._stream(stream)))
+        return t
+
+    def count_noncanonical_dev(self, t, stream=None):
+        p, n = self._dev(t)
+        c = ctypes.c_uint64()
+        self._check(self._lib.sr_count_noncanonical_dev(self._ctx, p, n // self.limbs, ctypes.byref(c), self._stream(stream)))
+        return c.value
+
+    # -- twiddle sharing across GPUs (one RCCL broadcast at start-up) -------------------------
+    def twiddle_block(self):
+        p = ctypes.c_void_p()
+        n = ctypes.c_size_t()
+        self._check(self._lib.sr_ctx_twiddle_block(self._ctx, ctypes.byref(p), ctypes.byref(n)))
+        return p.value, n.value
+
+    def twiddles_updated(self):
+        self._check(self._lib.sr_ctx_twiddles_updated(self._ctx))
+
+    # -- per-kernel timing --------------------------------------------------------------------
+    def profile_enable(self, on=True):
+        self._check(self._lib.sr_ctx_profile_enable(self._ctx, 1 if on else 0))
+
+    def profile_read(self):
+        ms = (ctypes.c_double * len(PROF_TAGS))()
+        n = (ctypes.c_uint64 * len(PROF_TAGS))()
+        self._check(self._lib.sr_ctx_profile_read(self._ctx, ms, n))
+        return {t: {"ms": ms[i], "launches": int(n[i])} for i, t in enumerate(PROF_TAGS)}

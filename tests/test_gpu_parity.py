@@ -1,0 +1,160 @@
+"""GPU parity tests: the HIP path (through the C ABI) vs the oracle, bit-exact.
+
+Shapes follow the reference's tests: literal KATs (stark_prime/ntt.rs:377-545), crt/icrt round trips
+(crt.rs:85-147), NTT-mul == schoolbook (stark_prime/mod.rs:161-177), crt(1) = 1 (mod.rs:125-137),
+reduce (mod.rs:139-159), plus ragged/edge batches.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+import oracle_lib as O
+import pyref as P
+
+I = lambda v: [int(x) for x in v]
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    return torch
+
+
+_rings = {}
+
+
+def ring_for(name, k):
+    from stark_rings_amd import CyclotomicRing
+
+    key = (name, k)
+    if key not in _rings:
+        _rings[key] = CyclotomicRing(name, k, device=0)
+    return _rings[key]
+
+
+def edge_and_random(F, k, batch, seed):
+    """batch elements: all-zero, all-(p-1), 1, X^(D-1), then uniform."""
+    name = [n for n, f in O.FIELD_ID.items() if f == F][0]
+    p = P.PRIMES[name][0]
+    L = O.LIMBS[F]
+    d = 1 << k
+    data = O.fill_uniform(F, seed, 0, batch * d).reshape(batch, d * L)
+    specials = []
+    specials.append([0] * d)
+    specials.append([p - 1] * d)
+    specials.append([1] + [0] * (d - 1))
+    specials.append([0] * (d - 1) + [1])
+    for i, s in enumerate(specials):
+        if i < batch:
+            data[i] = O.to_mont(F, s)
+    return np.ascontiguousarray(data.reshape(-1))
+
+
+CASES = [("goldilocks", k) for k in (0, 1, 2, 5, 10, 12, 13, 16)] + \
+        [("babybear", k) for k in (0, 1, 4, 10, 12, 14)] + \
+        [("stark", k) for k in (0, 1, 4, 8, 10, 12)]
+
+
+@pytest.mark.parametrize("name,k", CASES)
+def test_host_api_fwd_inv_mul_match_oracle(torch_cuda, name, k):
+    F = O.FIELD_ID[name]
+    ring = ring_for(name, k)
+    batch = 5 if k >= 12 else 37   # ragged: not a multiple of anything convenient
+    a = edge_and_random(F, k, batch, 0xA0 + k)
+    b = edge_and_random(F, k, batch, 0xB0 + k)[::-1].copy() if False else O.fill_uniform(F, 0xB0 + k, 0, batch << k)
+    fa = ring.elementwise_crt(a.copy())
+    assert np.array_equal(fa, O.pow2_fwd(F, a, k, batch)), "crt mismatch"
+    assert np.array_equal(ring.elementwise_icrt(fa.copy()), a), "icrt(crt(x)) != x"
+    assert np.array_equal(ring.elementwise_icrt(b.copy()), O.pow2_inv(F, b, k, batch)), "icrt mismatch"
+    fb = O.pow2_fwd(F, b, k, batch)
+    assert np.array_equal(ring.ntt_mul(fa.copy(), fb), O.pow2_pointwise(F, fa, fb)), "slot product mismatch"
+    assert np.array_equal(ring.mul(a, b), O.pow2_ring_mul(F, a, b, k, batch, 4)), "ring mul mismatch"
+
+
+@pytest.mark.parametrize("name,k", [("goldilocks", 16), ("goldilocks", 13), ("babybear", 16), ("stark", 12), ("stark", 4)])
+def test_device_api_matches_oracle(torch_cuda, name, k):
+    torch = torch_cuda
+    F = O.FIELD_ID[name]
+    ring = ring_for(name, k)
+    batch = 3
+    n = batch << k
+    a = O.fill_uniform(F, 1, 0, n)
+    b = O.fill_uniform(F, 2, 0, n)
+    ta = torch.from_numpy(a.view(np.int64)).cuda()
+    tb = torch.from_numpy(b.view(np.int64)).cuda()
+    # device generator == oracle generator
+    tg = torch.empty_like(ta)
+    ring.fill_uniform_dev(tg, 1, 0)
+    assert np.array_equal(tg.cpu().numpy().view(np.uint64), a)
+    assert ring.count_noncanonical_dev(tg) == 0
+    out = torch.empty_like(ta)
+    ring.mul_dev(out, ta, tb)
+    torch.cuda.synchronize()
+    assert np.array_equal(out.cpu().numpy().view(np.uint64), O.pow2_ring_mul(F, a, b, k, batch, 4))
+    # a is untouched
+    assert np.array_equal(ta.cpu().numpy().view(np.uint64), a)
+    # in place (out aliases a)
+    tb2 = torch.from_numpy(b.view(np.int64)).cuda()
+    ring.mul_dev(ta, ta, tb2)
+    assert torch.equal(ta, out)
+
+
+def test_stark16_reference_kats_on_gpu(torch_cuda, kats):
+    # stark_prime/ntt.rs:377-545 through the C ABI (SR_RING_STARK_POW2, log2_degree = 4)
+    F = O.STARK
+    ring = ring_for("stark", 4)
+    for k in kats["stark16"]["kats"]:
+        c, e = I(k["coeffs"]), I(k["evals"])
+        assert O.from_mont(F, ring.elementwise_crt(O.to_mont(F, c))) == e, k["name"]
+        assert O.from_mont(F, ring.elementwise_icrt(O.to_mont(F, e))) == c, k["name"]
+
+
+@pytest.mark.parametrize("name", ["goldilocks", "babybear", "stark"])
+def test_crt_of_one_and_mul_equals_schoolbook(torch_cuda, name):
+    F = O.FIELD_ID[name]
+    k = 6
+    d = 1 << k
+    ring = ring_for(name, k)
+    one = O.to_mont(F, [1] + [0] * (d - 1))
+    assert O.from_mont(F, ring.elementwise_crt(one.copy())) == [1] * d
+    a = O.fill_uniform(F, 5, 0, d)
+    b = O.fill_uniform(F, 6, 0, d)
+    sb = O.schoolbook(F, a, b, d)
+    red = ring.reduce(sb, 2 * d - 1, 1)
+    assert np.array_equal(red, O.pow2_reduce(F, sb, 2 * d - 1, k))
+    assert np.array_equal(ring.mul(a, b), red)
+
+
+@pytest.mark.parametrize("name", ["goldilocks", "babybear", "stark"])
+def test_reduce_ragged_lengths(torch_cuda, name):
+    F = O.FIELD_ID[name]
+    L = O.LIMBS[F]
+    k = 4
+    d = 16
+    ring = ring_for(name, k)
+    for in_len in (0, 1, 15, 16, 17, 31, 32):
+        batch = 3
+        src = O.fill_uniform(F, 9 + in_len, 0, batch * in_len) if in_len else np.zeros(0, dtype=np.uint64)
+        got = ring.reduce(src, in_len, batch)
+        for e in range(batch):
+            want = O.pow2_reduce(F, src[e * in_len * L:(e + 1) * in_len * L] if in_len else np.zeros(1, dtype=np.uint64), in_len, k)
+            assert np.array_equal(got[e * d * L:(e + 1) * d * L], want), (in_len, e)
+
+
+def test_errors(torch_cuda):
+    from stark_rings_amd import CyclotomicRing, RingError
+
+    ring = ring_for("goldilocks", 4)
+    with pytest.raises(RingError):
+        ring.elementwise_crt(np.zeros(17, dtype=np.uint64))  # not a multiple of D ("Wrong length")
+    with pytest.raises(RingError):
+        ring.reduce(np.zeros(33, dtype=np.uint64), 33, 1)     # more than 2D coefficients
+    with pytest.raises(RingError):
+        CyclotomicRing("goldilocks", 40)
+    with pytest.raises(RingError):
+        CyclotomicRing("babybear", 27)                         # 2D-th roots need 2-adicity >= k+1
+    empty = np.zeros(0, dtype=np.uint64)
+    assert ring.elementwise_crt(empty).size == 0               # empty batch is a no-op
