@@ -55,6 +55,13 @@ def load():
                 "%s not found: run `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(hipcc --offload-arch=gfx950).  There is no CPU fallback." % LIB_PATH
             )
+        # PyTorch-ROCm ships its own libamdhip64.so.7 / libhsa-runtime64; two HIP runtimes in one process
+        # cannot both own the device.  Import torch first (when present) so that our DT_NEEDED
+        # libamdhip64.so.7 resolves to the runtime torch already loaded.
+        try:
+            import torch  # noqa: F401
+        except Exception:  # pragma: no cover - plain C users run without torch
+            pass
         lib = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(lib, name)  # AttributeError if the header and the library ever diverge

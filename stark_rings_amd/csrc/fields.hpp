@@ -76,6 +76,9 @@ struct Goldilocks {
     }
     SR_HD static elem tw_from_u64(uint64_t x) { return x % P; }
     SR_HD static elem tw_one() { return 1; }
+    // sum-of-products helper: sum_i pre(a_i, b_i), then post() once == sum_i mul_boundary(a_i, b_i)
+    SR_HD static elem mul_boundary_pre(elem a, elem b) { return mul_boundary(a, b); }
+    SR_HD static elem boundary_post(elem x) { return x; }
 
     // LDS accessors: array of u64
     SR_HD static elem lds_get(const uint32_t *lds, int idx, int) {
@@ -127,6 +130,8 @@ struct BabyBear {
     SR_HD static elem mul_boundary(elem a, elem b) { return mont32(mont32(a, b), 1u); }
     SR_HD static elem tw_from_u64(uint64_t x) { return mont32((uint32_t)(x % P), R2); }
     SR_HD static elem tw_one() { return tw_from_u64(1); }
+    SR_HD static elem mul_boundary_pre(elem a, elem b) { return mont32(a, b); }
+    SR_HD static elem boundary_post(elem x) { return mont32(x, 1u); }
 
     SR_HD static elem lds_get(const uint32_t *lds, int idx, int) { return lds[idx]; }
     SR_HD static void lds_put(uint32_t *lds, int idx, int, elem v) { lds[idx] = v; }

@@ -158,3 +158,74 @@ def test_errors(torch_cuda):
         CyclotomicRing("babybear", 27)                         # 2D-th roots need 2-adicity >= k+1
     empty = np.zeros(0, dtype=np.uint64)
     assert ring.elementwise_crt(empty).size == 0               # empty batch is a no-op
+
+
+# ----------------------------------------------------------------------------- reference-native small rings
+def _small(name):
+    if name == "goldilocks24":
+        return O.GOLDILOCKS, 24, "sro_g24_", P.g24_reduce
+    return O.BABYBEAR, 72, "sro_bb72_", P.bb72_reduce
+
+
+def test_goldilocks24_reference_kats_on_gpu(torch_cuda, kats):
+    # goldilocks/ntt.rs:563-787: crt then dehomogenize == literal residues; homogenize then icrt == coefficients
+    F = O.GOLDILOCKS
+    ring = ring_for("goldilocks24", 0)
+    for k in kats["goldilocks24"]["kats"]:
+        c, r = I(k["coeffs"]), I(k["residues"])
+        got = ring.elementwise_crt(O.to_mont(F, c))
+        assert O.from_mont(F, O.small("sro_g24_dehomogenize", got)) == r, k["name"]
+        got = ring.elementwise_icrt(O.small("sro_g24_homogenize", O.to_mont(F, r)))
+        assert O.from_mont(F, got) == c, k["name"]
+
+
+def test_babybear72_reference_kat_on_gpu(torch_cuda, kats):
+    # babybear/ntt.rs:866-1019
+    F = O.BABYBEAR
+    ring = ring_for("babybear72", 0)
+    for k in kats["babybear72"]["kats"]:
+        c, r = I(k["coeffs"]), I(k["residues"])
+        got = ring.elementwise_icrt(O.small("sro_bb72_homogenize", O.to_mont(F, r)))
+        assert O.from_mont(F, got) == c
+        got = ring.elementwise_crt(O.to_mont(F, c))
+        assert O.from_mont(F, O.small("sro_bb72_dehomogenize", got)) == r
+
+
+@pytest.mark.parametrize("name", ["goldilocks24", "babybear72"])
+def test_small_rings_match_oracle(torch_cuda, name):
+    F, D, pre, pyreduce = _small(name)
+    ring = ring_for(name, 0)
+    batch = 301  # ragged vs the 64-lane workgroups
+    a = O.fill_uniform(F, 21, 0, batch * D)
+    b = O.fill_uniform(F, 22, 0, batch * D)
+    p = P.PRIMES["goldilocks" if D == 24 else "babybear"][0]
+    a[:D] = O.to_mont(F, [0] * D)
+    a[D:2 * D] = O.to_mont(F, [p - 1] * D)
+    a[2 * D:3 * D] = O.to_mont(F, [1] + [0] * (D - 1))
+    ca = ring.elementwise_crt(a.copy())
+    want_ca = O.small(pre + "crt", a)
+    assert np.array_equal(ca, want_ca)
+    # crt(1) = 1: goldilocks/mod.rs:179-191
+    W = D // 8
+    assert O.from_mont(F, ca[2 * D:3 * D]) == ([1] + [0] * (W - 1)) * 8
+    assert np.array_equal(ring.elementwise_icrt(ca.copy()), a)               # crt.rs:85-147 round trip
+    assert np.array_equal(ring.elementwise_icrt(b.copy()), O.small(pre + "icrt", b))
+    cb = O.small(pre + "crt", b)
+    prod = ring.ntt_mul(ca.copy(), cb)
+    assert np.array_equal(prod, O.small(pre + "ntt_mul", want_ca, cb))     # Fq3 / Fq9 slot products
+    want = O.small(pre + "icrt", prod)
+    assert np.array_equal(ring.mul(a, b), want)                            # fused ring product
+    # test_mul_crt (goldilocks/mod.rs:231-247): NTT product == schoolbook product reduced mod Phi
+    for e in (3, 17, 300):
+        sb = O.schoolbook(F, a[e * D:(e + 1) * D], b[e * D:(e + 1) * D], D)
+        red = ring.reduce(sb, 2 * D - 1, 1)
+        assert np.array_equal(red, want[e * D:(e + 1) * D])
+        std = O.from_mont(F, sb)
+        assert O.from_mont(F, red) == pyreduce(std)
+    # ragged reduce lengths (reduce_in_place uses .get(..).unwrap_or(ZERO))
+    for in_len in (0, 5, D, D + 3, 2 * D - 1, 2 * D):
+        src = O.fill_uniform(F, 77 + in_len, 0, 2 * in_len) if in_len else np.zeros(0, dtype=np.uint64)
+        got = ring.reduce(src, in_len, 2)
+        for e in range(2):
+            std = O.from_mont(F, src[e * in_len:(e + 1) * in_len]) if in_len else []
+            assert O.from_mont(F, got[e * D:(e + 1) * D]) == pyreduce(std), (in_len, e)
