@@ -1,0 +1,217 @@
+#!/usr/bin/env python3
+"""Headline benchmark: batched ring multiplications c = a * b in Fp[X]/(X^D+1) on MI355X.
+
+  python bench.py --gpus N --steps K --warmup W            (N = 1)
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...   (N > 1)
+
+One "step" = one pass of the hot path (forward NTT x2, slot product, inverse NTT) over one batch of
+synthetic coefficient vectors already resident in HBM.  Default workload = BASELINE.json configs[1]:
+Goldilocks, D = 2^16, batch = 2^14 per GPU (weak scaling: the batch shards by element, no data-path
+collective; the only collective is one RCCL broadcast of the twiddle block at start-up).
+
+Prints ONE JSON line on rank 0 (contract in the task description) with `roofline` (dominant kernel, HIP
+events on the launch stream) and `cpu_baseline` (the oracle -- a C restatement of the reference's CPU
+path -- timed on this host's cores over a bounded sample; rank 0, N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (ROOT, os.path.join(ROOT, "oracle")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+WORKLOADS = {
+    # name: (ring, log2 D, batch per GPU, bytes per coefficient)
+    "goldilocks_d65536_b16384": ("goldilocks", 16, 1 << 14, 8),   # BASELINE configs[1] (metric config)
+    "babybear_d65536_b16384": ("babybear", 16, 1 << 14, 8),       # configs[2], reference 8-byte layout
+    "goldilocks_d1048576_b8192": ("goldilocks", 20, 1 << 13, 8),  # configs[3] per-GPU shard (2^16 / 8)
+    "stark_d4096_b4096": ("stark", 12, 1 << 12, 32),              # configs[4]
+    "goldilocks_d1024_b1": ("goldilocks", 10, 1, 8),              # configs[0] plumbing
+}
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+
+
+class _DevMem:
+    """Zero-copy torch view of device memory owned by the C library (__cuda_array_interface__)."""
+
+    def __init__(self, ptr, nbytes):
+        self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr, False), "version": 2}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="goldilocks_d65536_b16384", choices=sorted(WORKLOADS))
+    ap.add_argument("--batch", type=int, default=0, help="override the per-GPU batch (debug only)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    from stark_rings_amd import CyclotomicRing
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, "WORLD_SIZE (%d) != --gpus (%d)" % (world, args.gpus)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    ring_name, k, batch, coeff_bytes = WORKLOADS[args.workload]
+    if args.batch:
+        batch = args.batch
+    d = 1 << k
+    ring = CyclotomicRing(ring_name, k, device=local_rank)
+    words = batch * ring.words_per_elem
+
+    # ---- shared twiddles: rank 0's tables broadcast once over RCCL/xGMI, adopted by every rank ----
+    if world > 1:
+        ptr, nbytes = ring.twiddle_block()
+        tw = torch.as_tensor(_DevMem(ptr, nbytes), device=dev)
+        if rank != 0:
+            tw.zero_()  # prove the tables really come from rank 0
+        dist.broadcast(tw, src=0)
+        torch.cuda.synchronize()
+        ring.twiddles_updated()
+
+    # ---- synthetic inputs generated on device (counter-based PRNG; rank-disjoint coefficient ranges) ----
+    a = torch.empty(words, dtype=torch.int64, device=dev)
+    b = torch.empty(words, dtype=torch.int64, device=dev)
+    first = rank * batch * d
+    ring.fill_uniform_dev(a, 0x5EED0001, first)
+    ring.fill_uniform_dev(b, 0x5EED0002, first)
+    torch.cuda.synchronize()
+
+    # ---- parity gate: one untimed step, sampled elements checked bit-for-bit against the oracle ----
+    import oracle_lib as O
+
+    F = O.FIELD_ID[ring_name]
+    ring.mul_dev(a, a, b)
+    torch.cuda.synchronize()
+    sample = sorted({0, batch // 3, batch - 1})
+    wpe = ring.words_per_elem
+    for e in sample:
+        ea = O.fill_uniform(F, 0x5EED0001, first + e * d, d)
+        eb = O.fill_uniform(F, 0x5EED0002, first + e * d, d)
+        want = O.pow2_ring_mul(F, ea, eb, k)
+        got = a[e * wpe:(e + 1) * wpe].cpu().numpy().view(np.uint64)
+        if not np.array_equal(got, want):
+            raise SystemExit("PARITY FAILURE rank %d element %d: GPU result differs from the oracle" % (rank, e))
+    assert ring.count_noncanonical_dev(a) == 0, "non-canonical outputs"
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        ring.mul_dev(a, a, b)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        ring.mul_dev(a, a, b)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # ---- per-kernel durations over the same K steps, HIP events on the launch stream ----
+    ring.profile_enable(True)
+    for _ in range(args.steps):
+        ring.mul_dev(a, a, b)
+    torch.cuda.synchronize()
+    prof = ring.profile_read()
+    ring.profile_enable(False)
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    total_muls = world * batch * args.steps
+    value = total_muls / elapsed
+    bytes_per_mul = 3 * d * coeff_bytes  # read a, read b, write c
+    kern = {t: v for t, v in prof.items() if v["launches"]}
+    dom_tag = max(kern, key=lambda t: kern[t]["ms"])
+    dom = kern[dom_tag]
+    launches_per_step = dom["launches"] / args.steps
+    dom_avg_ms = dom["ms"] / dom["launches"]
+    # algorithmic bytes one launch of the dominant kernel is responsible for: the whole batch's 3*D*w,
+    # split over the launches of that kernel in one step
+    alg_bytes_per_launch = bytes_per_mul * batch / launches_per_step
+    achieved_gbs = alg_bytes_per_launch / (dom_avg_ms * 1e-3) / 1e9
+    step_gbs = bytes_per_mul * batch * world / (elapsed / args.steps) / 1e9 / world
+
+    out = {
+        "metric": "ring-muls/sec (Goldilocks, deg 2^16, batch 2^14)" if args.workload == "goldilocks_d65536_b16384"
+                  else "ring-muls/sec (%s)" % args.workload,
+        "value": value,
+        "unit": "ring-muls/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "u64" if ring_name != "stark" else "u256",
+        "data": "synthetic",
+        "config": {"workload": args.workload, "ring": ring_name, "degree": d, "batch_per_gpu": batch,
+                   "global_batch": batch * world, "layout": "ark-ff Montgomery u64 limbs, in place (a *= b)",
+                   "parallelism": "batch-sharded x%d, twiddle broadcast only" % world},
+        "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": None,
+                     "kernel": dom_tag, "kernel_avg_ms": dom_avg_ms, "launches_per_step": launches_per_step,
+                     "algorithmic_bytes_per_ring_mul": bytes_per_mul,
+                     "whole_step_achieved_per_gpu": step_gbs, "whole_step_frac": step_gbs / HBM_PEAK_GBS,
+                     "per_kernel_ms_per_step": {t: v["ms"] / args.steps for t, v in kern.items()}},
+    }
+
+    if world == 1 and not args.no_cpu_baseline:
+        cores = os.cpu_count() or 1
+        n0 = max(cores, 8)
+        ea = O.fill_uniform(F, 1, 0, n0 * d)
+        eb = O.fill_uniform(F, 2, 0, n0 * d)
+        t1 = time.perf_counter()
+        O.pow2_ring_mul(F, ea, eb, k, n0, cores)
+        probe = time.perf_counter() - t1
+        n = int(min(max(n0, n0 * args.cpu_seconds / max(probe, 1e-6)), 1 << 15))
+        n = max(cores, (n // cores) * cores)
+        ea = O.fill_uniform(F, 1, 0, n * d)
+        eb = O.fill_uniform(F, 2, 0, n * d)
+        t1 = time.perf_counter()
+        O.pow2_ring_mul(F, ea, eb, k, n, cores)
+        cpu_t = time.perf_counter() - t1
+        t1 = time.perf_counter()
+        n1 = max(1, n // cores // 4)
+        O.pow2_ring_mul(F, ea[:n1 * ring.words_per_elem], eb[:n1 * ring.words_per_elem], k, n1, 1)
+        cpu_t1 = time.perf_counter() - t1
+        out["cpu_baseline"] = {
+            "value": n / cpu_t, "unit": "ring-muls/s", "cores": cores, "kind": "port",
+            "sample": "%d ring-muls of the same workload (D=2^%d), %d pthreads over the batch, %.1f s; "
+                      "C restatement of the reference CPU path (oracle/sr_oracle.c), not the Rust binary" % (n, k, cores, cpu_t),
+            "single_thread_value": n1 / cpu_t1,
+        }
+        out["gpu_over_cpu"] = value / (n / cpu_t)
+    print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -106,6 +106,23 @@ struct ProfScope {
     }
 };
 
+// timing hooks handed to the tuned Goldilocks launcher (tags: 0 strided fwd, 1 rows, 2 strided inv)
+void gl_prof_begin(void *user, int tag, hipStream_t st) {
+    sr_ctx *c = (sr_ctx *)user;
+    if (!c->prof.on) return;
+    Prof::Pair p;
+    (void)hipEventCreate(&p.a);
+    (void)hipEventCreate(&p.b);
+    p.tag = tag == 0 ? K_FWD_COLS : (tag == 1 ? K_ROWS : K_INV_COLS);
+    (void)hipEventRecord(p.a, st);
+    c->prof.pending.push_back(p);
+}
+void gl_prof_end(void *user, hipStream_t st) {
+    sr_ctx *c = (sr_ctx *)user;
+    if (!c->prof.on || c->prof.pending.empty()) return;
+    (void)hipEventRecord(c->prof.pending.back().b, st);
+}
+
 template <class F>
 void exponent_pm1_shift(int shift, uint64_t out[4]);  // (p-1) >> shift
 template <>
@@ -173,7 +190,9 @@ int init_pow2(sr_ctx *c) {
     c->log_tile = default_log_tile<F>();
     if (k > 2 * c->log_tile) return fail(SR_E_INVALID, "log2_degree too large for the two-level kernels");
     const size_t d = c->degree;
-    c->table_bytes = 2 * d * sizeof(E);
+    size_t extra = 0;
+    if constexpr (std::is_same<F, sr::Goldilocks>::value) extra = sr::gl_fast_extra_bytes(k);
+    c->table_bytes = 2 * d * sizeof(E) + extra;
     HIP_TRY(hipMalloc(&c->tables, c->table_bytes));
 
     // psi = g^((p-1)/2D)  (equals ROOTS_OF_UNITY_32[1] for Stark, D = 16)
@@ -215,6 +234,13 @@ int init_pow2(sr_ctx *c) {
     memcpy(c->inv_scale1, &s1, sizeof(E));
     memcpy(c->mul_scale0, &m0, sizeof(E));
     memcpy(c->mul_scale1, &m1, sizeof(E));
+    if constexpr (std::is_same<F, sr::Goldilocks>::value) {
+        // tuned-path tables live right behind [tw | itw] so one broadcast of the block ships everything
+        if (sr::gl_fast_init(c->gl_fast, k, (const uint64_t *)tw, (const uint64_t *)itw, (uint64_t *)(itw + d),
+                             (const uint64_t *)pows.data(), (const uint64_t *)ipows.data(), (uint64_t)dinv,
+                             (uint64_t)fused, c->stream))
+            return fail(SR_E_HIP, "goldilocks fast-path table build failed");
+    }
     return SR_OK;
 }
 
@@ -390,7 +416,6 @@ int dev_fwd(sr_ctx *c, uint64_t *d, size_t batch, hipStream_t st) {
     if (c->ring == SR_RING_GOLDILOCKS_24) return sr::small_launch(c->small, sr::SMALL_G24_CRT, d, nullptr, 0, d, batch, st) ? fail(SR_E_HIP, "small-ring launch failed") : SR_OK;
     if (c->ring == SR_RING_BABYBEAR_72) return sr::small_launch(c->small, sr::SMALL_B72_CRT, d, nullptr, 0, d, batch, st) ? fail(SR_E_HIP, "small-ring launch failed") : SR_OK;
     if (c->ring == SR_RING_GOLDILOCKS_POW2 && c->fast_goldilocks && sr::gl_fast_supported(c->gl_fast)) {
-        ProfScope ps(c, st, K_ROWS);
         return sr::gl_fast_fwd(c->gl_fast, d, batch, st) ? fail(SR_E_HIP, "goldilocks fast-path launch failed") : SR_OK;
     }
     DISPATCH_POW2(c, (fwd_dev<F>(c, d, batch, st)));
@@ -399,7 +424,6 @@ int dev_inv(sr_ctx *c, uint64_t *d, size_t batch, hipStream_t st) {
     if (c->ring == SR_RING_GOLDILOCKS_24) return sr::small_launch(c->small, sr::SMALL_G24_ICRT, d, nullptr, 0, d, batch, st) ? fail(SR_E_HIP, "small-ring launch failed") : SR_OK;
     if (c->ring == SR_RING_BABYBEAR_72) return sr::small_launch(c->small, sr::SMALL_B72_ICRT, d, nullptr, 0, d, batch, st) ? fail(SR_E_HIP, "small-ring launch failed") : SR_OK;
     if (c->ring == SR_RING_GOLDILOCKS_POW2 && c->fast_goldilocks && sr::gl_fast_supported(c->gl_fast)) {
-        ProfScope ps(c, st, K_ROWS);
         return sr::gl_fast_inv(c->gl_fast, d, batch, st) ? fail(SR_E_HIP, "goldilocks fast-path launch failed") : SR_OK;
     }
     DISPATCH_POW2(c, (inv_dev<F>(c, d, batch, st)));
@@ -413,7 +437,6 @@ int dev_ring_mul(sr_ctx *c, uint64_t *out, const uint64_t *a, uint64_t *b, size_
     if (c->ring == SR_RING_GOLDILOCKS_24) return sr::small_launch(c->small, sr::SMALL_G24_RINGMUL, a, b, 0, out, batch, st) ? fail(SR_E_HIP, "small-ring launch failed") : SR_OK;
     if (c->ring == SR_RING_BABYBEAR_72) return sr::small_launch(c->small, sr::SMALL_B72_RINGMUL, a, b, 0, out, batch, st) ? fail(SR_E_HIP, "small-ring launch failed") : SR_OK;
     if (c->ring == SR_RING_GOLDILOCKS_POW2 && c->fast_goldilocks && sr::gl_fast_supported(c->gl_fast)) {
-        ProfScope ps(c, st, K_ROWS);
         return sr::gl_fast_ring_mul(c->gl_fast, out, a, b, batch, st) ? fail(SR_E_HIP, "goldilocks fast-path launch failed") : SR_OK;
     }
     DISPATCH_POW2(c, (ring_mul_dev<F>(c, out, a, b, batch, st)));
@@ -467,9 +490,11 @@ int sr_ctx_create(int ring, int log2_degree, int device, sr_ctx **out) {
         }
         if (rc) return bail(rc);
         if (ring == SR_RING_GOLDILOCKS_POW2) {
-            if (sr::gl_fast_init(c->gl_fast, c->k, (const uint64_t *)c->tables, c->stream)) return bail(fail(SR_E_HIP, "goldilocks fast-path init failed"));
             const char *env = getenv("SR_GOLDILOCKS_GENERIC");
             c->fast_goldilocks = !(env && env[0] == '1');
+            c->gl_fast.prof_user = c;
+            c->gl_fast.prof_begin = gl_prof_begin;
+            c->gl_fast.prof_end = gl_prof_end;
         }
     } else {
         c->k = 0;
@@ -521,11 +546,7 @@ int sr_ctx_twiddles_updated(sr_ctx *c) {
     if (!c) return fail(SR_E_INVALID, "null context");
     std::lock_guard<std::mutex> lk(c->mu);
     DeviceGuard g(c->device);
-    if (c->ring == SR_RING_GOLDILOCKS_POW2) {
-        HIP_TRY(hipDeviceSynchronize());
-        sr::gl_fast_destroy(c->gl_fast);
-        if (sr::gl_fast_init(c->gl_fast, c->k, (const uint64_t *)c->tables, c->stream)) return fail(SR_E_HIP, "goldilocks fast-path re-init failed");
-    }
+    HIP_TRY(hipDeviceSynchronize());  // every table (generic and tuned) lives in the one block: nothing to rebuild
     return SR_OK;
 }
 

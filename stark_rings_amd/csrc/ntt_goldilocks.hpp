@@ -1,13 +1,477 @@
-// Tuned Goldilocks path (placeholder until the register-radix kernels land): reports unsupported so
-// that capi.hip routes Goldilocks through the generic kernels.
+// Tuned Goldilocks path for Fp[X]/(X^D+1), D = 2^k >= 4096 (BASELINE configs 2 and 4).
+//
+// Same function as the generic kernels -- the reference's stark_prime-style negacyclic NTT
+// (crates/ring/src/cyclotomic_ring/models/stark_prime/ntt.rs:121-346 generalised),
+// outputs bit-identical -- but decomposed for the gfx950 integer pipe, where a 64x64 product is four
+// quarter-rate v_mad_u64_u32 and dominates everything else:
+//
+//   D = 2^c * 4096.
+//   (1) strided passes: the first c merged negacyclic radix-2 stages, 2^M legs per lane in registers,
+//       twiddles tw[2^s + b] wave-uniform (scalar loads); the last pass multiplies block b, position i
+//       by gamma_b^i (gamma_b = psi^(2 brv_c(b) + 1)), which turns every 4096-block into a plain
+//       CYCLIC DFT problem.  Memory-bound streaming kernels.
+//   (2) rows kernel: cyclic DFT_4096 = 16 x 16 x 16 (decimation in frequency), 16 coefficients per
+//       lane in registers, two trips through a padded 34 KiB LDS tile.  In Goldilocks 2 has order 192
+//       and omega_64 = 7^((p-1)/64) = 8^13, so omega_16 = 2^156 = -2^60: every butterfly twiddle inside
+//       a radix-16 is a compile-time SHIFT (2^96 = -1 gives the sign for free), and only one table
+//       multiply per coefficient separates two passes.  General modmuls per coefficient and transform:
+//       2 in the rows kernel (+ c/2 + 1 in the memory-bound strided passes) instead of k/2 = 8.
+//   The fused ring product keeps fwd(a) in registers while fwd(b) runs, multiplies slot-wise
+//   (ntt_form.rs:177-189), and runs the inverse from registers: a, b read once, c written once.
+//   Inverse = mirror image; D^-1 (and, for the fused product, R^-1 = 2^-64, see fields.hpp) is folded
+//   into the inverse twist table.
+//
+// tools/model_fast_goldilocks.py is the index-level model of this file, checked against the oracle.
 #pragma once
+#include <utility>
+
 #include "fields.hpp"
+
 namespace sr {
-struct GoldilocksFastTables { int k = -1; };
-inline bool gl_fast_supported(const GoldilocksFastTables &) { return false; }
-inline int gl_fast_init(GoldilocksFastTables &t, int k, const uint64_t *, hipStream_t) { t.k = k; return 0; }
-inline void gl_fast_destroy(GoldilocksFastTables &) {}
-inline int gl_fast_fwd(const GoldilocksFastTables &, uint64_t *, size_t, hipStream_t) { return 1; }
-inline int gl_fast_inv(const GoldilocksFastTables &, uint64_t *, size_t, hipStream_t) { return 1; }
-inline int gl_fast_ring_mul(const GoldilocksFastTables &, uint64_t *, const uint64_t *, uint64_t *, size_t, hipStream_t) { return 1; }
+namespace gl {
+
+using G = Goldilocks;
+typedef uint64_t u64;
+typedef uint32_t u32;
+
+constexpr int kW16Exp = 156;  // omega_16 = 2^156 (= (8^13)^4)
+constexpr int kTile = 4096;
+constexpr int kLdsElems = kTile + kTile / 16;  // padded: pos + (pos >> 4)
+
+// x * 2^E mod p for a compile-time 0 < E < 96; canonical in, canonical out
+template <int E>
+SR_HD u64 mul_pow2(u64 x) {
+    static_assert(E > 0 && E < 96, "shift out of range");
+    constexpr int q = E / 32, r = E % 32;
+    const u64 xs = x << r;                                  // low 64 bits of x * 2^r
+    const u32 y2 = r ? (u32)(x >> (64 - r)) : 0u;           // bits 64.. of x * 2^r
+    if constexpr (q == 0) {
+        return G::reduce128(xs, (u64)y2);
+    } else if constexpr (q == 1) {
+        return G::reduce128(xs << 32, (xs >> 32) | ((u64)y2 << 32));
+    } else {
+        // (y0 + y1 2^32 + y2 2^64) * 2^64 = y0 * EPS - (y1 + y2 2^32)      [2^96 = -1, 2^128 = -2^32]
+        const u32 y0 = (u32)xs;
+        const u64 B = ((u64)y0 << 32) - y0;                  // y0 * (2^32 - 1) < p
+        const u64 C = (xs >> 32) | ((u64)y2 << 32);          // < 2^63 < p
+        return G::sub(B, C);
+    }
+}
+
+// decimation-in-frequency butterfly: (a, b) -> (a + b, (a - b) * 2^E), E in [0, 192)
+template <int E>
+SR_HD void bf_dif(u64 &a, u64 &b) {
+    const u64 s = G::add(a, b);
+    u64 d;
+    if constexpr (E == 0) {
+        d = G::sub(a, b);
+    } else if constexpr (E < 96) {
+        d = mul_pow2<E>(G::sub(a, b));
+    } else if constexpr (E == 96) {
+        d = G::sub(b, a);
+    } else {
+        d = mul_pow2<E - 96>(G::sub(b, a));
+    }
+    a = s;
+    b = d;
+}
+// decimation-in-time butterfly: (u, v) -> (u + v 2^E, u - v 2^E)
+template <int E>
+SR_HD void bf_dit(u64 &u, u64 &v) {
+    if constexpr (E == 0) {
+        const u64 s = G::add(u, v), d = G::sub(u, v);
+        u = s;
+        v = d;
+    } else if constexpr (E < 96) {
+        const u64 t = mul_pow2<E>(v);
+        const u64 s = G::add(u, t), d = G::sub(u, t);
+        u = s;
+        v = d;
+    } else if constexpr (E == 96) {
+        const u64 s = G::sub(u, v), d = G::add(u, v);
+        u = s;
+        v = d;
+    } else {
+        const u64 t = mul_pow2<E - 96>(v);
+        const u64 s = G::sub(u, t), d = G::add(u, t);
+        u = s;
+        v = d;
+    }
+}
+
+template <int HALF, int STEP, int BASE, int... Js>
+SR_HD void dif_group(u64 *x, std::integer_sequence<int, Js...>) {
+    (bf_dif<(STEP * Js) % 192>(x[BASE + Js], x[BASE + Js + HALF]), ...);
+}
+template <int HALF, int STEP, int BASE, int... Js>
+SR_HD void dit_group(u64 *x, std::integer_sequence<int, Js...>) {
+    (bf_dit<(192 - (STEP * Js) % 192) % 192>(x[BASE + Js], x[BASE + Js + HALF]), ...);
+}
+template <int HALF, int STEP, int... Bs>
+SR_HD void dif_stage(u64 *x, std::integer_sequence<int, Bs...>) {
+    (dif_group<HALF, STEP, Bs * 2 * HALF>(x, std::make_integer_sequence<int, HALF>{}), ...);
+}
+template <int HALF, int STEP, int... Bs>
+SR_HD void dit_stage(u64 *x, std::integer_sequence<int, Bs...>) {
+    (dit_group<HALF, STEP, Bs * 2 * HALF>(x, std::make_integer_sequence<int, HALF>{}), ...);
+}
+// 16-point cyclic DFT with omega_16 = 2^156: natural order in, bit-reversed order out (unnormalised)
+SR_HD void dft16_fwd(u64 *x) {
+    dif_stage<8, kW16Exp>(x, std::make_integer_sequence<int, 1>{});
+    dif_stage<4, (kW16Exp * 2) % 192>(x, std::make_integer_sequence<int, 2>{});
+    dif_stage<2, (kW16Exp * 4) % 192>(x, std::make_integer_sequence<int, 4>{});
+    dif_stage<1, (kW16Exp * 8) % 192>(x, std::make_integer_sequence<int, 8>{});
+}
+// inverse network: bit-reversed order in, natural order out, result = 16 * original
+SR_HD void dft16_inv(u64 *x) {
+    dit_stage<1, (kW16Exp * 8) % 192>(x, std::make_integer_sequence<int, 8>{});
+    dit_stage<2, (kW16Exp * 4) % 192>(x, std::make_integer_sequence<int, 4>{});
+    dit_stage<4, (kW16Exp * 2) % 192>(x, std::make_integer_sequence<int, 2>{});
+    dit_stage<8, kW16Exp>(x, std::make_integer_sequence<int, 1>{});
+}
+
+struct Tables {
+    const u64 *tw, *itw;                     // merged-stage twiddles (shared with the generic path)
+    const u64 *twist_f;                      // [b * 4096 + i] = gamma_b^i
+    const u64 *twist_i_plain, *twist_i_mul;  // gamma_b^-i * D^-1   (and * 2^-64 for the fused product)
+    const u64 *w1f, *w1i;                    // [rho * 256 + i0] = omega_4096^(+- i0 brv4(rho))
+    const u64 *w2f, *w2i;                    // [sigma * 16 + i0] = omega_256^(+- i0 brv4(sigma))
+};
+
+// ------------------------------------------------------------------------------------------------
+// strided pass: merged stages [s_lo, s_lo + M) of the negacyclic transform, 2^M legs per lane.
+// grid.x = npoly * 2^s_lo * (S / 256), S = D >> (s_lo + M) the leg stride.  FWD applies the twist after
+// its butterflies, INV before (TWIST only on the pass adjacent to the rows kernel, where S = 4096).
+// ------------------------------------------------------------------------------------------------
+template <int M, int DIR, bool TWIST>
+__global__ __launch_bounds__(256) void strided_kernel(u64 *data, int k, int s_lo, const u64 *tw, const u64 *twist) {
+    constexpr int R = 1 << M;
+    const int ls = k - s_lo - M;  // log2 S
+    const size_t S = (size_t)1 << ls;
+    const unsigned chunks = (unsigned)(S >> 8);
+    const unsigned ci = blockIdx.x % chunks;
+    const unsigned rest = blockIdx.x / chunks;
+    const unsigned h = rest & ((1u << s_lo) - 1u);
+    const size_t poly = rest >> s_lo;
+    const unsigned i = ci * 256u + threadIdx.x;
+    u64 *base = data + (poly << k) + ((size_t)h << (k - s_lo)) + i;
+
+    u64 x[R];
+#pragma unroll
+    for (int j = 0; j < R; j++) x[j] = base[(size_t)j << ls];
+
+    if (DIR == 0) {
+#pragma unroll
+        for (int t = 0; t < M; t++) {
+            const int half = 1 << (M - 1 - t);
+#pragma unroll
+            for (int j = 0; j < R; j++) {
+                if (j & half) continue;
+                const u64 w = tw[(1u << (s_lo + t)) + (h << t) + (unsigned)(j >> (M - t))];
+                const u64 u = x[j], v = G::mul(x[j + half], w);
+                x[j] = G::add(u, v);
+                x[j + half] = G::sub(u, v);
+            }
+        }
+        if (TWIST) {
+#pragma unroll
+            for (int j = 0; j < R; j++) x[j] = G::mul(x[j], twist[((size_t)((h << M) + j) << 12) + i]);
+        }
+    } else {
+        if (TWIST) {
+#pragma unroll
+            for (int j = 0; j < R; j++) x[j] = G::mul(x[j], twist[((size_t)((h << M) + j) << 12) + i]);
+        }
+#pragma unroll
+        for (int t = M - 1; t >= 0; t--) {
+            const int half = 1 << (M - 1 - t);
+#pragma unroll
+            for (int j = 0; j < R; j++) {
+                if (j & half) continue;
+                const u64 w = tw[(1u << (s_lo + t)) + (h << t) + (unsigned)(j >> (M - t))];
+                const u64 u = x[j], v = x[j + half];
+                x[j] = G::add(u, v);
+                x[j + half] = G::mul(G::sub(u, v), w);
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < R; j++) base[(size_t)j << ls] = x[j];
+}
+
+// ------------------------------------------------------------------------------------------------
+// rows kernel: one workgroup = one 4096-coefficient tile, 256 lanes x 16 coefficients
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int pad(int pos) { return pos + (pos >> 4); }
+
+// forward cyclic DFT_4096 of the tile at src; x[] returns positions 16 t .. 16 t + 15 of the result
+__device__ __forceinline__ void tile_fwd(const u64 *__restrict__ src, u64 *lds, const int t, const Tables &T, u64 *x) {
+#pragma unroll
+    for (int j = 0; j < 16; j++) x[j] = src[j * 256 + t];
+    dft16_fwd(x);
+#pragma unroll
+    for (int r = 1; r < 16; r++) x[r] = G::mul(x[r], T.w1f[r * 256 + t]);
+#pragma unroll
+    for (int r = 0; r < 16; r++) lds[pad(r * 256 + t)] = x[r];
+    __syncthreads();
+    const int i0 = t & 15, base2 = (t >> 4) * 256 + i0;
+#pragma unroll
+    for (int j = 0; j < 16; j++) x[j] = lds[pad(base2 + j * 16)];
+    dft16_fwd(x);
+#pragma unroll
+    for (int s = 1; s < 16; s++) x[s] = G::mul(x[s], T.w2f[s * 16 + i0]);
+#pragma unroll
+    for (int s = 0; s < 16; s++) lds[pad(base2 + s * 16)] = x[s];  // the very slots this lane just read
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 16; j++) x[j] = lds[17 * t + j];
+    dft16_fwd(x);
+}
+
+// inverse of tile_fwd (unnormalised: 4096 x); x[] holds positions 16 t .. 16 t + 15 on entry
+__device__ __forceinline__ void tile_inv(u64 *x, u64 *lds, const int t, const Tables &T, u64 *__restrict__ dst) {
+    dft16_inv(x);
+#pragma unroll
+    for (int j = 0; j < 16; j++) lds[17 * t + j] = x[j];
+    __syncthreads();
+    const int i0 = t & 15, base2 = (t >> 4) * 256 + i0;
+#pragma unroll
+    for (int s = 0; s < 16; s++) x[s] = lds[pad(base2 + s * 16)];
+#pragma unroll
+    for (int s = 1; s < 16; s++) x[s] = G::mul(x[s], T.w2i[s * 16 + i0]);
+    dft16_inv(x);
+#pragma unroll
+    for (int j = 0; j < 16; j++) lds[pad(base2 + j * 16)] = x[j];
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 16; r++) x[r] = lds[pad(r * 256 + t)];
+#pragma unroll
+    for (int r = 1; r < 16; r++) x[r] = G::mul(x[r], T.w1i[r * 256 + t]);
+    dft16_inv(x);
+#pragma unroll
+    for (int j = 0; j < 16; j++) dst[j * 256 + t] = x[j];
+}
+
+// MODE_FWD: a -> a (in place); MODE_INV: a -> a; MODE_MUL: out = a (.) b in the transformed domain and back
+template <int MODE>
+__global__ __launch_bounds__(256, 4) void rows_kernel(u64 *a, const u64 *b, u64 *out, Tables T) {
+    __shared__ u64 lds[kLdsElems];
+    const int t = threadIdx.x;
+    const size_t base = (size_t)blockIdx.x * kTile;
+    u64 A[16];
+    if (MODE == 1) {
+#pragma unroll
+        for (int j = 0; j < 16; j++) A[j] = a[base + 16 * t + j];
+    } else {
+        tile_fwd(a + base, lds, t, T, A);
+        if (MODE == 0) {
+#pragma unroll
+            for (int j = 0; j < 16; j++) a[base + 16 * t + j] = A[j];
+            return;
+        }
+        u64 B[16];
+        __syncthreads();  // everyone has read its pass-3 slots of a before b's pass-1 writes land
+        tile_fwd(b + base, lds, t, T, B);
+#pragma unroll
+        for (int j = 0; j < 16; j++) A[j] = G::mul(A[j], B[j]);
+        __syncthreads();
+    }
+    tile_inv(A, lds, t, T, out + base);
+}
+
+// ------------------------------------------------------------------------------------------------
+// table builder.  pows[j] = psi^(2^j), ipows[j] = psi^-(2^j), j = 0..k  (psi^(2^k) = -1)
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ u64 pow_from_bits(const u64 *pw, unsigned e, int k) {
+    u64 acc = 1;
+    for (int j = 0; j <= k; j++)
+        if ((e >> j) & 1u) acc = G::mul(acc, pw[j]);
+    return acc;
+}
+__global__ void build_tables_kernel(int k, const u64 *pows, const u64 *ipows, u64 dinv, u64 dinv_mul, u64 *twist_f,
+                                    u64 *twist_i_plain, u64 *twist_i_mul, u64 *w1f, u64 *w1i, u64 *w2f, u64 *w2i) {
+    const int c = k - 12;
+    const size_t d = (size_t)1 << k;
+    const unsigned mask2d = (unsigned)(2 * d - 1);
+    for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < d; idx += (size_t)gridDim.x * blockDim.x) {
+        unsigned b = (unsigned)(idx >> 12), i = (unsigned)(idx & 4095);
+        unsigned e = (unsigned)(((unsigned long long)(2 * bitrev(b, c) + 1) * i) & mask2d);
+        twist_f[idx] = pow_from_bits(pows, e, k);
+        u64 inv = pow_from_bits(ipows, e, k);
+        twist_i_plain[idx] = G::mul(inv, dinv);
+        twist_i_mul[idx] = G::mul(inv, dinv_mul);
+        if (idx < 4096) {
+            unsigned r = (unsigned)(idx >> 8), i0 = (unsigned)(idx & 255);
+            unsigned e1 = (unsigned)((((unsigned long long)i0 * bitrev(r, 4)) << (c + 1)) & mask2d);  // omega_4096 = psi^(2^(c+1))
+            w1f[idx] = pow_from_bits(pows, e1, k);
+            w1i[idx] = pow_from_bits(ipows, e1, k);
+        }
+        if (idx < 256) {
+            unsigned s = (unsigned)(idx >> 4), i0 = (unsigned)(idx & 15);
+            unsigned e2 = (unsigned)((((unsigned long long)i0 * bitrev(s, 4)) << (c + 5)) & mask2d);  // omega_256 = psi^(2^(c+5))
+            w2f[idx] = pow_from_bits(pows, e2, k);
+            w2i[idx] = pow_from_bits(ipows, e2, k);
+        }
+    }
+}
+
+}  // namespace gl
+
+// ---- host side ------------------------------------------------------------------------------------
+struct GoldilocksFastTables {
+    int k = -1;
+    bool ready = false;
+    gl::Tables t{};
+    size_t chunk_polys = 0;  // 0 = whole batch per launch
+    // optional per-launch timing hooks (set by capi.hip): tag 0 strided fwd, 1 rows, 2 strided inv
+    void (*prof_begin)(void *user, int tag, hipStream_t st) = nullptr;
+    void (*prof_end)(void *user, hipStream_t st) = nullptr;
+    void *prof_user = nullptr;
+};
+struct GlProfScope {
+    const GoldilocksFastTables &f;
+    hipStream_t st;
+    GlProfScope(const GoldilocksFastTables &ff, int tag, hipStream_t s) : f(ff), st(s) {
+        if (f.prof_begin) f.prof_begin(f.prof_user, tag, st);
+    }
+    ~GlProfScope() {
+        if (f.prof_end) f.prof_end(f.prof_user, st);
+    }
+};
+
+inline bool gl_fast_supported(const GoldilocksFastTables &f) { return f.ready; }
+inline size_t gl_fast_extra_bytes(int k) {
+    if (k < 12 || k > 22) return 0;
+    return (((size_t)3 << k) + 2 * 4096 + 2 * 256) * sizeof(uint64_t);
+}
+// extra = device memory of gl_fast_extra_bytes(k) bytes, placed right behind [tw | itw] in the context's
+// twiddle block so that one broadcast ships everything.
+inline int gl_fast_init(GoldilocksFastTables &f, int k, const uint64_t *tw, const uint64_t *itw, uint64_t *extra,
+                        const uint64_t *host_pows, const uint64_t *host_ipows, uint64_t dinv, uint64_t dinv_mul,
+                        hipStream_t st) {
+    f.k = k;
+    f.ready = false;
+    if (gl_fast_extra_bytes(k) == 0) return 0;
+    const size_t d = (size_t)1 << k;
+    uint64_t *p = extra;
+    uint64_t *twist_f = p;            p += d;
+    uint64_t *twist_ip = p;           p += d;
+    uint64_t *twist_im = p;           p += d;
+    uint64_t *w1f = p;                p += 4096;
+    uint64_t *w1i = p;                p += 4096;
+    uint64_t *w2f = p;                p += 256;
+    uint64_t *w2i = p;
+    uint64_t *d_pows = nullptr;
+    if (hipMalloc(&d_pows, 2 * (k + 1) * sizeof(uint64_t)) != hipSuccess) return 1;
+    if (hipMemcpy(d_pows, host_pows, (k + 1) * 8, hipMemcpyHostToDevice) != hipSuccess) return 1;
+    if (hipMemcpy(d_pows + k + 1, host_ipows, (k + 1) * 8, hipMemcpyHostToDevice) != hipSuccess) return 1;
+    unsigned blocks = (unsigned)((d + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(gl::build_tables_kernel, dim3(blocks), dim3(256), 0, st, k, d_pows, d_pows + k + 1, dinv, dinv_mul,
+                       twist_f, twist_ip, twist_im, w1f, w1i, w2f, w2i);
+    if (hipGetLastError() != hipSuccess) return 1;
+    if (hipStreamSynchronize(st) != hipSuccess) return 1;
+    (void)hipFree(d_pows);
+    f.t = gl::Tables{tw, itw, twist_f, twist_ip, twist_im, w1f, w1i, w2f, w2i};
+    const char *env = getenv("SR_CHUNK_POLYS");
+    f.chunk_polys = env ? (size_t)strtoull(env, nullptr, 10) : 0;
+    f.ready = true;
+    return 0;
+}
+inline void gl_fast_destroy(GoldilocksFastTables &f) { f.ready = false; }
+
+template <int DIR, bool TWIST>
+inline int gl_launch_strided(const GoldilocksFastTables &f, int M, uint64_t *data, int k, int s_lo, size_t npoly,
+                             const uint64_t *tw, const uint64_t *twist, hipStream_t st) {
+    GlProfScope ps(f, DIR == 0 ? 0 : 2, st);
+    const size_t S = (size_t)1 << (k - s_lo - M);
+    const size_t blocks = npoly * ((size_t)1 << s_lo) * (S >> 8);
+    if (blocks == 0 || blocks > 0x7FFFFFFFull) return 1;
+    dim3 g((unsigned)blocks), b(256);
+    switch (M) {
+        case 0: hipLaunchKernelGGL((gl::strided_kernel<0, DIR, TWIST>), g, b, 0, st, data, k, s_lo, tw, twist); break;
+        case 1: hipLaunchKernelGGL((gl::strided_kernel<1, DIR, TWIST>), g, b, 0, st, data, k, s_lo, tw, twist); break;
+        case 2: hipLaunchKernelGGL((gl::strided_kernel<2, DIR, TWIST>), g, b, 0, st, data, k, s_lo, tw, twist); break;
+        case 3: hipLaunchKernelGGL((gl::strided_kernel<3, DIR, TWIST>), g, b, 0, st, data, k, s_lo, tw, twist); break;
+        case 4: hipLaunchKernelGGL((gl::strided_kernel<4, DIR, TWIST>), g, b, 0, st, data, k, s_lo, tw, twist); break;
+        default: return 1;
+    }
+    return hipGetLastError() != hipSuccess;
+}
+// split the c = k - 12 strided stages into register passes of at most 4 stages each
+inline int gl_plan(int c, int *ms) {
+    int n = 0;
+    while (c > 0) {
+        int m = c > 4 ? (c >= 8 ? 4 : (c + 1) / 2) : c;
+        ms[n++] = m;
+        c -= m;
+    }
+    if (n == 0) ms[n++] = 0;  // D = 4096: twist-only pass
+    return n;
+}
+inline int gl_strided_fwd(const GoldilocksFastTables &f, uint64_t *d, size_t npoly, hipStream_t st) {
+    int ms[8];
+    const int n = gl_plan(f.k - 12, ms);
+    int s_lo = 0;
+    for (int p = 0; p < n; p++) {
+        const bool last = p == n - 1;
+        int rc = last ? gl_launch_strided<0, true>(f, ms[p], d, f.k, s_lo, npoly, f.t.tw, f.t.twist_f, st)
+                      : gl_launch_strided<0, false>(f, ms[p], d, f.k, s_lo, npoly, f.t.tw, nullptr, st);
+        if (rc) return rc;
+        s_lo += ms[p];
+    }
+    return 0;
+}
+inline int gl_strided_inv(const GoldilocksFastTables &f, uint64_t *d, size_t npoly, bool fused, hipStream_t st) {
+    int ms[8];
+    const int n = gl_plan(f.k - 12, ms);
+    int s_lo = f.k - 12;
+    for (int p = n - 1; p >= 0; p--) {
+        s_lo -= ms[p];
+        const bool first = p == n - 1;
+        int rc = first ? gl_launch_strided<1, true>(f, ms[p], d, f.k, s_lo, npoly, f.t.itw,
+                                                    fused ? f.t.twist_i_mul : f.t.twist_i_plain, st)
+                       : gl_launch_strided<1, false>(f, ms[p], d, f.k, s_lo, npoly, f.t.itw, nullptr, st);
+        if (rc) return rc;
+    }
+    return 0;
+}
+template <int MODE>
+inline int gl_launch_rows(const GoldilocksFastTables &f, uint64_t *a, const uint64_t *b, uint64_t *out, size_t npoly,
+                          hipStream_t st) {
+    const size_t tiles = npoly << (f.k - 12);
+    if (tiles == 0 || tiles > 0x7FFFFFFFull) return 1;
+    GlProfScope ps(f, 1, st);
+    hipLaunchKernelGGL((gl::rows_kernel<MODE>), dim3((unsigned)tiles), dim3(256), 0, st, a, b, out, f.t);
+    return hipGetLastError() != hipSuccess;
+}
+inline int gl_fast_fwd(const GoldilocksFastTables &f, uint64_t *d, size_t batch, hipStream_t st) {
+    if (batch == 0) return 0;
+    if (gl_strided_fwd(f, d, batch, st)) return 1;
+    return gl_launch_rows<0>(f, d, nullptr, d, batch, st);
+}
+inline int gl_fast_inv(const GoldilocksFastTables &f, uint64_t *d, size_t batch, hipStream_t st) {
+    if (batch == 0) return 0;
+    if (gl_launch_rows<1>(f, d, nullptr, d, batch, st)) return 1;
+    return gl_strided_inv(f, d, batch, false, st);
+}
+// out = a * b (ring product on in-memory images); b is overwritten with its strided-pass image.
+inline int gl_fast_ring_mul(const GoldilocksFastTables &f, uint64_t *out, const uint64_t *a, uint64_t *b, size_t batch,
+                            hipStream_t st) {
+    if (batch == 0) return 0;
+    const size_t chunk = f.chunk_polys ? f.chunk_polys : batch;
+    const size_t stride = (size_t)1 << f.k;
+    for (size_t e = 0; e < batch; e += chunk) {
+        const size_t n = batch - e < chunk ? batch - e : chunk;
+        uint64_t *o = out + e * stride, *bb = b + e * stride;
+        const uint64_t *aa = a + e * stride;
+        if (o != aa && hipMemcpyAsync(o, aa, n * stride * 8, hipMemcpyDeviceToDevice, st) != hipSuccess) return 1;
+        if (gl_strided_fwd(f, o, n, st)) return 1;
+        if (gl_strided_fwd(f, bb, n, st)) return 1;
+        if (gl_launch_rows<2>(f, o, bb, o, n, st)) return 1;
+        if (gl_strided_inv(f, o, n, true, st)) return 1;
+    }
+    return 0;
+}
+
 }  // namespace sr

@@ -229,3 +229,51 @@ def test_small_rings_match_oracle(torch_cuda, name):
         for e in range(2):
             std = O.from_mont(F, src[e * in_len:(e + 1) * in_len]) if in_len else []
             assert O.from_mont(F, got[e * D:(e + 1) * D]) == pyreduce(std), (in_len, e)
+
+
+# ----------------------------------------------------------------------------- tuned Goldilocks path
+@pytest.mark.parametrize("k,batch", [(12, 7), (14, 3), (15, 2), (17, 2), (18, 1), (20, 1)])
+def test_goldilocks_tuned_path_all_plans(torch_cuda, k, batch):
+    """D = 2^c * 4096 for every strided-pass plan (c = 0, single pass, two passes), vs the oracle
+    and vs the generic kernels (SR_GOLDILOCKS_GENERIC=1 routes the same ring through them)."""
+    import os
+
+    from stark_rings_amd import CyclotomicRing
+
+    F = O.GOLDILOCKS
+    ring = ring_for("goldilocks", k)
+    a = edge_and_random(F, k, batch, 0xC0 + k)
+    b = O.fill_uniform(F, 0xD0 + k, 0, batch << k)
+    fa = ring.elementwise_crt(a.copy())
+    assert np.array_equal(fa, O.pow2_fwd(F, a, k, batch, 4))
+    assert np.array_equal(ring.elementwise_icrt(fa.copy()), a)
+    want = O.pow2_ring_mul(F, a, b, k, batch, 4)
+    assert np.array_equal(ring.mul(a, b), want)
+    os.environ["SR_GOLDILOCKS_GENERIC"] = "1"
+    try:
+        generic = CyclotomicRing("goldilocks", k, device=0)
+    finally:
+        del os.environ["SR_GOLDILOCKS_GENERIC"]
+    assert np.array_equal(generic.elementwise_crt(a.copy()), fa)
+    assert np.array_equal(generic.mul(a, b), want)
+    generic.close()
+
+
+def test_goldilocks_chunked_launches_equal_single_launch(torch_cuda):
+    import os
+
+    from stark_rings_amd import CyclotomicRing
+
+    torch = torch_cuda
+    F = O.GOLDILOCKS
+    k, batch = 13, 11
+    a = O.fill_uniform(F, 31, 0, batch << k)
+    b = O.fill_uniform(F, 32, 0, batch << k)
+    want = O.pow2_ring_mul(F, a, b, k, batch, 4)
+    os.environ["SR_CHUNK_POLYS"] = "4"   # 4 + 4 + 3: ragged last chunk
+    try:
+        ring = CyclotomicRing("goldilocks", k, device=0)
+    finally:
+        del os.environ["SR_CHUNK_POLYS"]
+    assert np.array_equal(ring.mul(a, b), want)
+    ring.close()

@@ -1,0 +1,214 @@
+"""Index-level Python model of the tuned Goldilocks path (ntt_goldilocks.hpp), checked against the
+oracle's pure-Python model.  Development aid: validates the decomposition before it is written in HIP.
+
+  forward = merged negacyclic radix-2 stages 0..c-1 (strided, twiddles tw[2^s+b])        [cols pass]
+            -> twist by gamma_b^i (block b of 4096)                                      [cols pass]
+            -> cyclic DFT_4096 = 16 x 16 x 16, DIF, shift-only radix-16 butterflies
+               (omega_16 = 2^12), one table multiply between passes                      [rows kernel]
+"""
+import os
+import sys
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "oracle"))
+import random
+
+import pyref as P
+
+p = P.GOLDILOCKS_P
+
+
+def brv(x, bits):
+    return P.brv(x, bits)
+
+
+# omega_64 = 7^((p-1)/64) = 8^13, so the 16th root the transform actually uses is 2^(12*13) = 2^156 = -2^60
+W16_EXP = 156
+
+
+def dft16_fwd(x):
+    """DIF, natural in, bit-reversed out; omega_16 = 2^156."""
+    x = list(x)
+    half = 8
+    step = W16_EXP
+    while half >= 1:
+        for base in range(0, 16, 2 * half):
+            for j in range(half):
+                a, b = x[base + j], x[base + j + half]
+                x[base + j] = (a + b) % p
+                x[base + j + half] = (a - b) * pow(2, (step * j) % 192, p) % p
+        half //= 2
+        step = (step * 2) % 192
+    return x
+
+
+def dft16_inv(x):
+    """inverse network (unnormalised): bit-reversed in, natural out."""
+    x = list(x)
+    half = 1
+    steps = {1: (W16_EXP * 8) % 192, 2: (W16_EXP * 4) % 192, 4: (W16_EXP * 2) % 192, 8: W16_EXP}
+    while half <= 8:
+        step = steps[half]
+        for base in range(0, 16, 2 * half):
+            for j in range(half):
+                u, v = x[base + j], x[base + j + half] * pow(2, (192 - (step * j) % 192) % 192, p) % p
+                x[base + j] = (u + v) % p
+                x[base + j + half] = (u - v) % p
+        half *= 2
+    return x
+
+
+def tables(k):
+    c = k - 12
+    psi = P.psi("goldilocks", k)
+    D = 1 << k
+    w4096 = pow(psi, 2 * D // 4096, p)
+    w256 = pow(w4096, 16, p)
+    T = {}
+    T["twist_f"] = [[pow(psi, (2 * brv(b, c) + 1) * i, p) for i in range(4096)] for b in range(1 << c)]
+    T["W1f"] = [[pow(w4096, i0 * brv(r, 4), p) for i0 in range(256)] for r in range(16)]
+    T["W2f"] = [[pow(w256, i0 * brv(s, 4), p) for i0 in range(16)] for s in range(16)]
+    inv = lambda v: pow(v, -1, p)
+    dinv = inv(D)
+    T["twist_i"] = [[inv(T["twist_f"][b][i]) * inv(4096) % p for i in range(4096)] for b in range(1 << c)]
+    T["W1i"] = [[inv(v) for v in row] for row in T["W1f"]]
+    T["W2i"] = [[inv(v) for v in row] for row in T["W2f"]]
+    T["tw"] = [pow(psi, brv(i, k), p) for i in range(D)]
+    T["itw"] = [inv(v) for v in T["tw"]]
+    T["cols_scale"] = inv(1 << c)
+    return T
+
+
+def strided_fwd(a, k, s_lo, M, T, twist):
+    D = 1 << k
+    a = list(a)
+    Bsz = D >> s_lo
+    S = Bsz >> M
+    for h in range(1 << s_lo):
+        for i in range(S):
+            x = [a[h * Bsz + j * S + i] for j in range(1 << M)]
+            for t in range(M):
+                s = s_lo + t
+                half = 1 << (M - 1 - t)
+                for j in range(1 << M):
+                    if j & half:
+                        continue
+                    b = (h << t) + (j >> (M - t))
+                    w = T["tw"][(1 << s) + b]
+                    u, v = x[j], x[j + half] * w % p
+                    x[j], x[j + half] = (u + v) % p, (u - v) % p
+            for j in range(1 << M):
+                v = x[j]
+                if twist:
+                    bfin = (h << M) + j
+                    v = v * T["twist_f"][bfin][i] % p
+                a[h * Bsz + j * S + i] = v
+    return a
+
+
+def strided_inv(a, k, s_lo, M, T, twist):
+    D = 1 << k
+    a = list(a)
+    Bsz = D >> s_lo
+    S = Bsz >> M
+    for h in range(1 << s_lo):
+        for i in range(S):
+            x = [a[h * Bsz + j * S + i] for j in range(1 << M)]
+            if twist:
+                x = [x[j] * T["twist_i"][(h << M) + j][i] % p for j in range(1 << M)]
+            for t in range(M - 1, -1, -1):
+                s = s_lo + t
+                half = 1 << (M - 1 - t)
+                for j in range(1 << M):
+                    if j & half:
+                        continue
+                    b = (h << t) + (j >> (M - t))
+                    w = T["itw"][(1 << s) + b]
+                    u, v = x[j], x[j + half]
+                    x[j], x[j + half] = (u + v) % p, (u - v) * w % p
+            for j in range(1 << M):
+                a[h * Bsz + j * S + i] = x[j]
+    return a
+
+
+def rows_fwd(tile, T):
+    """cyclic DFT_4096, bit-reversed output, exactly the three register passes of the kernel."""
+    y = list(tile)
+    # pass 1: thread t = i0, slots i1 at i1*256 + t
+    for t in range(256):
+        x = dft16_fwd([y[j * 256 + t] for j in range(16)])
+        for r in range(16):
+            y[r * 256 + t] = x[r] * T["W1f"][r][t] % p
+    # pass 2: thread t = (rho, i0)
+    for t in range(256):
+        rho, i0 = t >> 4, t & 15
+        x = dft16_fwd([y[rho * 256 + j * 16 + i0] for j in range(16)])
+        for s in range(16):
+            y[rho * 256 + s * 16 + i0] = x[s] * T["W2f"][s][i0] % p
+    # pass 3: 16 contiguous
+    for t in range(256):
+        y[16 * t:16 * t + 16] = dft16_fwd(y[16 * t:16 * t + 16])
+    return y
+
+
+def rows_inv(tile, T):
+    y = list(tile)
+    for t in range(256):
+        y[16 * t:16 * t + 16] = dft16_inv(y[16 * t:16 * t + 16])
+    for t in range(256):
+        rho, i0 = t >> 4, t & 15
+        x = dft16_inv([y[rho * 256 + s * 16 + i0] * T["W2i"][s][i0] % p for s in range(16)])
+        for j in range(16):
+            y[rho * 256 + j * 16 + i0] = x[j]
+    for t in range(256):
+        x = dft16_inv([y[r * 256 + t] * T["W1i"][r][t] % p for r in range(16)])
+        for j in range(16):
+            y[j * 256 + t] = x[j]
+    return y
+
+
+def fast_fwd(a, k, T):
+    c = k - 12
+    a = strided_fwd(a, k, 0, c, T, True)
+    out = []
+    for b in range(1 << c):
+        out += rows_fwd(a[b * 4096:(b + 1) * 4096], T)
+    return out
+
+
+def fast_inv(A, k, T):
+    c = k - 12
+    a = []
+    for b in range(1 << c):
+        a += rows_inv(A[b * 4096:(b + 1) * 4096], T)
+    a = strided_inv(a, k, 0, c, T, True)
+    s = T["cols_scale"]
+    return [v * s % p for v in a]
+
+
+if __name__ == "__main__":
+    rng = random.Random(3)
+    # radix-16 networks
+    x = [rng.randrange(p) for _ in range(16)]
+    w = pow(2, W16_EXP, p)
+    ref = [sum(x[i] * pow(w, i * m, p) for i in range(16)) % p for m in range(16)]
+    got = dft16_fwd(x)
+    assert got == [ref[brv(r, 4)] for r in range(16)]
+    assert dft16_inv(got) == [16 * v % p for v in x]
+    for k in (12, 13):
+        T = tables(k)
+        a = [rng.randrange(p) for _ in range(1 << k)]
+        want = P.pow2_fwd("goldilocks", a, k)
+        got = fast_fwd(a, k, T)
+        assert got == want, "forward mismatch k=%d" % k
+        assert fast_inv(got, k, T) == a, "inverse mismatch k=%d" % k
+        print("k=%d ok" % k)
+    # two strided passes (c = 2 as 1 + 1) compose
+    k = 14
+    T = tables(k)
+    a = [rng.randrange(p) for _ in range(1 << k)]
+    one = strided_fwd(a, k, 0, 2, T, True)
+    two = strided_fwd(strided_fwd(a, k, 0, 1, T, False), k, 1, 1, T, True)
+    assert one == two
+    back = strided_inv(strided_inv(one, k, 1, 1, T, True), k, 0, 1, T, False)
+    assert back == strided_inv(one, k, 0, 2, T, True)
+    print("model OK")
