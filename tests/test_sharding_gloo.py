@@ -1,0 +1,78 @@
+"""N > 1 path on CPU: world_size-2 gloo processes exercise the sharding logic bench.py uses on GPUs
+(contiguous element ranges, one twiddle-block broadcast, no data-path collective).  The compute inside
+each rank is the oracle here (no GPU in this container); on the GPU box the same ranges feed the HIP path."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+from stark_rings_amd.sharding import shard_range
+
+
+def test_shard_range_partitions_exactly():
+    for batch in (0, 1, 7, 8, 9, 16384, 65536, 100003):
+        for world in (1, 2, 3, 4, 8):
+            got = [shard_range(batch, world, r) for r in range(world)]
+            assert got[0][0] == 0
+            for (f0, c0), (f1, _) in zip(got, got[1:]):
+                assert f0 + c0 == f1
+            assert got[-1][0] + got[-1][1] == batch
+            counts = [c for _, c in got]
+            assert max(counts) - min(counts) <= 1
+    with pytest.raises(ValueError):
+        shard_range(10, 2, 2)
+
+
+def _worker(rank, world, port, k, batch, tmp):
+    for p in (ROOT, os.path.join(ROOT, "oracle")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import oracle_lib as O
+    from stark_rings_amd.sharding import broadcast_block, init_process_group, shard_range
+
+    init_process_group("gloo", rank, world)
+    try:
+        # 1. the one collective: rank 0's table bytes reach every rank intact
+        ref = np.frombuffer(np.random.default_rng(1234).bytes(1 << 16), dtype=np.uint8).copy()
+        block = torch.from_numpy(ref.copy() if rank == 0 else np.full_like(ref, 0xAB))
+        broadcast_block(block, src=0)
+        assert np.array_equal(block.numpy(), ref), "broadcast mismatch on rank %d" % rank
+        # 2. independent shards: each rank multiplies only its element range; nothing is exchanged
+        F = O.GOLDILOCKS
+        d = 1 << k
+        first, count = shard_range(batch, world, rank)
+        a = O.fill_uniform(F, 0x5EED0001, first * d, count * d)
+        b = O.fill_uniform(F, 0x5EED0002, first * d, count * d)
+        c = O.pow2_ring_mul(F, a, b, k, count, 1) if count else np.zeros(0, dtype=np.uint64)
+        np.save(os.path.join(tmp, "shard%d.npy" % rank), c)
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,batch", [(2, 5), (2, 8)])
+def test_two_rank_shards_reassemble_to_the_unsharded_result(tmp_path, world, batch):
+    import socket
+
+    import oracle_lib as O
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    k = 8
+    mp.spawn(_worker, args=(world, port, k, batch, str(tmp_path)), nprocs=world, join=True)
+    parts = [np.load(os.path.join(str(tmp_path), "shard%d.npy" % r)) for r in range(world)]
+    got = np.concatenate(parts)
+    F = O.GOLDILOCKS
+    a = O.fill_uniform(F, 0x5EED0001, 0, batch << k)
+    b = O.fill_uniform(F, 0x5EED0002, 0, batch << k)
+    assert np.array_equal(got, O.pow2_ring_mul(F, a, b, k, batch, 2))

@@ -1,0 +1,51 @@
+#!/usr/bin/env python3
+"""Summarise a rocprofv3 run (kernel_stats + FETCH_SIZE/WRITE_SIZE passes) into profiles/<round>/README.md.
+usage: make_profile_readme.py profiles/r01"""
+import collections
+import csv
+import os
+import sys
+
+d = sys.argv[1]
+stats = [f for f in os.listdir(d) if f.startswith("kernel_stats")][0]
+out = []
+out.append("# %s -- MI355X (gfx950), workload goldilocks_d65536_b16384 (BASELINE configs[1])\n" % d)
+out.append("Commands (on the GPU box, from the repo root; counters in their own passes):\n")
+out.append("    rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof/trace -o r1 -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline")
+out.append("    rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/prof/pmc_fetch -o r1 -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline")
+out.append("    rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/prof/pmc_write -o r1 -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline\n")
+out.append("## kernel_stats (%s)\n" % stats)
+out.append("| kernel | calls | avg ms | share of GPU time |\n|---|---|---|---|")
+for r in csv.DictReader(open(os.path.join(d, stats))):
+    if "sr::" in r["Name"] and "build" not in r["Name"]:
+        out.append("| `%s` | %s | %.3f | %s %% |" % (r["Name"].split("(")[0].replace("void ", ""), r["Calls"],
+                                                    float(r["AverageNs"]) / 1e6, r["Percentage"]))
+agg = {}
+for name, cn in (("pmc_FETCH_SIZE", "FETCH_SIZE"), ("pmc_WRITE_SIZE", "WRITE_SIZE")):
+    dd = collections.defaultdict(list)
+    for r in csv.DictReader(open(os.path.join(d, name + ".csv"))):
+        dd[r["Kernel_Name"].split("(")[0].replace("void ", "")].append(float(r["Counter_Value"]))
+    agg[cn] = {k: sum(v) / len(v) for k, v in dd.items()}
+out.append("\n## HBM traffic per launch (PMC counters; the CSVs are in KiB)\n")
+out.append("FETCH_SIZE is doubled, as MI355X_MICROARCH.md (HBM section) prescribes for gfx950 streaming reads; the calibration")
+out.append("point inside the same run is `count_noncanonical_kernel`, which reads exactly 8 GiB (2^30 u64, 8 B per lane) and reports")
+cal = [v for k, v in agg["FETCH_SIZE"].items() if "count_noncanonical" in k]
+out.append("%.0f KiB.  WRITE_SIZE is taken as is (`fill_uniform_kernel` writes exactly 8 GiB and reports %.0f KiB).\n" % (
+    cal[0] if cal else float("nan"), [v for k, v in agg["WRITE_SIZE"].items() if "fill_uniform" in k][0]))
+out.append("| kernel | launches/step | FETCH_SIZE x2 (GiB) | WRITE_SIZE (GiB) |\n|---|---|---|---|")
+total = 0.0
+for k in sorted(agg["FETCH_SIZE"]):
+    if "sr::gl::" not in k or "build" in k:
+        continue
+    per_step = 2 if "strided_kernel" in k and ", 0, " in k else 1
+    f, w = 2 * agg["FETCH_SIZE"][k] / 2**20, agg["WRITE_SIZE"].get(k, 0) / 2**20
+    total += per_step * (f + w)
+    out.append("| `%s` | %d | %.2f | %.2f |" % (k, per_step, f, w))
+out.append("\nWhole step: %.1f GiB of HBM traffic for 16384 ring-muls = %.2f MB per ring-mul = %.2fx the algorithmic 3*D*8 = 1 572 864 B."
+           % (total, total * 2**30 / 16384 / 1e6, total * 2**30 / 16384 / 1572864))
+out.append("Algorithmic bytes: rows kernel 24 GiB per launch (read a, read b, write c); each strided launch 16 GiB (read + write one operand).\n")
+extra = os.path.join(d, "NOTES.md")
+if os.path.exists(extra):
+    out.append(open(extra).read())
+open(os.path.join(d, "README.md"), "w").write("\n".join(out) + "\n")
+print("\n".join(out))
