@@ -1,0 +1,172 @@
+// stark_rings.hpp -- C++17 host-side mirror of the reference's ring interface for the CRT/NTT hot path,
+// header-only, on top of the C ABI (stark_rings_hip.h).  The reference is Rust; no Rust toolchain exists in
+// this image, so the host layer a crates/ring maintainer would write in Rust is restated
+// here in C++ with the same names, argument meaning and error behaviour:
+//
+//   reference (crates/ring/src/cyclotomic_ring/)                     here
+//   ---------------------------------------------------------------  ------------------------------------------
+//   trait CyclotomicConfig<N>            ring_config.rs:11-35        class CyclotomicConfig  (one ring + degree)
+//     reduce_in_place(&mut Vec<Fp>)      ring_config.rs:23             reduce_in_place(std::vector<Fp>&)
+//     crt_in_place(&mut [Fp])            ring_config.rs:27             crt_in_place(Fp*, len)
+//     icrt_in_place(&mut [Fp])           ring_config.rs:34             icrt_in_place(Fp*, len)
+//     crt(Vec<Fp>) -> Vec<CRTField>      ring_config.rs:29             crt(std::vector<Fp>) (same allocation)
+//     icrt(Vec<CRTField>) -> Vec<Fp>     ring_config.rs:30             icrt(std::vector<Fp>)
+//     CRT_FIELD_EXTENSION_DEGREE         ring_config.rs:19             crt_field_extension_degree()
+//   CyclotomicPolyRingGeneral<C,N,D>     coeff_form.rs:31-33         class RqPolyVec   (a Vec<RqPoly>, flat)
+//     Mul  (poly_mul + reduce)           coeff_form.rs:54-67,250-258   operator*, operator*=
+//   CyclotomicPolyRingNTTGeneral<C,N,D>  ntt_form.rs:25-27           class RqNTTVec    (a Vec<RqNTT>, flat)
+//     Mul / MulAssign (slot-wise)        ntt_form.rs:159-225           operator*, operator*=
+//   CRT::elementwise_crt                 crt.rs:10-25                RqPolyVec::elementwise_crt() &&  (in place, same allocation)
+//   ICRT::elementwise_icrt               crt.rs:34-49                RqNTTVec::elementwise_icrt() &&
+//   Flatten::flatten_to_coeffs           flatten.rs:11-17            flatten_to_coeffs(Vec&&) -> std::vector<uint64_t>
+//   Flatten::promote_from_coeffs         flatten.rs:19-33            promote_from_coeffs(...) -> std::optional (nullopt if len % D != 0)
+//
+// What is deliberately narrowed: ring elements of degree 2^16 are 512 KiB, so the per-element `Copy` value type of
+// the reference (ring.rs:13-15) is not mirrored; the drop-in seam is the batch (hard part 4).
+// Errors: the reference panics (assert_eq!(len, D): goldilocks/ntt.rs:136, stark_prime/ntt.rs:122; "Wrong length":
+// coeff_form.rs:39); here std::length_error / std::runtime_error are thrown.
+#pragma once
+#include <cstdint>
+#include <memory>
+#include <optional>
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "stark_rings_hip.h"
+
+namespace stark_rings {
+
+class CyclotomicConfig {
+public:
+    CyclotomicConfig(sr_ring ring, int log2_degree = 0, int device = 0) : ring_(ring) {
+        sr_ctx *c = nullptr;
+        check(sr_ctx_create(ring, log2_degree, device, &c), "sr_ctx_create");
+        ctx_.reset(c, [](sr_ctx *p) { sr_ctx_destroy(p); });
+        check(sr_ctx_degree(c, &degree_), "sr_ctx_degree");
+        check(sr_ctx_limbs(c, &limbs_), "sr_ctx_limbs");
+    }
+    size_t dimension() const { return degree_; }            // PolyRing::dimension()
+    int limbs() const { return limbs_; }                    // N
+    size_t words_per_elem() const { return degree_ * (size_t)limbs_; }
+    int crt_field_extension_degree() const {
+        return ring_ == SR_RING_GOLDILOCKS_24 ? 3 : (ring_ == SR_RING_BABYBEAR_72 ? 9 : 1);
+    }
+    sr_ctx *raw() const { return ctx_.get(); }
+
+    // coefficients: up to 2*D coefficients of N limbs each -> reduced mod Phi, resized to D
+    void reduce_in_place(std::vector<uint64_t> &coefficients) const {
+        if (coefficients.size() % limbs_) throw std::length_error("reduce_in_place: not whole coefficients");
+        const size_t in_len = coefficients.size() / limbs_;
+        std::vector<uint64_t> out(words_per_elem());
+        std::vector<uint64_t> dummy(1);
+        check(sr_reduce_batch(raw(), in_len ? coefficients.data() : dummy.data(), in_len, out.data(), 1), "reduce_in_place");
+        coefficients.swap(out);
+    }
+    void crt_in_place(uint64_t *coefficients, size_t len_words) const {
+        if (len_words != words_per_elem()) throw std::length_error("crt_in_place: coefficients.len() != D");
+        check(sr_ntt_fwd_batch(raw(), coefficients, 1), "crt_in_place");
+    }
+    void icrt_in_place(uint64_t *evaluations, size_t len_words) const {
+        if (len_words != words_per_elem()) throw std::length_error("icrt_in_place: evaluations.len() != D");
+        check(sr_ntt_inv_batch(raw(), evaluations, 1), "icrt_in_place");
+    }
+    std::vector<uint64_t> crt(std::vector<uint64_t> coefficients) const {
+        crt_in_place(coefficients.data(), coefficients.size());
+        return coefficients;
+    }
+    std::vector<uint64_t> icrt(std::vector<uint64_t> evaluations) const {
+        icrt_in_place(evaluations.data(), evaluations.size());
+        return evaluations;
+    }
+    static void check(int rc, const char *what) {
+        if (rc != SR_OK) throw std::runtime_error(std::string(what) + ": " + sr_last_error_string());
+    }
+
+private:
+    sr_ring ring_;
+    std::shared_ptr<sr_ctx> ctx_;
+    size_t degree_ = 0;
+    int limbs_ = 1;
+};
+
+class RqNTTVec;
+
+// Vec<RqPoly>: `len` ring elements in coefficient form, flat element-major storage (flatten.rs layout)
+class RqPolyVec {
+public:
+    RqPolyVec(CyclotomicConfig cfg, std::vector<uint64_t> words) : cfg_(std::move(cfg)), w_(std::move(words)) {
+        if (w_.size() % cfg_.words_per_elem()) throw std::length_error("Wrong length");  // coeff_form.rs:39
+    }
+    size_t len() const { return w_.size() / cfg_.words_per_elem(); }
+    const std::vector<uint64_t> &words() const { return w_; }
+    const CyclotomicConfig &config() const { return cfg_; }
+    uint64_t *element(size_t i) { return w_.data() + i * cfg_.words_per_elem(); }
+    bool operator==(const RqPolyVec &o) const { return w_ == o.w_; }
+
+    RqNTTVec elementwise_crt() &&;                               // crt.rs:10-25
+    RqPolyVec &operator*=(const RqPolyVec &rhs) {                // coeff_form.rs:250-258 per element
+        if (rhs.w_.size() != w_.size()) throw std::length_error("operand lengths differ");
+        CyclotomicConfig::check(sr_ring_mul_batch(cfg_.raw(), w_.data(), w_.data(), rhs.w_.data(), len()), "RqPoly *");
+        return *this;
+    }
+    friend RqPolyVec operator*(RqPolyVec lhs, const RqPolyVec &rhs) {
+        lhs *= rhs;
+        return lhs;
+    }
+    std::vector<uint64_t> into_words() && { return std::move(w_); }
+
+private:
+    CyclotomicConfig cfg_;
+    std::vector<uint64_t> w_;
+};
+
+// Vec<RqNTT>: the same bytes reinterpreted as CRT slots (crt.rs:61 transmute)
+class RqNTTVec {
+public:
+    RqNTTVec(CyclotomicConfig cfg, std::vector<uint64_t> words) : cfg_(std::move(cfg)), w_(std::move(words)) {
+        if (w_.size() % cfg_.words_per_elem()) throw std::length_error("Should be of correct length");  // ntt_form.rs:703
+    }
+    size_t len() const { return w_.size() / cfg_.words_per_elem(); }
+    const std::vector<uint64_t> &words() const { return w_; }
+    const CyclotomicConfig &config() const { return cfg_; }
+    bool operator==(const RqNTTVec &o) const { return w_ == o.w_; }
+
+    RqPolyVec elementwise_icrt() && {                            // crt.rs:34-49
+        CyclotomicConfig::check(sr_ntt_inv_batch(cfg_.raw(), w_.data(), len()), "elementwise_icrt");
+        return RqPolyVec(cfg_, std::move(w_));
+    }
+    RqNTTVec &operator*=(const RqNTTVec &rhs) {                  // ntt_form.rs:213-225
+        if (rhs.w_.size() != w_.size()) throw std::length_error("operand lengths differ");
+        CyclotomicConfig::check(sr_pointwise_mul_batch(cfg_.raw(), w_.data(), rhs.w_.data(), len()), "RqNTT *=");
+        return *this;
+    }
+    friend RqNTTVec operator*(RqNTTVec lhs, const RqNTTVec &rhs) {
+        lhs *= rhs;
+        return lhs;
+    }
+    std::vector<uint64_t> into_words() && { return std::move(w_); }
+
+private:
+    CyclotomicConfig cfg_;
+    std::vector<uint64_t> w_;
+};
+
+inline RqNTTVec RqPolyVec::elementwise_crt() && {
+    CyclotomicConfig::check(sr_ntt_fwd_batch(cfg_.raw(), w_.data(), len()), "elementwise_crt");
+    return RqNTTVec(cfg_, std::move(w_));
+}
+
+// Flatten (flatten.rs:10-34): the flat coefficient vector IS the batch's storage; both directions are moves.
+template <class V>
+inline std::vector<uint64_t> flatten_to_coeffs(V &&vec) {
+    return std::move(vec).into_words();
+}
+template <class V>
+inline std::optional<V> promote_from_coeffs(const CyclotomicConfig &cfg, std::vector<uint64_t> coeffs) {
+    if (coeffs.size() % cfg.words_per_elem() != 0) return std::nullopt;  // flatten.rs:22-24
+    return V(cfg, std::move(coeffs));
+}
+
+}  // namespace stark_rings

@@ -1,0 +1,124 @@
+// C++ parity tests of the host-side mirror (include/stark_rings.hpp), shaped after the reference's own tests:
+//   crt.rs:85-147            trait-level round trips, single and elementwise (all models)
+//   flatten.rs:58-139        flatten / promote
+//   stark_prime/mod.rs:161-177, goldilocks/mod.rs:231-247   NTT product == schoolbook product reduced mod Phi
+//   goldilocks/ntt.rs:136 etc.  wrong length panics
+// The expected values come from the oracle (oracle/sr_oracle.h), which this TEST links; the product does not.
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "../../include/stark_rings.hpp"
+#include "../../oracle/sr_oracle.h"
+
+using namespace stark_rings;
+
+static int failures = 0;
+#define EXPECT(cond)                                                       \
+    do {                                                                   \
+        if (!(cond)) {                                                     \
+            std::printf("FAIL %s:%d  %s\n", __FILE__, __LINE__, #cond);    \
+            failures++;                                                    \
+        }                                                                  \
+    } while (0)
+
+static std::vector<uint64_t> uniform(int field, uint64_t seed, size_t n_coeffs) {
+    std::vector<uint64_t> v(n_coeffs * sro_limbs(field));
+    sro_fill_uniform(field, seed, 0, n_coeffs, v.data());
+    return v;
+}
+
+static void pow2_suite(sr_ring ring, int field, int log2d, size_t batch) {
+    CyclotomicConfig cfg(ring, log2d);
+    const size_t d = cfg.dimension(), L = cfg.limbs();
+    EXPECT(d == (size_t)1 << log2d);
+    auto a = uniform(field, 11, batch * d), b = uniform(field, 12, batch * d);
+
+    // test_crt_trait_vec_conversion_* (crt.rs:103-121)
+    RqPolyVec orig(cfg, a);
+    RqNTTVec ntt = RqPolyVec(cfg, a).elementwise_crt();
+    std::vector<uint64_t> want = a;
+    sro_pow2_fwd_batch(field, want.data(), log2d, batch, 2);
+    EXPECT(ntt.words() == want);
+    RqPolyVec back = std::move(ntt).elementwise_icrt();
+    EXPECT(back == orig);
+
+    // single element through CyclotomicConfig::crt / icrt (ring_config.rs:29-30)
+    std::vector<uint64_t> one(a.begin(), a.begin() + d * L);
+    auto c1 = cfg.crt(one);
+    EXPECT(std::equal(c1.begin(), c1.end(), want.begin()));
+    EXPECT(cfg.icrt(c1) == one);
+
+    // test_mul_crt: ntt_form_1 * ntt_form_2 then icrt == coeff_1 * coeff_2 == schoolbook reduced
+    RqNTTVec n1 = RqPolyVec(cfg, a).elementwise_crt(), n2 = RqPolyVec(cfg, b).elementwise_crt();
+    RqPolyVec via_ntt = (std::move(n1) * n2).elementwise_icrt();
+    RqPolyVec direct = RqPolyVec(cfg, a) * RqPolyVec(cfg, b);
+    EXPECT(via_ntt == direct);
+    if (d <= 256) {
+        std::vector<uint64_t> sb((2 * d - 1) * L);
+        sro_schoolbook(field, a.data(), b.data(), d, sb.data());
+        cfg.reduce_in_place(sb);  // test_reduce (stark_prime/mod.rs:139-159)
+        EXPECT(sb.size() == d * L);
+        EXPECT(std::equal(sb.begin(), sb.end(), direct.words().begin()));
+    }
+
+    // flatten / promote (flatten.rs:128-138)
+    auto flat = flatten_to_coeffs(RqPolyVec(cfg, a));
+    EXPECT(flat == a);
+    auto promoted = promote_from_coeffs<RqPolyVec>(cfg, flat);
+    EXPECT(promoted.has_value() && *promoted == orig);
+    flat.pop_back();
+    EXPECT(!promote_from_coeffs<RqPolyVec>(cfg, flat).has_value());
+
+    // "Panics if coefficients.len() != D"
+    bool threw = false;
+    try {
+        std::vector<uint64_t> bad(d * L + L);
+        cfg.crt_in_place(bad.data(), bad.size());
+    } catch (const std::length_error &) {
+        threw = true;
+    }
+    EXPECT(threw);
+}
+
+static void small_suite(sr_ring ring, int field, int D, void (*crt)(uint64_t *), void (*mul)(uint64_t *, const uint64_t *),
+                        void (*icrt)(uint64_t *)) {
+    CyclotomicConfig cfg(ring);
+    EXPECT(cfg.dimension() == (size_t)D);
+    EXPECT(cfg.crt_field_extension_degree() == D / 8);
+    const size_t batch = 100;  // crt.rs:106-121 uses 100 x 100
+    auto a = uniform(field, 21, batch * D), b = uniform(field, 22, batch * D);
+    RqNTTVec na = RqPolyVec(cfg, a).elementwise_crt();
+    RqNTTVec nb = RqPolyVec(cfg, b).elementwise_crt();
+    std::vector<uint64_t> wa = a, wb = b;
+    for (size_t e = 0; e < batch; e++) {
+        crt(wa.data() + e * D);
+        crt(wb.data() + e * D);
+    }
+    EXPECT(na.words() == wa);
+    RqNTTVec prod = na * nb;
+    for (size_t e = 0; e < batch; e++) mul(wa.data() + e * D, wb.data() + e * D);
+    EXPECT(prod.words() == wa);
+    RqPolyVec c = std::move(prod).elementwise_icrt();
+    for (size_t e = 0; e < batch; e++) icrt(wa.data() + e * D);
+    EXPECT(c.words() == wa);
+    EXPECT(c == RqPolyVec(cfg, a) * RqPolyVec(cfg, b));
+    EXPECT(std::move(na).elementwise_icrt() == RqPolyVec(cfg, a));
+}
+
+int main() {
+    try {
+        pow2_suite(SR_RING_GOLDILOCKS_POW2, SRO_GOLDILOCKS, 10, 3);   // BASELINE configs[0]: D = 2^10 (batch 1 is element 0)
+        pow2_suite(SR_RING_GOLDILOCKS_POW2, SRO_GOLDILOCKS, 13, 2);
+        pow2_suite(SR_RING_BABYBEAR_POW2, SRO_BABYBEAR, 8, 5);
+        pow2_suite(SR_RING_STARK_POW2, SRO_STARK, 4, 100);            // the reference's stark_prime ring
+        pow2_suite(SR_RING_STARK_POW2, SRO_STARK, 8, 3);
+        small_suite(SR_RING_GOLDILOCKS_24, SRO_GOLDILOCKS, 24, sro_g24_crt, sro_g24_ntt_mul, sro_g24_icrt);
+        small_suite(SR_RING_BABYBEAR_72, SRO_BABYBEAR, 72, sro_bb72_crt, sro_bb72_ntt_mul, sro_bb72_icrt);
+    } catch (const std::exception &e) {
+        std::printf("EXCEPTION %s\n", e.what());
+        return 2;
+    }
+    std::printf(failures ? "host api: %d FAILURES\n" : "host api: all ok\n", failures);
+    return failures ? 1 : 0;
+}
