@@ -35,6 +35,30 @@ WORKLOADS = {
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 
 
+def usable_cores():
+    """Host cores this process may actually use: affinity mask capped by the cgroup CPU quota."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, -(-int(txt[0]) // int(txt[1]))))
+            else:
+                q = int(txt[0])
+                per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if q > 0:
+                    n = min(n, max(1, -(-q // per)))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    env = os.environ.get("SR_CPU_THREADS")
+    return int(env) if env else n
+
+
 class _DevMem:
     """Zero-copy torch view of device memory owned by the C library (__cuda_array_interface__)."""
 
@@ -157,6 +181,17 @@ def main():
     achieved_gbs = alg_bytes_per_launch / (dom_avg_ms * 1e-3) / 1e9
     step_gbs = bytes_per_mul * batch * world / (elapsed / args.steps) / 1e9 / world
 
+    # HBM traffic of the dominant kernel per launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE /
+    # WRITE_SIZE in their own runs, FETCH_SIZE doubled per MI355X_MICROARCH.md): profiles/<round>/traffic.json
+    traffic = None
+    try:
+        rounds = sorted(r for r in os.listdir(os.path.join(ROOT, "profiles")) if r.startswith("r"))
+        tj = json.load(open(os.path.join(ROOT, "profiles", rounds[-1], "traffic.json")))
+        if tj.get("workload") == args.workload and batch == tj.get("batch"):
+            traffic = tj["bytes_per_launch"].get(dom_tag)
+    except (OSError, ValueError, KeyError, IndexError):
+        pass
+
     out = {
         "metric": "ring-muls/sec (Goldilocks, deg 2^16, batch 2^14)" if args.workload == "goldilocks_d65536_b16384"
                   else "ring-muls/sec (%s)" % args.workload,
@@ -175,7 +210,7 @@ def main():
                    "global_batch": batch * world, "layout": "ark-ff Montgomery u64 limbs, in place (a *= b)",
                    "parallelism": "batch-sharded x%d, twiddle broadcast only" % world},
         "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": None,
+                     "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic,
                      "kernel": dom_tag, "kernel_avg_ms": dom_avg_ms, "launches_per_step": launches_per_step,
                      "algorithmic_bytes_per_ring_mul": bytes_per_mul,
                      "whole_step_achieved_per_gpu": step_gbs, "whole_step_frac": step_gbs / HBM_PEAK_GBS,
@@ -183,7 +218,7 @@ def main():
     }
 
     if world == 1 and not args.no_cpu_baseline:
-        cores = os.cpu_count() or 1
+        cores = usable_cores()
         n0 = max(cores, 8)
         ea = O.fill_uniform(F, 1, 0, n0 * d)
         eb = O.fill_uniform(F, 2, 0, n0 * d)

@@ -323,6 +323,11 @@ struct GoldilocksFastTables {
     bool ready = false;
     gl::Tables t{};
     size_t chunk_polys = 0;  // 0 = whole batch per launch
+    // optional 2-lane pipelining of chunks so that the memory-bound strided passes of one chunk overlap the
+    // VALU-bound rows kernel of another (lanes are internal streams forked from / joined to the caller's)
+    int n_lanes = 1;
+    hipStream_t lane[2] = {nullptr, nullptr};
+    hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr};
     // optional per-launch timing hooks (set by capi.hip): tag 0 strided fwd, 1 rows, 2 strided inv
     void (*prof_begin)(void *user, int tag, hipStream_t st) = nullptr;
     void (*prof_end)(void *user, hipStream_t st) = nullptr;
@@ -375,10 +380,30 @@ inline int gl_fast_init(GoldilocksFastTables &f, int k, const uint64_t *tw, cons
     f.t = gl::Tables{tw, itw, twist_f, twist_ip, twist_im, w1f, w1i, w2f, w2i};
     const char *env = getenv("SR_CHUNK_POLYS");
     f.chunk_polys = env ? (size_t)strtoull(env, nullptr, 10) : 0;
+    env = getenv("SR_LANES");
+    f.n_lanes = env ? atoi(env) : 1;
+    if (f.n_lanes < 1 || f.n_lanes > 2) f.n_lanes = 1;
+    if (f.n_lanes > 1) {
+        for (int i = 0; i < 2; i++) {
+            if (hipStreamCreateWithFlags(&f.lane[i], hipStreamNonBlocking) != hipSuccess) return 1;
+            if (hipEventCreateWithFlags(&f.ev_join[i], hipEventDisableTiming) != hipSuccess) return 1;
+        }
+        if (hipEventCreateWithFlags(&f.ev_fork, hipEventDisableTiming) != hipSuccess) return 1;
+    }
     f.ready = true;
     return 0;
 }
-inline void gl_fast_destroy(GoldilocksFastTables &f) { f.ready = false; }
+inline void gl_fast_destroy(GoldilocksFastTables &f) {
+    f.ready = false;
+    for (int i = 0; i < 2; i++) {
+        if (f.lane[i]) (void)hipStreamDestroy(f.lane[i]);
+        if (f.ev_join[i]) (void)hipEventDestroy(f.ev_join[i]);
+        f.lane[i] = nullptr;
+        f.ev_join[i] = nullptr;
+    }
+    if (f.ev_fork) (void)hipEventDestroy(f.ev_fork);
+    f.ev_fork = nullptr;
+}
 
 template <int DIR, bool TWIST>
 inline int gl_launch_strided(const GoldilocksFastTables &f, int M, uint64_t *data, int k, int s_lo, size_t npoly,
@@ -461,15 +486,29 @@ inline int gl_fast_ring_mul(const GoldilocksFastTables &f, uint64_t *out, const 
     if (batch == 0) return 0;
     const size_t chunk = f.chunk_polys ? f.chunk_polys : batch;
     const size_t stride = (size_t)1 << f.k;
-    for (size_t e = 0; e < batch; e += chunk) {
+    const bool lanes = f.n_lanes > 1 && chunk < batch;
+    if (lanes) {
+        if (hipEventRecord(f.ev_fork, st) != hipSuccess) return 1;
+        for (int i = 0; i < 2; i++)
+            if (hipStreamWaitEvent(f.lane[i], f.ev_fork, 0) != hipSuccess) return 1;
+    }
+    size_t ci = 0;
+    for (size_t e = 0; e < batch; e += chunk, ci++) {
         const size_t n = batch - e < chunk ? batch - e : chunk;
+        hipStream_t s = lanes ? f.lane[ci & 1] : st;
         uint64_t *o = out + e * stride, *bb = b + e * stride;
         const uint64_t *aa = a + e * stride;
-        if (o != aa && hipMemcpyAsync(o, aa, n * stride * 8, hipMemcpyDeviceToDevice, st) != hipSuccess) return 1;
-        if (gl_strided_fwd(f, o, n, st)) return 1;
-        if (gl_strided_fwd(f, bb, n, st)) return 1;
-        if (gl_launch_rows<2>(f, o, bb, o, n, st)) return 1;
-        if (gl_strided_inv(f, o, n, true, st)) return 1;
+        if (o != aa && hipMemcpyAsync(o, aa, n * stride * 8, hipMemcpyDeviceToDevice, s) != hipSuccess) return 1;
+        if (gl_strided_fwd(f, o, n, s)) return 1;
+        if (gl_strided_fwd(f, bb, n, s)) return 1;
+        if (gl_launch_rows<2>(f, o, bb, o, n, s)) return 1;
+        if (gl_strided_inv(f, o, n, true, s)) return 1;
+    }
+    if (lanes) {
+        for (int i = 0; i < 2; i++) {
+            if (hipEventRecord(f.ev_join[i], f.lane[i]) != hipSuccess) return 1;
+            if (hipStreamWaitEvent(st, f.ev_join[i], 0) != hipSuccess) return 1;
+        }
     }
     return 0;
 }

@@ -44,6 +44,14 @@ for k in sorted(agg["FETCH_SIZE"]):
 out.append("\nWhole step: %.1f GiB of HBM traffic for 16384 ring-muls = %.2f MB per ring-mul = %.2fx the algorithmic 3*D*8 = 1 572 864 B."
            % (total, total * 2**30 / 16384 / 1e6, total * 2**30 / 16384 / 1572864))
 out.append("Algorithmic bytes: rows kernel 24 GiB per launch (read a, read b, write c); each strided launch 16 GiB (read + write one operand).\n")
+import json
+tags = {"rows": [k for k in agg["FETCH_SIZE"] if "gl::rows_kernel<2>" in k],
+        "fwd_cols": [k for k in agg["FETCH_SIZE"] if "strided_kernel" in k and ", 0, " in k],
+        "inv_cols": [k for k in agg["FETCH_SIZE"] if "strided_kernel" in k and ", 1, " in k]}
+tj = {"workload": "goldilocks_d65536_b16384", "batch": 16384, "unit": "bytes of HBM traffic per launch (2*FETCH_SIZE + WRITE_SIZE)",
+      "bytes_per_launch": {t: int(sum(2 * agg["FETCH_SIZE"][k] + agg["WRITE_SIZE"].get(k, 0) for k in ks) * 1024 / max(1, len(ks)))
+                           for t, ks in tags.items() if ks}}
+json.dump(tj, open(os.path.join(d, "traffic.json"), "w"), indent=1)
 extra = os.path.join(d, "NOTES.md")
 if os.path.exists(extra):
     out.append(open(extra).read())
