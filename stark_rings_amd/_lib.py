@@ -7,7 +7,7 @@ import ctypes
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libstarkrings_hip.so")
+LIB_PATH = os.environ.get("SR_LIB_PATH") or os.path.join(HERE, "libstarkrings_hip.so")
 
 u64p = ctypes.POINTER(ctypes.c_uint64)
 _c = ctypes

@@ -20,6 +20,17 @@
 
 #define SR_HD __host__ __device__ __forceinline__
 
+// Optimisation barrier for carry chains.  ROCm 7.2's AMDGPU DAG combiner folds
+//   addcarry(subcarry(x, b, c0).value, 0, c1)  ->  addcarry(x, -b, c1)
+// keeping the VALUE right but not the CARRY-OUT, which breaks `carry of (x - b') + k` tests (seen as results off
+// by 2^64 mod p in the Fq3 slot products).  Passing the intermediate limb through an empty asm keeps the two
+// carry operations separate; it emits no instruction.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define SR_OPAQUE(x) asm("" : "+v"(x))  /* not volatile: free to be scheduled, only opaque to the combiner */
+#else
+#define SR_OPAQUE(x) ((void)0)
+#endif
+
 namespace sr {
 
 // ------------------------------------------------------------------------------------------
@@ -41,27 +52,74 @@ struct Goldilocks {
     SR_HD static void store(storage *p, elem v) { *p = v; }
     SR_HD static bool valid(elem v) { return v < P; }
 
+    // Carry chains are written with __builtin_addc / __builtin_subc on 32-bit limbs: hipcc turns them into
+    // v_add_co/v_addc_co (v_sub_co/v_subb_co) and pads the VCC hazards itself.  On gfx950 nearly every integer
+    // VALU instruction (carries, compares, v_cndmask, v_mad_u64_u32) issues at the same rate, so the goal is
+    // simply the fewest instructions: add 6, sub 5, reduce128 12 (profiles/r01/valu_issue_rates_gfx950.txt).
+#ifdef SR_OLD_ADD
     SR_HD static elem add(elem a, elem b) {
         uint64_t s = a + b;
-        bool fix = (s < a) | (s >= P);  // s - p == s + EPS (mod 2^64) in both cases
+        bool fix = (s < a) | (s >= P);
         return fix ? s + EPS : s;
     }
+#else
+    SR_HD static elem add(elem a, elem b) {
+        uint32_t c, c1, c2;
+        uint32_t s0 = __builtin_addc((uint32_t)a, (uint32_t)b, 0u, &c);
+        uint32_t s1 = __builtin_addc((uint32_t)(a >> 32), (uint32_t)(b >> 32), c, &c1);
+        SR_OPAQUE(s1);
+        uint32_t u0 = __builtin_addc(s0, 0xFFFFFFFFu, 0u, &c);  // u = s + EPS = s - p (mod 2^64)
+        uint32_t u1 = __builtin_addc(s1, 0u, c, &c2);            // c2 <=> s >= p (when c1 = 0)
+        bool fix = (c1 | c2) != 0;
+        return (uint64_t)(fix ? u0 : s0) | ((uint64_t)(fix ? u1 : s1) << 32);
+    }
+#endif
+    // a - b (+ p on borrow).  Exact for canonical a, b; also used with arbitrary a and b < 2^32 (reduce128).
+#ifdef SR_OLD_SUB
     SR_HD static elem sub(elem a, elem b) {
         uint64_t d = a - b;
-        return (a < b) ? d - EPS : d;  // + p == - EPS (mod 2^64)
+        return (a < b) ? d - EPS : d;
     }
+#else
+    SR_HD static elem sub(elem a, elem b) {
+        uint32_t c, br;
+        uint32_t d0 = __builtin_subc((uint32_t)a, (uint32_t)b, 0u, &c);
+        uint32_t d1 = __builtin_subc((uint32_t)(a >> 32), (uint32_t)(b >> 32), c, &br);
+        SR_OPAQUE(d1);
+        uint32_t m = 0u - br;                                     // borrow ? 0xFFFFFFFF : 0
+        uint32_t e0 = __builtin_subc(d0, m, 0u, &c);              // + p == - EPS (mod 2^64)
+        uint32_t e1 = __builtin_subc(d1, 0u, c, &c);
+        return (uint64_t)e0 | ((uint64_t)e1 << 32);
+    }
+#endif
     SR_HD static elem neg(elem a) { return a ? P - a : 0; }
 
-    // (hi * 2^64 + lo) mod p, using 2^64 = EPS and 2^96 = -1
+    // (hi * 2^64 + lo) mod p, using 2^64 = EPS and 2^96 = -1:  lo - hh + hl * EPS
+#ifdef SR_OLD_REDUCE
     SR_HD static elem reduce128(uint64_t lo, uint64_t hi) {
         uint32_t hh = (uint32_t)(hi >> 32), hl = (uint32_t)hi;
         uint64_t t0 = lo - hh;
         if (lo < hh) t0 -= EPS;
-        uint64_t t1 = ((uint64_t)hl << 32) - hl;  // hl * EPS
+        uint64_t t1 = ((uint64_t)hl << 32) - hl;
         uint64_t r = t0 + t1;
         if (r < t1) r += EPS;
         return r >= P ? r - P : r;
     }
+#else
+    SR_HD static elem reduce128(uint64_t lo, uint64_t hi) {
+        uint32_t hh = (uint32_t)(hi >> 32), hl = (uint32_t)hi;
+        uint64_t l2 = sub(lo, (uint64_t)hh);                      // any u64; borrow fixed by + p (never overflows: hh < 2^32)
+        unsigned __int128 w = (unsigned __int128)l2 + (uint64_t)hl * EPS;
+        uint64_t t = (uint64_t)w;
+        bool c1 = (uint64_t)(w >> 64) != 0;                       // then t <= 2^64 - 2^33 and t + EPS < p
+        uint32_t c, c2, t0 = (uint32_t)t, t1 = (uint32_t)(t >> 32);
+        SR_OPAQUE(t1);
+        uint32_t u0 = __builtin_addc(t0, 0xFFFFFFFFu, 0u, &c);
+        uint32_t u1 = __builtin_addc(t1, 0u, c, &c2);             // c2 <=> t >= p (when c1 = 0)
+        bool fix = c1 | (c2 != 0);
+        return (uint64_t)(fix ? u0 : t0) | ((uint64_t)(fix ? u1 : t1) << 32);
+    }
+#endif
     SR_HD static elem mul(elem a, elem b) {
         unsigned __int128 x = (unsigned __int128)a * b;
         return reduce128((uint64_t)x, (uint64_t)(x >> 64));
