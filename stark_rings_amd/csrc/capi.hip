@@ -16,6 +16,7 @@
 #include "fields.hpp"
 #include "ntt_generic.hpp"
 #include "ntt_goldilocks.hpp"
+#include "ntt_regtile.hpp"
 #include "small_rings.hpp"
 
 namespace {
@@ -56,6 +57,8 @@ struct sr_ctx {
     int device = 0;
     int log_tile = 12;
     bool fast_goldilocks = true;
+    bool regtile = false;   // BabyBear (and, for cross-checks, Goldilocks with SR_GOLDILOCKS_REGTILE=1): ntt_regtile.hpp
+    sr::rt::Hooks rt_hooks{};
     void *tables = nullptr;  // [tw (D elems) | itw (D elems)] in table form
     size_t table_bytes = 0;
     // inverse stage-0 constants (table form): plain inverse, and fused ring-mul (with boundary correction)
@@ -383,6 +386,36 @@ int count_dev(sr_ctx *c, const uint64_t *d, size_t n, uint64_t *host_count, hipS
     return SR_OK;
 }
 
+template <class F>
+sr::rt::Params<F> make_rt_params(const sr_ctx *c, bool fused) {
+    using E = typename F::elem;
+    sr::rt::Params<F> p;
+    p.k = c->k;
+    p.c = c->k - 12;
+    p.tw = (const E *)c->tables;
+    p.itw = p.tw + c->degree;
+    memcpy(&p.scale0, fused ? c->mul_scale0 : c->inv_scale0, sizeof(E));
+    memcpy(&p.scale1, fused ? c->mul_scale1 : c->inv_scale1, sizeof(E));
+    return p;
+}
+template <class F>
+int rt_fwd(sr_ctx *c, uint64_t *d, size_t batch, hipStream_t st) {
+    return sr::rt::fwd<F>(c->rt_hooks, reinterpret_cast<typename F::storage *>(d), batch, make_rt_params<F>(c, false), st)
+               ? fail(SR_E_HIP, "register-tiled launch failed") : SR_OK;
+}
+template <class F>
+int rt_inv(sr_ctx *c, uint64_t *d, size_t batch, hipStream_t st) {
+    return sr::rt::inv<F>(c->rt_hooks, reinterpret_cast<typename F::storage *>(d), batch, make_rt_params<F>(c, false), st)
+               ? fail(SR_E_HIP, "register-tiled launch failed") : SR_OK;
+}
+template <class F>
+int rt_ring_mul(sr_ctx *c, uint64_t *out, const uint64_t *a, uint64_t *b, size_t batch, hipStream_t st) {
+    using S = typename F::storage;
+    return sr::rt::ring_mul<F>(c->rt_hooks, reinterpret_cast<S *>(out), reinterpret_cast<const S *>(a),
+                               reinterpret_cast<S *>(b), batch, make_rt_params<F>(c, true), st)
+               ? fail(SR_E_HIP, "register-tiled launch failed") : SR_OK;
+}
+
 bool is_pow2_ring(int ring) { return ring >= SR_RING_GOLDILOCKS_POW2 && ring <= SR_RING_STARK_POW2; }
 
 // dispatch over the field of a pow2 ring
@@ -415,6 +448,10 @@ int check(sr_ctx *c, const void *p0, const void *p1 = (const void *)1, const voi
 int dev_fwd(sr_ctx *c, uint64_t *d, size_t batch, hipStream_t st) {
     if (c->ring == SR_RING_GOLDILOCKS_24) return sr::small_launch(c->small, sr::SMALL_G24_CRT, d, nullptr, 0, d, batch, st) ? fail(SR_E_HIP, "small-ring launch failed") : SR_OK;
     if (c->ring == SR_RING_BABYBEAR_72) return sr::small_launch(c->small, sr::SMALL_B72_CRT, d, nullptr, 0, d, batch, st) ? fail(SR_E_HIP, "small-ring launch failed") : SR_OK;
+    if (c->regtile) {
+        if (c->ring == SR_RING_BABYBEAR_POW2) return rt_fwd<sr::BabyBear>(c, d, batch, st);
+        return rt_fwd<sr::Goldilocks>(c, d, batch, st);
+    }
     if (c->ring == SR_RING_GOLDILOCKS_POW2 && c->fast_goldilocks && sr::gl_fast_supported(c->gl_fast)) {
         return sr::gl_fast_fwd(c->gl_fast, d, batch, st) ? fail(SR_E_HIP, "goldilocks fast-path launch failed") : SR_OK;
     }
@@ -423,6 +460,10 @@ int dev_fwd(sr_ctx *c, uint64_t *d, size_t batch, hipStream_t st) {
 int dev_inv(sr_ctx *c, uint64_t *d, size_t batch, hipStream_t st) {
     if (c->ring == SR_RING_GOLDILOCKS_24) return sr::small_launch(c->small, sr::SMALL_G24_ICRT, d, nullptr, 0, d, batch, st) ? fail(SR_E_HIP, "small-ring launch failed") : SR_OK;
     if (c->ring == SR_RING_BABYBEAR_72) return sr::small_launch(c->small, sr::SMALL_B72_ICRT, d, nullptr, 0, d, batch, st) ? fail(SR_E_HIP, "small-ring launch failed") : SR_OK;
+    if (c->regtile) {
+        if (c->ring == SR_RING_BABYBEAR_POW2) return rt_inv<sr::BabyBear>(c, d, batch, st);
+        return rt_inv<sr::Goldilocks>(c, d, batch, st);
+    }
     if (c->ring == SR_RING_GOLDILOCKS_POW2 && c->fast_goldilocks && sr::gl_fast_supported(c->gl_fast)) {
         return sr::gl_fast_inv(c->gl_fast, d, batch, st) ? fail(SR_E_HIP, "goldilocks fast-path launch failed") : SR_OK;
     }
@@ -436,6 +477,10 @@ int dev_pointwise(sr_ctx *c, uint64_t *l, const uint64_t *r, size_t batch, hipSt
 int dev_ring_mul(sr_ctx *c, uint64_t *out, const uint64_t *a, uint64_t *b, size_t batch, hipStream_t st) {
     if (c->ring == SR_RING_GOLDILOCKS_24) return sr::small_launch(c->small, sr::SMALL_G24_RINGMUL, a, b, 0, out, batch, st) ? fail(SR_E_HIP, "small-ring launch failed") : SR_OK;
     if (c->ring == SR_RING_BABYBEAR_72) return sr::small_launch(c->small, sr::SMALL_B72_RINGMUL, a, b, 0, out, batch, st) ? fail(SR_E_HIP, "small-ring launch failed") : SR_OK;
+    if (c->regtile) {
+        if (c->ring == SR_RING_BABYBEAR_POW2) return rt_ring_mul<sr::BabyBear>(c, out, a, b, batch, st);
+        return rt_ring_mul<sr::Goldilocks>(c, out, a, b, batch, st);
+    }
     if (c->ring == SR_RING_GOLDILOCKS_POW2 && c->fast_goldilocks && sr::gl_fast_supported(c->gl_fast)) {
         return sr::gl_fast_ring_mul(c->gl_fast, out, a, b, batch, st) ? fail(SR_E_HIP, "goldilocks fast-path launch failed") : SR_OK;
     }
@@ -495,7 +540,16 @@ int sr_ctx_create(int ring, int log2_degree, int device, sr_ctx **out) {
             c->gl_fast.prof_user = c;
             c->gl_fast.prof_begin = gl_prof_begin;
             c->gl_fast.prof_end = gl_prof_end;
+            const char *rt = getenv("SR_GOLDILOCKS_REGTILE");
+            c->regtile = rt && rt[0] == '1' && c->k >= 12 && c->k <= 24;
         }
+        if (ring == SR_RING_BABYBEAR_POW2) {
+            const char *env = getenv("SR_BABYBEAR_GENERIC");
+            c->regtile = !(env && env[0] == '1') && c->k >= 12 && c->k <= 24;
+        }
+        c->rt_hooks.user = c;
+        c->rt_hooks.begin = gl_prof_begin;
+        c->rt_hooks.end = gl_prof_end;
     } else {
         c->k = 0;
         c->degree = ring == SR_RING_GOLDILOCKS_24 ? 24 : 72;

@@ -254,7 +254,10 @@ __device__ __forceinline__ void tile_inv(u64 *x, u64 *lds, const int t, const Ta
 
 // MODE_FWD: a -> a (in place); MODE_INV: a -> a; MODE_MUL: out = a (.) b in the transformed domain and back
 template <int MODE>
-__global__ __launch_bounds__(256, 4) void rows_kernel(u64 *a, const u64 *b, u64 *out, Tables T) {
+#ifndef SR_ROWS_WAVES
+#define SR_ROWS_WAVES 4
+#endif
+__global__ __launch_bounds__(256, SR_ROWS_WAVES) void rows_kernel(u64 *a, const u64 *b, u64 *out, Tables T) {
     __shared__ u64 lds[kLdsElems];
     const int t = threadIdx.x;
     const size_t base = (size_t)blockIdx.x * kTile;

@@ -1,0 +1,322 @@
+// Register-tiled negacyclic NTT for word-sized fields (BabyBear here; any F with a 1- or 2-word element):
+// the reference's merged radix-2 stages (crates/ring/src/cyclotomic_ring/models/stark_prime/ntt.rs:121-346
+// generalised, twiddle of stage s block b = psi^brv_k(2^s + b)) executed FOUR STAGES AT A TIME on 16
+// coefficients held in registers, instead of one LDS round trip per stage (ntt_generic.hpp).
+//
+//   D = 2^c * 4096:  strided passes run stages 0..c-1 (2^M legs per lane, wave-uniform twiddles from scalar
+//   loads, coalesced stride-4096 accesses); the rows kernel owns one 4096-coefficient tile per workgroup
+//   (256 lanes x 16 coefficients) and runs stages c..c+11 as three radix-16 register passes with two trips
+//   through a padded LDS tile (pad = pos + pos/16: conflict-free for all three access patterns).
+//   MODE_MUL transforms a and b side by side (one twiddle fetch serves both), multiplies slot-wise
+//   (ntt_form.rs:177-189) and runs the inverse from registers: a, b read once, c written once.
+//   BabyBear arithmetic is 32-bit Montgomery (fields.hpp): 5 instructions per twiddle product, 3 per add/sub.
+#pragma once
+#include "fields.hpp"
+
+namespace sr {
+namespace rt {
+
+constexpr int kTile = 4096;
+constexpr int kLds = kTile + kTile / 16;
+
+template <class F>
+struct Params {
+    int k;   // log2 D
+    int c;   // k - 12
+    const typename F::elem *tw, *itw;
+    typename F::elem scale0, scale1;  // inverse stage 0: sum leg, diff leg (table form)
+};
+
+__device__ __forceinline__ int pad(int pos) { return pos + (pos >> 4); }
+
+// four merged forward stages on x[0..15]; stage u (0..3) of this pass is global stage s0 + u, and the pair
+// (j, j + (8 >> u)) belongs to block `blk0 << u | j >> (4 - u)` of that stage
+template <class F>
+__device__ __forceinline__ void fwd16(typename F::elem *x, const typename F::elem *tw, int s0, unsigned blk0) {
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+        const int half = 8 >> u;
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            if (j & half) continue;
+            const typename F::elem w = tw[(1u << (s0 + u)) + (blk0 << u) + (unsigned)(j >> (4 - u))];
+            const typename F::elem a = x[j], v = F::mul_tw(x[j + half], w);
+            x[j] = F::add(a, v);
+            x[j + half] = F::sub(a, v);
+        }
+    }
+}
+// same for two operands sharing the twiddles
+template <class F>
+__device__ __forceinline__ void fwd16x2(typename F::elem *x, typename F::elem *y, const typename F::elem *tw, int s0,
+                                        unsigned blk0) {
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+        const int half = 8 >> u;
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            if (j & half) continue;
+            const typename F::elem w = tw[(1u << (s0 + u)) + (blk0 << u) + (unsigned)(j >> (4 - u))];
+            typename F::elem a = x[j], v = F::mul_tw(x[j + half], w);
+            x[j] = F::add(a, v);
+            x[j + half] = F::sub(a, v);
+            a = y[j];
+            v = F::mul_tw(y[j + half], w);
+            y[j] = F::add(a, v);
+            y[j + half] = F::sub(a, v);
+        }
+    }
+}
+// four merged inverse (Gentleman-Sande) stages, stage s0+3 first; global stage 0 applies the D^-1 constants
+template <class F>
+__device__ __forceinline__ void inv16(typename F::elem *x, const Params<F> &p, int s0, unsigned blk0) {
+#pragma unroll
+    for (int u = 3; u >= 0; u--) {
+        const int half = 8 >> u;
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            if (j & half) continue;
+            const typename F::elem a = x[j], b = x[j + half];
+            const typename F::elem sum = F::add(a, b), dif = F::sub(a, b);
+            if (s0 + u == 0) {
+                x[j] = F::mul_tw(sum, p.scale0);
+                x[j + half] = F::mul_tw(dif, p.scale1);
+            } else {
+                x[j] = sum;
+                x[j + half] = F::mul_tw(dif, p.itw[(1u << (s0 + u)) + (blk0 << u) + (unsigned)(j >> (4 - u))]);
+            }
+        }
+    }
+}
+
+// MODE 0: forward in place; 1: inverse in place; 2: out = icrt(crt(a) (.) crt(b)) for this tile
+template <class F, int MODE>
+__global__ __launch_bounds__(256, 4) void rows_kernel(typename F::storage *a, const typename F::storage *b,
+                                                   typename F::storage *out, Params<F> p) {
+    using E = typename F::elem;
+    __shared__ E lds[(MODE == 2 ? 2 : 1) * kLds];
+    E *la = lds, *lb = lds + kLds;
+    const int t = threadIdx.x;
+    const size_t base = (size_t)blockIdx.x * kTile;
+    const unsigned tile_blk = blockIdx.x & ((1u << p.c) - 1u);
+    const int i0 = t & 15, base2 = (t >> 4) * 256 + i0;
+    E x[16], y[16];
+
+    if (MODE != 1) {
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            x[j] = F::load(a + base + j * 256 + t);
+            if (MODE == 2) y[j] = F::load(b + base + j * 256 + t);
+        }
+        // pass 1: tile-local stages 0..3, twiddles uniform over the workgroup
+        if (MODE == 2) fwd16x2<F>(x, y, p.tw, p.c, tile_blk); else fwd16<F>(x, p.tw, p.c, tile_blk);
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            la[pad(r * 256 + t)] = x[r];
+            if (MODE == 2) lb[pad(r * 256 + t)] = y[r];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            x[j] = la[pad(base2 + j * 16)];
+            if (MODE == 2) y[j] = lb[pad(base2 + j * 16)];
+        }
+        // pass 2: stages 4..7; after stage 3 the tile holds 16 blocks of 256, this lane works in block t >> 4
+        const unsigned blk2 = (tile_blk << 4) + (unsigned)(t >> 4);
+        if (MODE == 2) fwd16x2<F>(x, y, p.tw, p.c + 4, blk2); else fwd16<F>(x, p.tw, p.c + 4, blk2);
+#pragma unroll
+        for (int s = 0; s < 16; s++) {  // the very slots this lane just read
+            la[pad(base2 + s * 16)] = x[s];
+            if (MODE == 2) lb[pad(base2 + s * 16)] = y[s];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            x[j] = la[17 * t + j];
+            if (MODE == 2) y[j] = lb[17 * t + j];
+        }
+        // pass 3: stages 8..11 inside this lane's own 16 coefficients
+        const unsigned blk3 = (tile_blk << 8) + (unsigned)t;
+        if (MODE == 2) fwd16x2<F>(x, y, p.tw, p.c + 8, blk3); else fwd16<F>(x, p.tw, p.c + 8, blk3);
+        if (MODE == 0) {
+#pragma unroll
+            for (int j = 0; j < 16; j++) F::store(a + base + 16 * t + j, x[j]);
+            return;
+        }
+#pragma unroll
+        for (int j = 0; j < 16; j++) x[j] = F::mul_tw(x[j], y[j]);
+    } else {
+#pragma unroll
+        for (int j = 0; j < 16; j++) x[j] = F::load(a + base + 16 * t + j);
+    }
+
+    // inverse: stages c+11 .. c
+    inv16<F>(x, p, p.c + 8, (tile_blk << 8) + (unsigned)t);
+#pragma unroll
+    for (int j = 0; j < 16; j++) la[17 * t + j] = x[j];  // own slots (pass-3 reads of la by this lane are done)
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < 16; s++) x[s] = la[pad(base2 + s * 16)];
+    inv16<F>(x, p, p.c + 4, (tile_blk << 4) + (unsigned)(t >> 4));
+#pragma unroll
+    for (int j = 0; j < 16; j++) la[pad(base2 + j * 16)] = x[j];
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 16; r++) x[r] = la[pad(r * 256 + t)];
+    inv16<F>(x, p, p.c, tile_blk);
+#pragma unroll
+    for (int j = 0; j < 16; j++) F::store(out + base + j * 256 + t, x[j]);
+}
+
+// merged stages [s_lo, s_lo + M) on strided legs (stride S = D >> (s_lo + M) >= 4096), 2^M legs per lane
+template <class F, int M, int DIR>
+__global__ __launch_bounds__(256) void strided_kernel(typename F::storage *data, int s_lo, Params<F> p) {
+    using E = typename F::elem;
+    constexpr int R = 1 << M;
+    const int ls = p.k - s_lo - M;
+    const unsigned chunks = 1u << (ls - 8);
+    const unsigned ci = blockIdx.x & (chunks - 1u);
+    const unsigned rest = blockIdx.x >> (ls - 8);
+    const unsigned h = rest & ((1u << s_lo) - 1u);
+    const size_t poly = rest >> s_lo;
+    typename F::storage *base = data + (poly << p.k) + ((size_t)h << (p.k - s_lo)) + ci * 256u + threadIdx.x;
+    E x[R];
+#pragma unroll
+    for (int j = 0; j < R; j++) x[j] = F::load(base + ((size_t)j << ls));
+    if (DIR == 0) {
+#pragma unroll
+        for (int u = 0; u < M; u++) {
+            const int half = 1 << (M - 1 - u);
+#pragma unroll
+            for (int j = 0; j < R; j++) {
+                if (j & half) continue;
+                const E w = p.tw[(1u << (s_lo + u)) + (h << u) + (unsigned)(j >> (M - u))];
+                const E a = x[j], v = F::mul_tw(x[j + half], w);
+                x[j] = F::add(a, v);
+                x[j + half] = F::sub(a, v);
+            }
+        }
+    } else {
+#pragma unroll
+        for (int u = M - 1; u >= 0; u--) {
+            const int half = 1 << (M - 1 - u);
+#pragma unroll
+            for (int j = 0; j < R; j++) {
+                if (j & half) continue;
+                const E a = x[j], b = x[j + half];
+                const E sum = F::add(a, b), dif = F::sub(a, b);
+                if (s_lo + u == 0) {
+                    x[j] = F::mul_tw(sum, p.scale0);
+                    x[j + half] = F::mul_tw(dif, p.scale1);
+                } else {
+                    x[j] = sum;
+                    x[j + half] = F::mul_tw(dif, p.itw[(1u << (s_lo + u)) + (h << u) + (unsigned)(j >> (M - u))]);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < R; j++) F::store(base + ((size_t)j << ls), x[j]);
+}
+
+// ---- host-side launchers ---------------------------------------------------------------------------
+inline int plan(int c, int *ms) {  // split c strided stages into register passes of at most 4
+    int n = 0;
+    while (c > 0) {
+        int m = c > 4 ? (c >= 8 ? 4 : (c + 1) / 2) : c;
+        ms[n++] = m;
+        c -= m;
+    }
+    return n;
+}
+struct Hooks {  // optional per-launch timing (tags: 0 strided fwd, 1 rows, 2 strided inv)
+    void (*begin)(void *user, int tag, hipStream_t st) = nullptr;
+    void (*end)(void *user, hipStream_t st) = nullptr;
+    void *user = nullptr;
+};
+struct Scope {
+    const Hooks &h;
+    hipStream_t st;
+    Scope(const Hooks &hh, int tag, hipStream_t s) : h(hh), st(s) {
+        if (h.begin) h.begin(h.user, tag, st);
+    }
+    ~Scope() {
+        if (h.end) h.end(h.user, st);
+    }
+};
+template <class F, int DIR>
+inline int launch_strided(const Hooks &hk, int M, typename F::storage *d, int s_lo, size_t npoly, const Params<F> &p,
+                          hipStream_t st) {
+    const size_t blocks = (npoly << s_lo) << (p.k - s_lo - M - 8);
+    if (blocks == 0 || blocks > 0x7FFFFFFFull) return 1;
+    Scope sc(hk, DIR == 0 ? 0 : 2, st);
+    dim3 g((unsigned)blocks), b(256);
+    switch (M) {
+        case 1: hipLaunchKernelGGL((strided_kernel<F, 1, DIR>), g, b, 0, st, d, s_lo, p); break;
+        case 2: hipLaunchKernelGGL((strided_kernel<F, 2, DIR>), g, b, 0, st, d, s_lo, p); break;
+        case 3: hipLaunchKernelGGL((strided_kernel<F, 3, DIR>), g, b, 0, st, d, s_lo, p); break;
+        case 4: hipLaunchKernelGGL((strided_kernel<F, 4, DIR>), g, b, 0, st, d, s_lo, p); break;
+        default: return 1;
+    }
+    return hipGetLastError() != hipSuccess;
+}
+template <class F>
+inline int strided_fwd(const Hooks &hk, typename F::storage *d, size_t npoly, const Params<F> &p, hipStream_t st) {
+    int ms[8], s_lo = 0;
+    const int n = plan(p.c, ms);
+    for (int i = 0; i < n; i++) {
+        if (launch_strided<F, 0>(hk, ms[i], d, s_lo, npoly, p, st)) return 1;
+        s_lo += ms[i];
+    }
+    return 0;
+}
+template <class F>
+inline int strided_inv(const Hooks &hk, typename F::storage *d, size_t npoly, const Params<F> &p, hipStream_t st) {
+    int ms[8], s_lo = p.c;
+    const int n = plan(p.c, ms);
+    for (int i = n - 1; i >= 0; i--) {
+        s_lo -= ms[i];
+        if (launch_strided<F, 1>(hk, ms[i], d, s_lo, npoly, p, st)) return 1;
+    }
+    return 0;
+}
+template <class F, int MODE>
+inline int launch_rows(const Hooks &hk, typename F::storage *a, const typename F::storage *b, typename F::storage *out,
+                       size_t npoly, const Params<F> &p, hipStream_t st) {
+    const size_t tiles = npoly << p.c;
+    if (tiles == 0 || tiles > 0x7FFFFFFFull) return 1;
+    Scope sc(hk, 1, st);
+    hipLaunchKernelGGL((rows_kernel<F, MODE>), dim3((unsigned)tiles), dim3(256), 0, st, a, b, out, p);
+    return hipGetLastError() != hipSuccess;
+}
+template <class F>
+inline int fwd(const Hooks &hk, typename F::storage *d, size_t batch, const Params<F> &p, hipStream_t st) {
+    if (batch == 0) return 0;
+    if (strided_fwd<F>(hk, d, batch, p, st)) return 1;
+    return launch_rows<F, 0>(hk, d, nullptr, d, batch, p, st);
+}
+template <class F>
+inline int inv(const Hooks &hk, typename F::storage *d, size_t batch, const Params<F> &p, hipStream_t st) {
+    if (batch == 0) return 0;
+    if (launch_rows<F, 1>(hk, d, nullptr, d, batch, p, st)) return 1;
+    return strided_inv<F>(hk, d, batch, p, st);
+}
+// p must carry the FUSED stage-0 constants; b is overwritten with its strided-pass image when c > 0
+template <class F>
+inline int ring_mul(const Hooks &hk, typename F::storage *out, const typename F::storage *a, typename F::storage *b,
+                    size_t batch, const Params<F> &p, hipStream_t st) {
+    if (batch == 0) return 0;
+    if (p.c > 0) {
+        if (out != a &&
+            hipMemcpyAsync(out, a, (batch << p.k) * sizeof(typename F::storage), hipMemcpyDeviceToDevice, st) != hipSuccess)
+            return 1;
+        if (strided_fwd<F>(hk, out, batch, p, st)) return 1;
+        if (strided_fwd<F>(hk, b, batch, p, st)) return 1;
+        if (launch_rows<F, 2>(hk, out, b, out, batch, p, st)) return 1;
+        return strided_inv<F>(hk, out, batch, p, st);
+    }
+    return launch_rows<F, 2>(hk, const_cast<typename F::storage *>(a), b, out, batch, p, st);
+}
+
+}  // namespace rt
+}  // namespace sr

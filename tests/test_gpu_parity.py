@@ -277,3 +277,40 @@ def test_goldilocks_chunked_launches_equal_single_launch(torch_cuda):
         del os.environ["SR_CHUNK_POLYS"]
     assert np.array_equal(ring.mul(a, b), want)
     ring.close()
+
+
+# ----------------------------------------------------------------------------- register-tiled path (BabyBear; Goldilocks cross-check)
+@pytest.mark.parametrize("name,k,batch", [("babybear", 12, 5), ("babybear", 13, 3), ("babybear", 15, 2), ("babybear", 16, 3),
+                                          ("babybear", 17, 2), ("babybear", 18, 1), ("babybear", 20, 1),
+                                          ("goldilocks", 12, 3), ("goldilocks", 14, 2), ("goldilocks", 16, 2)])
+def test_register_tiled_path_matches_oracle_and_generic(torch_cuda, name, k, batch):
+    import os
+
+    from stark_rings_amd import CyclotomicRing
+
+    F = O.FIELD_ID[name]
+    env_on = {"goldilocks": "SR_GOLDILOCKS_REGTILE"}.get(name)      # BabyBear uses the register-tiled path by default
+    env_generic = {"babybear": "SR_BABYBEAR_GENERIC", "goldilocks": "SR_GOLDILOCKS_GENERIC"}[name]
+    if env_on:
+        os.environ[env_on] = "1"
+    try:
+        ring = CyclotomicRing(name, k, device=0)
+    finally:
+        if env_on:
+            del os.environ[env_on]
+    a = edge_and_random(F, k, batch, 0xE0 + k)
+    b = O.fill_uniform(F, 0xF0 + k, 0, batch << k)
+    fa = ring.elementwise_crt(a.copy())
+    assert np.array_equal(fa, O.pow2_fwd(F, a, k, batch, 4))
+    assert np.array_equal(ring.elementwise_icrt(fa.copy()), a)
+    assert np.array_equal(ring.elementwise_icrt(b.copy()), O.pow2_inv(F, b, k, batch, 4))
+    want = O.pow2_ring_mul(F, a, b, k, batch, 4)
+    assert np.array_equal(ring.mul(a, b), want)
+    ring.close()
+    os.environ[env_generic] = "1"
+    try:
+        generic = CyclotomicRing(name, k, device=0)
+    finally:
+        del os.environ[env_generic]
+    assert np.array_equal(generic.mul(a, b), want)
+    generic.close()
