@@ -204,7 +204,7 @@ def main():
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "u64" if ring_name != "stark" else "u256",
+        "dtype": {"goldilocks": "u64", "babybear": "u32", "stark": "u256"}[ring_name],
         "data": "synthetic",
         "config": {"workload": args.workload, "ring": ring_name, "degree": d, "batch_per_gpu": batch,
                    "global_batch": batch * world, "layout": "ark-ff Montgomery u64 limbs, in place (a *= b)",

@@ -59,6 +59,8 @@ struct sr_ctx {
     bool fast_goldilocks = true;
     bool regtile = false;   // BabyBear (and, for cross-checks, Goldilocks with SR_GOLDILOCKS_REGTILE=1): ntt_regtile.hpp
     sr::rt::Hooks rt_hooks{};
+    void *rt_scratch[2] = {nullptr, nullptr};   // packed intermediates of the register-tiled path
+    size_t rt_scratch_bytes[2] = {0, 0};
     void *tables = nullptr;  // [tw (D elems) | itw (D elems)] in table form
     size_t table_bytes = 0;
     // inverse stage-0 constants (table form): plain inverse, and fused ring-mul (with boundary correction)
@@ -398,21 +400,46 @@ sr::rt::Params<F> make_rt_params(const sr_ctx *c, bool fused) {
     memcpy(&p.scale1, fused ? c->mul_scale1 : c->inv_scale1, sizeof(E));
     return p;
 }
+// grow-only scratch for packed intermediates (allocated on first use; a hipMalloc here is why the very first
+// call of a given size is not graph-capturable)
+int rt_ensure_scratch(sr_ctx *c, int n_buffers, size_t bytes) {
+    if (c->k <= 12) return SR_OK;
+    for (int i = 0; i < n_buffers; i++) {
+        if (c->rt_scratch_bytes[i] >= bytes) continue;
+        HIP_TRY(hipDeviceSynchronize());
+        if (c->rt_scratch[i]) HIP_TRY(hipFree(c->rt_scratch[i]));
+        c->rt_scratch[i] = nullptr;
+        c->rt_scratch_bytes[i] = 0;
+        hipError_t e = hipMalloc(&c->rt_scratch[i], bytes);
+        if (e != hipSuccess) return fail(SR_E_ALLOC, std::string("hipMalloc scratch: ") + hipGetErrorString(e));
+        c->rt_scratch_bytes[i] = bytes;
+    }
+    return SR_OK;
+}
 template <class F>
 int rt_fwd(sr_ctx *c, uint64_t *d, size_t batch, hipStream_t st) {
-    return sr::rt::fwd<F>(c->rt_hooks, reinterpret_cast<typename F::storage *>(d), batch, make_rt_params<F>(c, false), st)
+    using E = typename F::elem;
+    if (int rc = rt_ensure_scratch(c, 1, (batch << c->k) * sizeof(E))) return rc;
+    return sr::rt::fwd<F>(c->rt_hooks, reinterpret_cast<typename F::storage *>(d), batch, make_rt_params<F>(c, false),
+                          (E *)c->rt_scratch[0], st)
                ? fail(SR_E_HIP, "register-tiled launch failed") : SR_OK;
 }
 template <class F>
 int rt_inv(sr_ctx *c, uint64_t *d, size_t batch, hipStream_t st) {
-    return sr::rt::inv<F>(c->rt_hooks, reinterpret_cast<typename F::storage *>(d), batch, make_rt_params<F>(c, false), st)
+    using E = typename F::elem;
+    if (int rc = rt_ensure_scratch(c, 1, (batch << c->k) * sizeof(E))) return rc;
+    return sr::rt::inv<F>(c->rt_hooks, reinterpret_cast<typename F::storage *>(d), batch, make_rt_params<F>(c, false),
+                          (E *)c->rt_scratch[0], st)
                ? fail(SR_E_HIP, "register-tiled launch failed") : SR_OK;
 }
 template <class F>
 int rt_ring_mul(sr_ctx *c, uint64_t *out, const uint64_t *a, uint64_t *b, size_t batch, hipStream_t st) {
     using S = typename F::storage;
+    using E = typename F::elem;
+    if (int rc = rt_ensure_scratch(c, 2, (batch << c->k) * sizeof(E))) return rc;
     return sr::rt::ring_mul<F>(c->rt_hooks, reinterpret_cast<S *>(out), reinterpret_cast<const S *>(a),
-                               reinterpret_cast<S *>(b), batch, make_rt_params<F>(c, true), st)
+                               reinterpret_cast<const S *>(b), batch, make_rt_params<F>(c, true), (E *)c->rt_scratch[0],
+                               (E *)c->rt_scratch[1], st)
                ? fail(SR_E_HIP, "register-tiled launch failed") : SR_OK;
 }
 
@@ -571,8 +598,10 @@ int sr_ctx_destroy(sr_ctx *c) {
     sr::gl_fast_destroy(c->gl_fast);
     sr::small_destroy(c->small);
     if (c->tables) (void)hipFree(c->tables);
-    for (int i = 0; i < 2; i++)
+    for (int i = 0; i < 2; i++) {
         if (c->stage[i]) (void)hipFree(c->stage[i]);
+        if (c->rt_scratch[i]) (void)hipFree(c->rt_scratch[i]);
+    }
     if (c->d_counter) (void)hipFree(c->d_counter);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;

@@ -10,6 +10,9 @@
 //   MODE_MUL transforms a and b side by side (one twiddle fetch serves both), multiplies slot-wise
 //   (ntt_form.rs:177-189) and runs the inverse from registers: a, b read once, c written once.
 //   BabyBear arithmetic is 32-bit Montgomery (fields.hpp): 5 instructions per twiddle product, 3 per add/sub.
+//   Intermediates between kernels live in library-owned scratch as bare 32-bit words (the reference's
+//   BabyBear limb is an 8-byte Fp64 with an always-zero upper half), so the caller's a and b are only read
+//   and a ring product moves 48 instead of 72 bytes per coefficient through HBM.
 #pragma once
 #include "fields.hpp"
 
@@ -28,6 +31,23 @@ struct Params {
 };
 
 __device__ __forceinline__ int pad(int pos) { return pos + (pos >> 4); }
+
+// Memory views.  Boundary = the reference's in-memory words (F::storage: for BabyBear an 8-byte Fp64 word whose
+// upper half is zero); Packed = bare F::elem words in library-owned scratch.  Intermediates between the strided
+// passes and the rows kernel travel Packed, which for BabyBear halves their HBM traffic.
+struct Boundary {};
+struct Packed {};
+template <class F, class V> struct View;
+template <class F> struct View<F, Boundary> {
+    typedef typename F::storage T;
+    static __device__ __forceinline__ typename F::elem ld(const T *p) { return F::load(p); }
+    static __device__ __forceinline__ void st(T *p, const typename F::elem &v) { F::store(p, v); }
+};
+template <class F> struct View<F, Packed> {
+    typedef typename F::elem T;
+    static __device__ __forceinline__ typename F::elem ld(const T *p) { return *p; }
+    static __device__ __forceinline__ void st(T *p, const typename F::elem &v) { *p = v; }
+};
 
 // four merged forward stages on x[0..15]; stage u (0..3) of this pass is global stage s0 + u, and the pair
 // (j, j + (8 >> u)) belongs to block `blk0 << u | j >> (4 - u)` of that stage
@@ -90,10 +110,12 @@ __device__ __forceinline__ void inv16(typename F::elem *x, const Params<F> &p, i
 }
 
 // MODE 0: forward in place; 1: inverse in place; 2: out = icrt(crt(a) (.) crt(b)) for this tile
-template <class F, int MODE>
-__global__ __launch_bounds__(256, 4) void rows_kernel(typename F::storage *a, const typename F::storage *b,
-                                                   typename F::storage *out, Params<F> p) {
+template <class F, int MODE, class VI, class VO>
+__global__ __launch_bounds__(256, 4) void rows_kernel(const typename View<F, VI>::T *a, const typename View<F, VI>::T *b,
+                                                      typename View<F, VO>::T *out, Params<F> p) {
     using E = typename F::elem;
+    using In = View<F, VI>;
+    using Out = View<F, VO>;
     __shared__ E lds[(MODE == 2 ? 2 : 1) * kLds];
     E *la = lds, *lb = lds + kLds;
     const int t = threadIdx.x;
@@ -105,8 +127,8 @@ __global__ __launch_bounds__(256, 4) void rows_kernel(typename F::storage *a, co
     if (MODE != 1) {
 #pragma unroll
         for (int j = 0; j < 16; j++) {
-            x[j] = F::load(a + base + j * 256 + t);
-            if (MODE == 2) y[j] = F::load(b + base + j * 256 + t);
+            x[j] = In::ld(a + base + j * 256 + t);
+            if (MODE == 2) y[j] = In::ld(b + base + j * 256 + t);
         }
         // pass 1: tile-local stages 0..3, twiddles uniform over the workgroup
         if (MODE == 2) fwd16x2<F>(x, y, p.tw, p.c, tile_blk); else fwd16<F>(x, p.tw, p.c, tile_blk);
@@ -140,14 +162,14 @@ __global__ __launch_bounds__(256, 4) void rows_kernel(typename F::storage *a, co
         if (MODE == 2) fwd16x2<F>(x, y, p.tw, p.c + 8, blk3); else fwd16<F>(x, p.tw, p.c + 8, blk3);
         if (MODE == 0) {
 #pragma unroll
-            for (int j = 0; j < 16; j++) F::store(a + base + 16 * t + j, x[j]);
+            for (int j = 0; j < 16; j++) Out::st(out + base + 16 * t + j, x[j]);
             return;
         }
 #pragma unroll
         for (int j = 0; j < 16; j++) x[j] = F::mul_tw(x[j], y[j]);
     } else {
 #pragma unroll
-        for (int j = 0; j < 16; j++) x[j] = F::load(a + base + 16 * t + j);
+        for (int j = 0; j < 16; j++) x[j] = In::ld(a + base + 16 * t + j);
     }
 
     // inverse: stages c+11 .. c
@@ -165,12 +187,13 @@ __global__ __launch_bounds__(256, 4) void rows_kernel(typename F::storage *a, co
     for (int r = 0; r < 16; r++) x[r] = la[pad(r * 256 + t)];
     inv16<F>(x, p, p.c, tile_blk);
 #pragma unroll
-    for (int j = 0; j < 16; j++) F::store(out + base + j * 256 + t, x[j]);
+    for (int j = 0; j < 16; j++) Out::st(out + base + j * 256 + t, x[j]);
 }
 
 // merged stages [s_lo, s_lo + M) on strided legs (stride S = D >> (s_lo + M) >= 4096), 2^M legs per lane
-template <class F, int M, int DIR>
-__global__ __launch_bounds__(256) void strided_kernel(typename F::storage *data, int s_lo, Params<F> p) {
+template <class F, int M, int DIR, class VI, class VO>
+__global__ __launch_bounds__(256) void strided_kernel(const typename View<F, VI>::T *src, typename View<F, VO>::T *dst,
+                                                      int s_lo, Params<F> p) {
     using E = typename F::elem;
     constexpr int R = 1 << M;
     const int ls = p.k - s_lo - M;
@@ -179,10 +202,10 @@ __global__ __launch_bounds__(256) void strided_kernel(typename F::storage *data,
     const unsigned rest = blockIdx.x >> (ls - 8);
     const unsigned h = rest & ((1u << s_lo) - 1u);
     const size_t poly = rest >> s_lo;
-    typename F::storage *base = data + (poly << p.k) + ((size_t)h << (p.k - s_lo)) + ci * 256u + threadIdx.x;
+    const size_t off = (poly << p.k) + ((size_t)h << (p.k - s_lo)) + ci * 256u + threadIdx.x;
     E x[R];
 #pragma unroll
-    for (int j = 0; j < R; j++) x[j] = F::load(base + ((size_t)j << ls));
+    for (int j = 0; j < R; j++) x[j] = View<F, VI>::ld(src + off + ((size_t)j << ls));
     if (DIR == 0) {
 #pragma unroll
         for (int u = 0; u < M; u++) {
@@ -216,7 +239,7 @@ __global__ __launch_bounds__(256) void strided_kernel(typename F::storage *data,
         }
     }
 #pragma unroll
-    for (int j = 0; j < R; j++) F::store(base + ((size_t)j << ls), x[j]);
+    for (int j = 0; j < R; j++) View<F, VO>::st(dst + off + ((size_t)j << ls), x[j]);
 }
 
 // ---- host-side launchers ---------------------------------------------------------------------------
@@ -244,78 +267,86 @@ struct Scope {
         if (h.end) h.end(h.user, st);
     }
 };
-template <class F, int DIR>
-inline int launch_strided(const Hooks &hk, int M, typename F::storage *d, int s_lo, size_t npoly, const Params<F> &p,
-                          hipStream_t st) {
+template <class F, int DIR, class VI, class VO>
+inline int launch_strided(const Hooks &hk, int M, const typename View<F, VI>::T *src, typename View<F, VO>::T *dst, int s_lo,
+                          size_t npoly, const Params<F> &p, hipStream_t st) {
     const size_t blocks = (npoly << s_lo) << (p.k - s_lo - M - 8);
     if (blocks == 0 || blocks > 0x7FFFFFFFull) return 1;
     Scope sc(hk, DIR == 0 ? 0 : 2, st);
     dim3 g((unsigned)blocks), b(256);
     switch (M) {
-        case 1: hipLaunchKernelGGL((strided_kernel<F, 1, DIR>), g, b, 0, st, d, s_lo, p); break;
-        case 2: hipLaunchKernelGGL((strided_kernel<F, 2, DIR>), g, b, 0, st, d, s_lo, p); break;
-        case 3: hipLaunchKernelGGL((strided_kernel<F, 3, DIR>), g, b, 0, st, d, s_lo, p); break;
-        case 4: hipLaunchKernelGGL((strided_kernel<F, 4, DIR>), g, b, 0, st, d, s_lo, p); break;
+        case 1: hipLaunchKernelGGL((strided_kernel<F, 1, DIR, VI, VO>), g, b, 0, st, src, dst, s_lo, p); break;
+        case 2: hipLaunchKernelGGL((strided_kernel<F, 2, DIR, VI, VO>), g, b, 0, st, src, dst, s_lo, p); break;
+        case 3: hipLaunchKernelGGL((strided_kernel<F, 3, DIR, VI, VO>), g, b, 0, st, src, dst, s_lo, p); break;
+        case 4: hipLaunchKernelGGL((strided_kernel<F, 4, DIR, VI, VO>), g, b, 0, st, src, dst, s_lo, p); break;
         default: return 1;
     }
     return hipGetLastError() != hipSuccess;
 }
+// forward strided stages: boundary words at `src` -> packed words at `dst` (c >= 1)
 template <class F>
-inline int strided_fwd(const Hooks &hk, typename F::storage *d, size_t npoly, const Params<F> &p, hipStream_t st) {
+inline int strided_fwd(const Hooks &hk, const typename F::storage *src, typename F::elem *dst, size_t npoly,
+                       const Params<F> &p, hipStream_t st) {
     int ms[8], s_lo = 0;
     const int n = plan(p.c, ms);
     for (int i = 0; i < n; i++) {
-        if (launch_strided<F, 0>(hk, ms[i], d, s_lo, npoly, p, st)) return 1;
+        int rc = i == 0 ? launch_strided<F, 0, Boundary, Packed>(hk, ms[i], src, dst, s_lo, npoly, p, st)
+                        : launch_strided<F, 0, Packed, Packed>(hk, ms[i], dst, dst, s_lo, npoly, p, st);
+        if (rc) return rc;
         s_lo += ms[i];
     }
     return 0;
 }
+// inverse strided stages: packed words at `src` (clobbered) -> boundary words at `dst`
 template <class F>
-inline int strided_inv(const Hooks &hk, typename F::storage *d, size_t npoly, const Params<F> &p, hipStream_t st) {
+inline int strided_inv(const Hooks &hk, typename F::elem *src, typename F::storage *dst, size_t npoly, const Params<F> &p,
+                       hipStream_t st) {
     int ms[8], s_lo = p.c;
     const int n = plan(p.c, ms);
     for (int i = n - 1; i >= 0; i--) {
         s_lo -= ms[i];
-        if (launch_strided<F, 1>(hk, ms[i], d, s_lo, npoly, p, st)) return 1;
+        int rc = i == 0 ? launch_strided<F, 1, Packed, Boundary>(hk, ms[i], src, dst, s_lo, npoly, p, st)
+                        : launch_strided<F, 1, Packed, Packed>(hk, ms[i], src, src, s_lo, npoly, p, st);
+        if (rc) return rc;
     }
     return 0;
 }
-template <class F, int MODE>
-inline int launch_rows(const Hooks &hk, typename F::storage *a, const typename F::storage *b, typename F::storage *out,
-                       size_t npoly, const Params<F> &p, hipStream_t st) {
+template <class F, int MODE, class VI, class VO>
+inline int launch_rows(const Hooks &hk, const typename View<F, VI>::T *a, const typename View<F, VI>::T *b,
+                       typename View<F, VO>::T *out, size_t npoly, const Params<F> &p, hipStream_t st) {
     const size_t tiles = npoly << p.c;
     if (tiles == 0 || tiles > 0x7FFFFFFFull) return 1;
     Scope sc(hk, 1, st);
-    hipLaunchKernelGGL((rows_kernel<F, MODE>), dim3((unsigned)tiles), dim3(256), 0, st, a, b, out, p);
+    hipLaunchKernelGGL((rows_kernel<F, MODE, VI, VO>), dim3((unsigned)tiles), dim3(256), 0, st, a, b, out, p);
     return hipGetLastError() != hipSuccess;
 }
+// scratch0 / scratch1: library-owned device buffers of batch * D elems each (only touched when c > 0)
 template <class F>
-inline int fwd(const Hooks &hk, typename F::storage *d, size_t batch, const Params<F> &p, hipStream_t st) {
+inline int fwd(const Hooks &hk, typename F::storage *d, size_t batch, const Params<F> &p, typename F::elem *scratch0,
+               hipStream_t st) {
     if (batch == 0) return 0;
-    if (strided_fwd<F>(hk, d, batch, p, st)) return 1;
-    return launch_rows<F, 0>(hk, d, nullptr, d, batch, p, st);
+    if (p.c == 0) return launch_rows<F, 0, Boundary, Boundary>(hk, d, nullptr, d, batch, p, st);
+    if (strided_fwd<F>(hk, d, scratch0, batch, p, st)) return 1;
+    return launch_rows<F, 0, Packed, Boundary>(hk, scratch0, nullptr, d, batch, p, st);
 }
 template <class F>
-inline int inv(const Hooks &hk, typename F::storage *d, size_t batch, const Params<F> &p, hipStream_t st) {
+inline int inv(const Hooks &hk, typename F::storage *d, size_t batch, const Params<F> &p, typename F::elem *scratch0,
+               hipStream_t st) {
     if (batch == 0) return 0;
-    if (launch_rows<F, 1>(hk, d, nullptr, d, batch, p, st)) return 1;
-    return strided_inv<F>(hk, d, batch, p, st);
+    if (p.c == 0) return launch_rows<F, 1, Boundary, Boundary>(hk, d, nullptr, d, batch, p, st);
+    if (launch_rows<F, 1, Boundary, Packed>(hk, d, nullptr, scratch0, batch, p, st)) return 1;
+    return strided_inv<F>(hk, scratch0, d, batch, p, st);
 }
-// p must carry the FUSED stage-0 constants; b is overwritten with its strided-pass image when c > 0
+// p must carry the FUSED stage-0 constants.  a and b are only read; out may alias a.
 template <class F>
-inline int ring_mul(const Hooks &hk, typename F::storage *out, const typename F::storage *a, typename F::storage *b,
-                    size_t batch, const Params<F> &p, hipStream_t st) {
+inline int ring_mul(const Hooks &hk, typename F::storage *out, const typename F::storage *a, const typename F::storage *b,
+                    size_t batch, const Params<F> &p, typename F::elem *scratch0, typename F::elem *scratch1, hipStream_t st) {
     if (batch == 0) return 0;
-    if (p.c > 0) {
-        if (out != a &&
-            hipMemcpyAsync(out, a, (batch << p.k) * sizeof(typename F::storage), hipMemcpyDeviceToDevice, st) != hipSuccess)
-            return 1;
-        if (strided_fwd<F>(hk, out, batch, p, st)) return 1;
-        if (strided_fwd<F>(hk, b, batch, p, st)) return 1;
-        if (launch_rows<F, 2>(hk, out, b, out, batch, p, st)) return 1;
-        return strided_inv<F>(hk, out, batch, p, st);
-    }
-    return launch_rows<F, 2>(hk, const_cast<typename F::storage *>(a), b, out, batch, p, st);
+    if (p.c == 0) return launch_rows<F, 2, Boundary, Boundary>(hk, a, b, out, batch, p, st);
+    if (strided_fwd<F>(hk, a, scratch0, batch, p, st)) return 1;
+    if (strided_fwd<F>(hk, b, scratch1, batch, p, st)) return 1;
+    if (launch_rows<F, 2, Packed, Packed>(hk, scratch0, scratch1, scratch0, batch, p, st)) return 1;
+    return strided_inv<F>(hk, scratch0, out, batch, p, st);
 }
 
 }  // namespace rt

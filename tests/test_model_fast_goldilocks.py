@@ -1,0 +1,37 @@
+"""The index-level Python model of the tuned Goldilocks decomposition (tools/model_fast_goldilocks.py) against the
+oracle's pure-Python model: strided merged stages + twist + cyclic 16x16x16 with omega_16 = 2^156 == the reference's
+negacyclic transform.  CPU only; this is the specification ntt_goldilocks.hpp was written from."""
+import os
+import random
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+import model_fast_goldilocks as M
+import pyref as P
+
+
+def test_radix16_networks_are_the_cyclic_dft_with_omega_2_pow_156():
+    rng = random.Random(3)
+    p = P.GOLDILOCKS_P
+    # omega_64 = 7^((p-1)/64) = 8^13  =>  omega_16 = 2^(12*13) = 2^156
+    assert pow(7, (p - 1) // 64, p) == pow(8, 13, p)
+    x = [rng.randrange(p) for _ in range(16)]
+    w = pow(2, M.W16_EXP, p)
+    ref = [sum(x[i] * pow(w, i * m, p) for i in range(16)) % p for m in range(16)]
+    got = M.dft16_fwd(x)
+    assert got == [ref[P.brv(r, 4)] for r in range(16)]
+    assert M.dft16_inv(got) == [16 * v % p for v in x]
+
+
+def test_decomposition_equals_reference_transform():
+    rng = random.Random(4)
+    p = P.GOLDILOCKS_P
+    for k in (12, 13):
+        T = M.tables(k)
+        a = [rng.randrange(p) for _ in range(1 << k)]
+        want = P.pow2_fwd("goldilocks", a, k)
+        got = M.fast_fwd(a, k, T)
+        assert got == want
+        assert M.fast_inv(got, k, T) == a
