@@ -168,21 +168,24 @@ struct BabyBear {
     SR_HD static void store(storage *p, elem v) { *p = (uint64_t)v; }
     SR_HD static bool valid(elem v) { return v < P; }
 
+    // conditional corrections as unsigned min(x, x -+ p): one plain add/sub plus one v_min_u32 (p < 2^31, so the
+    // wrapped alternative is always the larger of the two when no correction is due)
+    SR_HD static uint32_t umin(uint32_t x, uint32_t y) { return x < y ? x : y; }
     SR_HD static elem add(elem a, elem b) {
         uint32_t s = a + b;  // < 2^32
-        return s >= P ? s - P : s;
+        return umin(s, s - P);
     }
     SR_HD static elem sub(elem a, elem b) {
         uint32_t d = a - b;
-        return a < b ? d + P : d;
+        return umin(d, d + P);
     }
     SR_HD static elem neg(elem a) { return a ? P - a : 0; }
     // a * b * 2^-32 mod p
     SR_HD static elem mont32(elem a, elem b) {
         uint64_t t = (uint64_t)a * b;
         uint32_t m = (uint32_t)t * PINV;
-        uint32_t u = (uint32_t)((t + (uint64_t)m * P) >> 32);
-        return u >= P ? u - P : u;
+        uint32_t u = (uint32_t)((t + (uint64_t)m * P) >> 32);  // < 2p
+        return umin(u, u - P);
     }
     SR_HD static elem mul_tw(elem a, elem w) { return mont32(a, w); }
     SR_HD static elem mul_boundary(elem a, elem b) { return mont32(mont32(a, b), 1u); }

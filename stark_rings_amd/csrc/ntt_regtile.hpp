@@ -49,47 +49,34 @@ template <class F> struct View<F, Packed> {
     static __device__ __forceinline__ void st(T *p, const typename F::elem &v) { *p = v; }
 };
 
-// four merged forward stages on x[0..15]; stage u (0..3) of this pass is global stage s0 + u, and the pair
-// (j, j + (8 >> u)) belongs to block `blk0 << u | j >> (4 - u)` of that stage
+// the 15 twiddles of four merged stages starting at global stage s0 for a lane working in block blk0 of stage s0:
+// w[(1 << u) - 1 + i] = table[2^(s0+u) + (blk0 << u) + i], u = 0..3, i < 2^u
 template <class F>
-__device__ __forceinline__ void fwd16(typename F::elem *x, const typename F::elem *tw, int s0, unsigned blk0) {
+__device__ __forceinline__ void load_tw16(typename F::elem *w, const typename F::elem *table, int s0, unsigned blk0) {
+#pragma unroll
+    for (int u = 0; u < 4; u++)
+#pragma unroll
+        for (int i = 0; i < (1 << u); i++) w[(1 << u) - 1 + i] = table[(1u << (s0 + u)) + (blk0 << u) + (unsigned)i];
+}
+// four merged forward stages on x[0..15]: stage u pairs (j, j + (8 >> u)) with twiddle w[(1 << u) - 1 + (j >> (4 - u))]
+template <class F>
+__device__ __forceinline__ void fwd16(typename F::elem *x, const typename F::elem *w) {
 #pragma unroll
     for (int u = 0; u < 4; u++) {
         const int half = 8 >> u;
 #pragma unroll
         for (int j = 0; j < 16; j++) {
             if (j & half) continue;
-            const typename F::elem w = tw[(1u << (s0 + u)) + (blk0 << u) + (unsigned)(j >> (4 - u))];
-            const typename F::elem a = x[j], v = F::mul_tw(x[j + half], w);
+            const typename F::elem a = x[j], v = F::mul_tw(x[j + half], w[(1 << u) - 1 + (j >> (4 - u))]);
             x[j] = F::add(a, v);
             x[j + half] = F::sub(a, v);
         }
     }
 }
-// same for two operands sharing the twiddles
-template <class F>
-__device__ __forceinline__ void fwd16x2(typename F::elem *x, typename F::elem *y, const typename F::elem *tw, int s0,
-                                        unsigned blk0) {
-#pragma unroll
-    for (int u = 0; u < 4; u++) {
-        const int half = 8 >> u;
-#pragma unroll
-        for (int j = 0; j < 16; j++) {
-            if (j & half) continue;
-            const typename F::elem w = tw[(1u << (s0 + u)) + (blk0 << u) + (unsigned)(j >> (4 - u))];
-            typename F::elem a = x[j], v = F::mul_tw(x[j + half], w);
-            x[j] = F::add(a, v);
-            x[j + half] = F::sub(a, v);
-            a = y[j];
-            v = F::mul_tw(y[j + half], w);
-            y[j] = F::add(a, v);
-            y[j + half] = F::sub(a, v);
-        }
-    }
-}
-// four merged inverse (Gentleman-Sande) stages, stage s0+3 first; global stage 0 applies the D^-1 constants
-template <class F>
-__device__ __forceinline__ void inv16(typename F::elem *x, const Params<F> &p, int s0, unsigned blk0) {
+// four merged inverse (Gentleman-Sande) stages, last stage first; with HAS_STAGE0 the final one is global stage 0
+// and applies the D^-1 constants instead of a twiddle
+template <class F, bool HAS_STAGE0>
+__device__ __forceinline__ void inv16(typename F::elem *x, const typename F::elem *w, const Params<F> &p) {
 #pragma unroll
     for (int u = 3; u >= 0; u--) {
         const int half = 8 >> u;
@@ -98,19 +85,20 @@ __device__ __forceinline__ void inv16(typename F::elem *x, const Params<F> &p, i
             if (j & half) continue;
             const typename F::elem a = x[j], b = x[j + half];
             const typename F::elem sum = F::add(a, b), dif = F::sub(a, b);
-            if (s0 + u == 0) {
+            if (HAS_STAGE0 && u == 0) {
                 x[j] = F::mul_tw(sum, p.scale0);
                 x[j + half] = F::mul_tw(dif, p.scale1);
             } else {
                 x[j] = sum;
-                x[j + half] = F::mul_tw(dif, p.itw[(1u << (s0 + u)) + (blk0 << u) + (unsigned)(j >> (4 - u))]);
+                x[j + half] = F::mul_tw(dif, w[(1 << u) - 1 + (j >> (4 - u))]);
             }
         }
     }
 }
 
 // MODE 0: forward in place; 1: inverse in place; 2: out = icrt(crt(a) (.) crt(b)) for this tile
-template <class F, int MODE, class VI, class VO>
+// C0: D = 4096 (c = 0), the tile is a whole ring element and its last inverse pass contains global stage 0
+template <class F, int MODE, class VI, class VO, bool C0>
 __global__ __launch_bounds__(256, 4) void rows_kernel(const typename View<F, VI>::T *a, const typename View<F, VI>::T *b,
                                                       typename View<F, VO>::T *out, Params<F> p) {
     using E = typename F::elem;
@@ -122,7 +110,8 @@ __global__ __launch_bounds__(256, 4) void rows_kernel(const typename View<F, VI>
     const size_t base = (size_t)blockIdx.x * kTile;
     const unsigned tile_blk = blockIdx.x & ((1u << p.c) - 1u);
     const int i0 = t & 15, base2 = (t >> 4) * 256 + i0;
-    E x[16], y[16];
+    E x[16], y[16], w[15], wn[15];
+    const unsigned blk2 = (tile_blk << 4) + (unsigned)(t >> 4), blk3 = (tile_blk << 8) + (unsigned)t;
 
     if (MODE != 1) {
 #pragma unroll
@@ -130,8 +119,12 @@ __global__ __launch_bounds__(256, 4) void rows_kernel(const typename View<F, VI>
             x[j] = In::ld(a + base + j * 256 + t);
             if (MODE == 2) y[j] = In::ld(b + base + j * 256 + t);
         }
-        // pass 1: tile-local stages 0..3, twiddles uniform over the workgroup
-        if (MODE == 2) fwd16x2<F>(x, y, p.tw, p.c, tile_blk); else fwd16<F>(x, p.tw, p.c, tile_blk);
+        // pass 1: tile-local stages 0..3, twiddles uniform over the workgroup (scalar loads); the per-lane
+        // twiddles of pass 2 are requested now so that they arrive behind the LDS exchange
+        load_tw16<F>(w, p.tw, p.c, tile_blk);
+        load_tw16<F>(wn, p.tw, p.c + 4, blk2);
+        fwd16<F>(x, w);
+        if (MODE == 2) fwd16<F>(y, w);
 #pragma unroll
         for (int r = 0; r < 16; r++) {
             la[pad(r * 256 + t)] = x[r];
@@ -144,8 +137,9 @@ __global__ __launch_bounds__(256, 4) void rows_kernel(const typename View<F, VI>
             if (MODE == 2) y[j] = lb[pad(base2 + j * 16)];
         }
         // pass 2: stages 4..7; after stage 3 the tile holds 16 blocks of 256, this lane works in block t >> 4
-        const unsigned blk2 = (tile_blk << 4) + (unsigned)(t >> 4);
-        if (MODE == 2) fwd16x2<F>(x, y, p.tw, p.c + 4, blk2); else fwd16<F>(x, p.tw, p.c + 4, blk2);
+        load_tw16<F>(w, p.tw, p.c + 8, blk3);  // pass-3 twiddles in flight during pass 2
+        fwd16<F>(x, wn);
+        if (MODE == 2) fwd16<F>(y, wn);
 #pragma unroll
         for (int s = 0; s < 16; s++) {  // the very slots this lane just read
             la[pad(base2 + s * 16)] = x[s];
@@ -158,40 +152,44 @@ __global__ __launch_bounds__(256, 4) void rows_kernel(const typename View<F, VI>
             if (MODE == 2) y[j] = lb[17 * t + j];
         }
         // pass 3: stages 8..11 inside this lane's own 16 coefficients
-        const unsigned blk3 = (tile_blk << 8) + (unsigned)t;
-        if (MODE == 2) fwd16x2<F>(x, y, p.tw, p.c + 8, blk3); else fwd16<F>(x, p.tw, p.c + 8, blk3);
+        if (MODE == 2) load_tw16<F>(wn, p.itw, p.c + 8, blk3);  // first inverse pass
+        fwd16<F>(x, w);
         if (MODE == 0) {
 #pragma unroll
             for (int j = 0; j < 16; j++) Out::st(out + base + 16 * t + j, x[j]);
             return;
         }
+        fwd16<F>(y, w);
 #pragma unroll
         for (int j = 0; j < 16; j++) x[j] = F::mul_tw(x[j], y[j]);
     } else {
 #pragma unroll
         for (int j = 0; j < 16; j++) x[j] = In::ld(a + base + 16 * t + j);
+        load_tw16<F>(wn, p.itw, p.c + 8, blk3);
     }
 
     // inverse: stages c+11 .. c
-    inv16<F>(x, p, p.c + 8, (tile_blk << 8) + (unsigned)t);
+    load_tw16<F>(w, p.itw, p.c + 4, blk2);
+    inv16<F, false>(x, wn, p);
 #pragma unroll
     for (int j = 0; j < 16; j++) la[17 * t + j] = x[j];  // own slots (pass-3 reads of la by this lane are done)
     __syncthreads();
 #pragma unroll
     for (int s = 0; s < 16; s++) x[s] = la[pad(base2 + s * 16)];
-    inv16<F>(x, p, p.c + 4, (tile_blk << 4) + (unsigned)(t >> 4));
+    load_tw16<F>(wn, p.itw, p.c, tile_blk);
+    inv16<F, false>(x, w, p);
 #pragma unroll
     for (int j = 0; j < 16; j++) la[pad(base2 + j * 16)] = x[j];
     __syncthreads();
 #pragma unroll
     for (int r = 0; r < 16; r++) x[r] = la[pad(r * 256 + t)];
-    inv16<F>(x, p, p.c, tile_blk);
+    inv16<F, C0>(x, wn, p);
 #pragma unroll
     for (int j = 0; j < 16; j++) Out::st(out + base + j * 256 + t, x[j]);
 }
 
-// merged stages [s_lo, s_lo + M) on strided legs (stride S = D >> (s_lo + M) >= 4096), 2^M legs per lane
-template <class F, int M, int DIR, class VI, class VO>
+// S0: this pass starts at global stage 0 (s_lo == 0)
+template <class F, int M, int DIR, class VI, class VO, bool S0>
 __global__ __launch_bounds__(256) void strided_kernel(const typename View<F, VI>::T *src, typename View<F, VO>::T *dst,
                                                       int s_lo, Params<F> p) {
     using E = typename F::elem;
@@ -228,7 +226,7 @@ __global__ __launch_bounds__(256) void strided_kernel(const typename View<F, VI>
                 if (j & half) continue;
                 const E a = x[j], b = x[j + half];
                 const E sum = F::add(a, b), dif = F::sub(a, b);
-                if (s_lo + u == 0) {
+                if (S0 && u == 0) {
                     x[j] = F::mul_tw(sum, p.scale0);
                     x[j + half] = F::mul_tw(dif, p.scale1);
                 } else {
@@ -274,13 +272,16 @@ inline int launch_strided(const Hooks &hk, int M, const typename View<F, VI>::T 
     if (blocks == 0 || blocks > 0x7FFFFFFFull) return 1;
     Scope sc(hk, DIR == 0 ? 0 : 2, st);
     dim3 g((unsigned)blocks), b(256);
+#define SR_RT_STRIDED(MM)                                                                                          \
+    case MM:                                                                                                       \
+        if (s_lo == 0) hipLaunchKernelGGL((strided_kernel<F, MM, DIR, VI, VO, true>), g, b, 0, st, src, dst, s_lo, p); \
+        else hipLaunchKernelGGL((strided_kernel<F, MM, DIR, VI, VO, false>), g, b, 0, st, src, dst, s_lo, p);          \
+        break;
     switch (M) {
-        case 1: hipLaunchKernelGGL((strided_kernel<F, 1, DIR, VI, VO>), g, b, 0, st, src, dst, s_lo, p); break;
-        case 2: hipLaunchKernelGGL((strided_kernel<F, 2, DIR, VI, VO>), g, b, 0, st, src, dst, s_lo, p); break;
-        case 3: hipLaunchKernelGGL((strided_kernel<F, 3, DIR, VI, VO>), g, b, 0, st, src, dst, s_lo, p); break;
-        case 4: hipLaunchKernelGGL((strided_kernel<F, 4, DIR, VI, VO>), g, b, 0, st, src, dst, s_lo, p); break;
+        SR_RT_STRIDED(1) SR_RT_STRIDED(2) SR_RT_STRIDED(3) SR_RT_STRIDED(4)
         default: return 1;
     }
+#undef SR_RT_STRIDED
     return hipGetLastError() != hipSuccess;
 }
 // forward strided stages: boundary words at `src` -> packed words at `dst` (c >= 1)
@@ -317,7 +318,10 @@ inline int launch_rows(const Hooks &hk, const typename View<F, VI>::T *a, const 
     const size_t tiles = npoly << p.c;
     if (tiles == 0 || tiles > 0x7FFFFFFFull) return 1;
     Scope sc(hk, 1, st);
-    hipLaunchKernelGGL((rows_kernel<F, MODE, VI, VO>), dim3((unsigned)tiles), dim3(256), 0, st, a, b, out, p);
+    if (p.c == 0)
+        hipLaunchKernelGGL((rows_kernel<F, MODE, VI, VO, true>), dim3((unsigned)tiles), dim3(256), 0, st, a, b, out, p);
+    else
+        hipLaunchKernelGGL((rows_kernel<F, MODE, VI, VO, false>), dim3((unsigned)tiles), dim3(256), 0, st, a, b, out, p);
     return hipGetLastError() != hipSuccess;
 }
 // scratch0 / scratch1: library-owned device buffers of batch * D elems each (only touched when c > 0)
