@@ -59,13 +59,6 @@ def usable_cores():
     return int(env) if env else n
 
 
-class _DevMem:
-    """Zero-copy torch view of device memory owned by the C library (__cuda_array_interface__)."""
-
-    def __init__(self, ptr, nbytes):
-        self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr, False), "version": 2}
-
-
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -75,6 +68,7 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="override the per-GPU batch (debug only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo for rehearsals)")
     args = ap.parse_args()
 
     import numpy as np
@@ -87,28 +81,30 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, "WORLD_SIZE (%d) != --gpus (%d)" % (world, args.gpus)
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    ndev = torch.cuda.device_count()
+    assert ndev > 0, "bench.py needs a GPU"
+    dev_index = local_rank % ndev  # one rank per GPU on a full node; a 1-GPU rehearsal folds ranks onto device 0
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
 
     ring_name, k, batch, coeff_bytes = WORKLOADS[args.workload]
     if args.batch:
         batch = args.batch
     d = 1 << k
-    ring = CyclotomicRing(ring_name, k, device=local_rank)
+    ring = CyclotomicRing(ring_name, k, device=dev_index)
     words = batch * ring.words_per_elem
 
     # ---- shared twiddles: rank 0's tables broadcast once over RCCL/xGMI, adopted by every rank ----
     if world > 1:
-        ptr, nbytes = ring.twiddle_block()
-        tw = torch.as_tensor(_DevMem(ptr, nbytes), device=dev)
-        if rank != 0:
-            tw.zero_()  # prove the tables really come from rank 0
-        dist.broadcast(tw, src=0)
-        torch.cuda.synchronize()
-        ring.twiddles_updated()
+        from stark_rings_amd.sharding import share_twiddles
+
+        share_twiddles(ring, dev)  # non-zero ranks zero their block first: the tables really come from rank 0
 
     # ---- synthetic inputs generated on device (counter-based PRNG; rank-disjoint coefficient ranges) ----
     a = torch.empty(words, dtype=torch.int64, device=dev)
