@@ -314,3 +314,73 @@ def test_register_tiled_path_matches_oracle_and_generic(torch_cuda, name, k, bat
         del os.environ[env_generic]
     assert np.array_equal(generic.mul(a, b), want)
     generic.close()
+
+
+# ----------------------------------------------------------------------------- maximum sizes and BASELINE full sizes
+@pytest.mark.parametrize("name,k", [("goldilocks", 22), ("goldilocks", 24), ("babybear", 24), ("stark", 18)])
+def test_maximum_degrees_single_element(torch_cuda, name, k):
+    """Largest degrees each kernel family accepts (tuned Goldilocks <= 2^22, generic / register-tiled <= 2^24, Stark <= 2^20)."""
+    F = O.FIELD_ID[name]
+    ring = ring_for(name, k)
+    a = O.fill_uniform(F, 0x11 + k, 0, 1 << k)
+    b = O.fill_uniform(F, 0x22 + k, 0, 1 << k)
+    fa = ring.elementwise_crt(a.copy())
+    assert np.array_equal(fa, O.pow2_fwd(F, a, k, 1))
+    assert np.array_equal(ring.elementwise_icrt(fa), a)
+    assert np.array_equal(ring.mul(a, b), O.pow2_ring_mul(F, a, b, k, 1))
+    _rings.pop((name, k)).close()   # free the large tables
+
+
+@pytest.mark.parametrize("name,k,batch", [("goldilocks", 16, 1 << 14), ("babybear", 16, 1 << 14), ("stark", 12, 1 << 12)])
+def test_full_size_properties(torch_cuda, name, k, batch):
+    """BASELINE configs 2, 3, 5 at full size, through size-independent properties (the oracle would take minutes):
+    round trip, multiplication by 1, commutativity, the negacyclic wrap X^(D-1) * X = -1, canonical outputs,
+    plus sampled elements against the oracle."""
+    torch = torch_cuda
+    F = O.FIELD_ID[name]
+    L = O.LIMBS[F]
+    d = 1 << k
+    p = P.PRIMES[name][0]
+    ring = ring_for(name, k)
+    n = batch * d * L
+    a = torch.empty(n, dtype=torch.int64, device="cuda")
+    b = torch.empty(n, dtype=torch.int64, device="cuda")
+    ring.fill_uniform_dev(a, 0xAA, 0)
+    ring.fill_uniform_dev(b, 0xBB, 0)
+    a0, b0 = a.clone(), b.clone()
+    # icrt(crt(a)) == a   (crt.rs:85-147 at full size)
+    ring.elementwise_crt_dev(a)
+    assert not torch.equal(a, a0)
+    ring.elementwise_icrt_dev(a)
+    assert torch.equal(a, a0)
+    # a * b == b * a, and a few elements against the oracle
+    ab = torch.empty_like(a)
+    ring.mul_dev(ab, a, b)            # b may now hold crt-side scratch
+    b.copy_(b0)
+    ba = torch.empty_like(a)
+    ring.mul_dev(ba, b, a)
+    a.copy_(a0)
+    assert torch.equal(ab, ba)
+    assert ring.count_noncanonical_dev(ab) == 0
+    w = d * L
+    for e in (0, batch // 2 + 1, batch - 1):
+        ea = O.fill_uniform(F, 0xAA, e * d, d)
+        eb = O.fill_uniform(F, 0xBB, e * d, d)
+        assert np.array_equal(ab[e * w:(e + 1) * w].cpu().numpy().view(np.uint64), O.pow2_ring_mul(F, ea, eb, k))
+    # a * 1 == a ;  X^(D-1) * X == -1
+    one = torch.zeros(n, dtype=torch.int64, device="cuda")
+    one_elem = torch.from_numpy(O.to_mont(F, [1] + [0] * (d - 1)).view(np.int64)).cuda()
+    one.view(batch, w)[:] = one_elem
+    out = torch.empty_like(a)
+    b.copy_(one)
+    ring.mul_dev(out, a, b)
+    assert torch.equal(out, a0)
+    x1 = torch.from_numpy(O.to_mont(F, [0, 1] + [0] * (d - 2)).view(np.int64)).cuda()
+    xd = torch.from_numpy(O.to_mont(F, [0] * (d - 1) + [1]).view(np.int64)).cuda()
+    minus_one = O.to_mont(F, [p - 1] + [0] * (d - 1))
+    small = 4
+    ta = xd.repeat(small).contiguous()
+    tb = x1.repeat(small).contiguous()
+    to = torch.empty_like(ta)
+    ring.mul_dev(to, ta, tb)
+    assert np.array_equal(to[:w].cpu().numpy().view(np.uint64), minus_one)
