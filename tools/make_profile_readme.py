@@ -7,7 +7,7 @@ import os
 import sys
 
 d = sys.argv[1]
-stats = [f for f in os.listdir(d) if f.startswith("kernel_stats")][0]
+stats = "kernel_stats_goldilocks_d65536_b16384.csv"
 out = []
 out.append("# %s -- MI355X (gfx950), workload goldilocks_d65536_b16384 (BASELINE configs[1])\n" % d)
 out.append("Commands (on the GPU box, from the repo root; counters in their own passes):\n")
