@@ -16,6 +16,7 @@
 //     Mul  (poly_mul + reduce)           coeff_form.rs:54-67,250-258   operator*, operator*=
 //   CyclotomicPolyRingNTTGeneral<C,N,D>  ntt_form.rs:25-27           class RqNTTVec    (a Vec<RqNTT>, flat)
 //     Mul / MulAssign (slot-wise)        ntt_form.rs:159-225           operator*, operator*=
+//     Add / Sub                          ntt_form.rs:227-285,588-638   operator+=, operator-=  (both forms)
 //   CRT::elementwise_crt                 crt.rs:10-25                RqPolyVec::elementwise_crt() &&  (in place, same allocation)
 //   ICRT::elementwise_icrt               crt.rs:34-49                RqNTTVec::elementwise_icrt() &&
 //   Flatten::flatten_to_coeffs           flatten.rs:11-17            flatten_to_coeffs(Vec&&) -> std::vector<uint64_t>
@@ -115,6 +116,16 @@ public:
         lhs *= rhs;
         return lhs;
     }
+    RqPolyVec &operator+=(const RqPolyVec &rhs) {                // coeff_form.rs Add<&Self>
+        if (rhs.w_.size() != w_.size()) throw std::length_error("operand lengths differ");
+        CyclotomicConfig::check(sr_add_batch(cfg_.raw(), w_.data(), rhs.w_.data(), len()), "RqPoly +=");
+        return *this;
+    }
+    RqPolyVec &operator-=(const RqPolyVec &rhs) {
+        if (rhs.w_.size() != w_.size()) throw std::length_error("operand lengths differ");
+        CyclotomicConfig::check(sr_sub_batch(cfg_.raw(), w_.data(), rhs.w_.data(), len()), "RqPoly -=");
+        return *this;
+    }
     std::vector<uint64_t> into_words() && { return std::move(w_); }
 
 private:
@@ -145,6 +156,16 @@ public:
     friend RqNTTVec operator*(RqNTTVec lhs, const RqNTTVec &rhs) {
         lhs *= rhs;
         return lhs;
+    }
+    RqNTTVec &operator+=(const RqNTTVec &rhs) {                  // ntt_form.rs:227-285
+        if (rhs.w_.size() != w_.size()) throw std::length_error("operand lengths differ");
+        CyclotomicConfig::check(sr_add_batch(cfg_.raw(), w_.data(), rhs.w_.data(), len()), "RqNTT +=");
+        return *this;
+    }
+    RqNTTVec &operator-=(const RqNTTVec &rhs) {                  // ntt_form.rs:588-638
+        if (rhs.w_.size() != w_.size()) throw std::length_error("operand lengths differ");
+        CyclotomicConfig::check(sr_sub_batch(cfg_.raw(), w_.data(), rhs.w_.data(), len()), "RqNTT -=");
+        return *this;
     }
     std::vector<uint64_t> into_words() && { return std::move(w_); }
 

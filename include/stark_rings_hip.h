@@ -81,6 +81,9 @@ int sr_ntt_fwd_batch(sr_ctx *ctx, uint64_t *data, size_t batch);
 int sr_ntt_inv_batch(sr_ctx *ctx, uint64_t *data, size_t batch);
 /* RqNTT MulAssign<&Self> per element (ntt_form.rs:213-225; values of mul_unchecked :177-189) */
 int sr_pointwise_mul_batch(sr_ctx *ctx, uint64_t *lhs_inout, const uint64_t *rhs, size_t batch);
+/* RqNTT += / -= &RqNTT (ntt_form.rs:227-285, 588-638) and the same for RqPoly: coefficient-wise in either form. */
+int sr_add_batch(sr_ctx *ctx, uint64_t *lhs_inout, const uint64_t *rhs, size_t batch);
+int sr_sub_batch(sr_ctx *ctx, uint64_t *lhs_inout, const uint64_t *rhs, size_t batch);
 /* RqPoly * RqPoly == icrt(crt(a) * crt(b)) (coeff_form.rs:250-258; identity tested at
  * stark_prime/mod.rs:161-177).  out may alias a.                                          */
 int sr_ring_mul_batch(sr_ctx *ctx, uint64_t *out, const uint64_t *a, const uint64_t *b, size_t batch);
@@ -93,6 +96,13 @@ int sr_reduce_batch(sr_ctx *ctx, const uint64_t *in, size_t in_len_per_elem, uin
 int sr_ntt_fwd_batch_dev(sr_ctx *ctx, uint64_t *d_data, size_t batch, void *stream);
 int sr_ntt_inv_batch_dev(sr_ctx *ctx, uint64_t *d_data, size_t batch, void *stream);
 int sr_pointwise_mul_batch_dev(sr_ctx *ctx, uint64_t *d_lhs_inout, const uint64_t *d_rhs, size_t batch, void *stream);
+int sr_add_batch_dev(sr_ctx *ctx, uint64_t *d_lhs_inout, const uint64_t *d_rhs, size_t batch, void *stream);
+int sr_sub_batch_dev(sr_ctx *ctx, uint64_t *d_lhs_inout, const uint64_t *d_rhs, size_t batch, void *stream);
+/* First "next" row: y = M * v for a dense nrows x ncols matrix of ring elements in CRT/NTT form
+ * (row-major, each entry one ring element) and a vector of ncols elements -- Matrix<RqNTT>::checked_mul_vec,
+ * crates/linear_algebra/src/matrix.rs:168-178 -- as one fused multiply-accumulate pass over M.  Power-of-two
+ * (fully split) rings only; d_y must not alias d_m or d_v. */
+int sr_matvec_ntt_dev(sr_ctx *ctx, uint64_t *d_y, const uint64_t *d_m, const uint64_t *d_v, size_t nrows, size_t ncols, void *stream);
 /* d_b is used as scratch and holds crt(b) afterwards when D exceeds one LDS tile; d_out may alias d_a. */
 int sr_ring_mul_batch_dev(sr_ctx *ctx, uint64_t *d_out, const uint64_t *d_a, uint64_t *d_b, size_t batch, void *stream);
 int sr_reduce_batch_dev(sr_ctx *ctx, const uint64_t *d_in, size_t in_len_per_elem, uint64_t *d_out, size_t batch, void *stream);

@@ -23,11 +23,16 @@ SYMBOLS = {
     "sr_ntt_fwd_batch": (_c.c_int, [_c.c_void_p, u64p, _c.c_size_t]),
     "sr_ntt_inv_batch": (_c.c_int, [_c.c_void_p, u64p, _c.c_size_t]),
     "sr_pointwise_mul_batch": (_c.c_int, [_c.c_void_p, u64p, u64p, _c.c_size_t]),
+    "sr_add_batch": (_c.c_int, [_c.c_void_p, u64p, u64p, _c.c_size_t]),
+    "sr_sub_batch": (_c.c_int, [_c.c_void_p, u64p, u64p, _c.c_size_t]),
     "sr_ring_mul_batch": (_c.c_int, [_c.c_void_p, u64p, u64p, u64p, _c.c_size_t]),
     "sr_reduce_batch": (_c.c_int, [_c.c_void_p, u64p, _c.c_size_t, u64p, _c.c_size_t]),
     "sr_ntt_fwd_batch_dev": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_size_t, _c.c_void_p]),
     "sr_ntt_inv_batch_dev": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_size_t, _c.c_void_p]),
     "sr_pointwise_mul_batch_dev": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_size_t, _c.c_void_p]),
+    "sr_add_batch_dev": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_size_t, _c.c_void_p]),
+    "sr_sub_batch_dev": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_size_t, _c.c_void_p]),
+    "sr_matvec_ntt_dev": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_size_t, _c.c_size_t, _c.c_void_p]),
     "sr_ring_mul_batch_dev": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_size_t, _c.c_void_p]),
     "sr_reduce_batch_dev": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_size_t, _c.c_void_p, _c.c_size_t, _c.c_void_p]),
     "sr_fill_uniform_dev": (_c.c_int, [_c.c_void_p, _c.c_uint64, _c.c_uint64, _c.c_size_t, _c.c_void_p, _c.c_void_p]),

@@ -325,6 +325,34 @@ int pointwise_dev(sr_ctx *c, uint64_t *lhs, const uint64_t *rhs, size_t n_coeffs
     return SR_OK;
 }
 template <class F>
+int addsub_dev(sr_ctx *c, uint64_t *lhs, const uint64_t *rhs, size_t n_coeffs, bool sub, hipStream_t st) {
+    if (n_coeffs == 0) return SR_OK;
+    size_t blocks = (n_coeffs + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    ProfScope ps(c, st, K_POINTWISE);
+    auto *l = reinterpret_cast<typename F::storage *>(lhs);
+    auto *r = reinterpret_cast<const typename F::storage *>(rhs);
+    if (sub)
+        hipLaunchKernelGGL((sr::addsub_kernel<F, true>), dim3((unsigned)blocks), dim3(256), 0, st, l, r, n_coeffs);
+    else
+        hipLaunchKernelGGL((sr::addsub_kernel<F, false>), dim3((unsigned)blocks), dim3(256), 0, st, l, r, n_coeffs);
+    HIP_TRY(hipGetLastError());
+    return SR_OK;
+}
+template <class F>
+int matvec_dev(sr_ctx *c, uint64_t *y, const uint64_t *m, const uint64_t *v, size_t nrows, size_t ncols, hipStream_t st) {
+    using S = typename F::storage;
+    if (nrows == 0) return SR_OK;
+    constexpr int RB = 4;
+    const size_t bx = (c->degree + 255) / 256, by = (nrows + RB - 1) / RB;
+    if (by > 65535) return fail(SR_E_INVALID, "matvec: too many rows for one launch");
+    ProfScope ps(c, st, K_OTHER);
+    hipLaunchKernelGGL((sr::matvec_kernel<F, RB>), dim3((unsigned)bx, (unsigned)by), dim3(256), 0, st, reinterpret_cast<S *>(y),
+                       reinterpret_cast<const S *>(m), reinterpret_cast<const S *>(v), nrows, ncols, c->k);
+    HIP_TRY(hipGetLastError());
+    return SR_OK;
+}
+template <class F>
 int ring_mul_dev(sr_ctx *c, uint64_t *out, const uint64_t *a, uint64_t *b, size_t batch, hipStream_t st) {
     using S = typename F::storage;
     if (batch == 0) return SR_OK;
@@ -501,6 +529,19 @@ int dev_pointwise(sr_ctx *c, uint64_t *l, const uint64_t *r, size_t batch, hipSt
     if (c->ring == SR_RING_BABYBEAR_72) return sr::small_launch(c->small, sr::SMALL_B72_MUL, l, r, 0, l, batch, st) ? fail(SR_E_HIP, "small-ring launch failed") : SR_OK;
     DISPATCH_POW2(c, (pointwise_dev<F>(c, l, r, batch << c->k, st)));
 }
+int dev_addsub(sr_ctx *c, uint64_t *l, const uint64_t *r, size_t batch, bool sub, hipStream_t st) {
+    const size_t n = batch * c->degree;
+    switch (c->ring) {
+        case SR_RING_GOLDILOCKS_POW2:
+        case SR_RING_GOLDILOCKS_24: return addsub_dev<sr::Goldilocks>(c, l, r, n, sub, st);
+        case SR_RING_BABYBEAR_POW2:
+        case SR_RING_BABYBEAR_72: return addsub_dev<sr::BabyBear>(c, l, r, n, sub, st);
+        default: return addsub_dev<sr::Stark>(c, l, r, n, sub, st);
+    }
+}
+int dev_matvec(sr_ctx *c, uint64_t *y, const uint64_t *m, const uint64_t *v, size_t nrows, size_t ncols, hipStream_t st) {
+    DISPATCH_POW2(c, (matvec_dev<F>(c, y, m, v, nrows, ncols, st)));
+}
 int dev_ring_mul(sr_ctx *c, uint64_t *out, const uint64_t *a, uint64_t *b, size_t batch, hipStream_t st) {
     if (c->ring == SR_RING_GOLDILOCKS_24) return sr::small_launch(c->small, sr::SMALL_G24_RINGMUL, a, b, 0, out, batch, st) ? fail(SR_E_HIP, "small-ring launch failed") : SR_OK;
     if (c->ring == SR_RING_BABYBEAR_72) return sr::small_launch(c->small, sr::SMALL_B72_RINGMUL, a, b, 0, out, batch, st) ? fail(SR_E_HIP, "small-ring launch failed") : SR_OK;
@@ -652,6 +693,25 @@ int sr_pointwise_mul_batch_dev(sr_ctx *c, uint64_t *l, const uint64_t *r, size_t
     DeviceGuard g(c->device);
     return dev_pointwise(c, l, r, batch, (hipStream_t)stream);
 }
+int sr_add_batch_dev(sr_ctx *c, uint64_t *l, const uint64_t *r, size_t batch, void *stream) {
+    if (int rc = check(c, l, r)) return rc;
+    std::lock_guard<std::mutex> lk(c->mu);
+    DeviceGuard g(c->device);
+    return dev_addsub(c, l, r, batch, false, (hipStream_t)stream);
+}
+int sr_sub_batch_dev(sr_ctx *c, uint64_t *l, const uint64_t *r, size_t batch, void *stream) {
+    if (int rc = check(c, l, r)) return rc;
+    std::lock_guard<std::mutex> lk(c->mu);
+    DeviceGuard g(c->device);
+    return dev_addsub(c, l, r, batch, true, (hipStream_t)stream);
+}
+int sr_matvec_ntt_dev(sr_ctx *c, uint64_t *y, const uint64_t *m, const uint64_t *v, size_t nrows, size_t ncols, void *stream) {
+    if (int rc = check(c, y, m, v)) return rc;
+    if (y == m || y == v) return fail(SR_E_INVALID, "matvec: y must not alias M or v");
+    std::lock_guard<std::mutex> lk(c->mu);
+    DeviceGuard g(c->device);
+    return dev_matvec(c, y, m, v, nrows, ncols, (hipStream_t)stream);
+}
 int sr_ring_mul_batch_dev(sr_ctx *c, uint64_t *out, const uint64_t *a, uint64_t *b, size_t batch, void *stream) {
     if (int rc = check(c, out, a, b)) return rc;
     if ((const uint64_t *)b == a || b == out) return fail(SR_E_INVALID, "ring_mul: b must not alias a or out");
@@ -710,7 +770,8 @@ static int host_inplace(sr_ctx *c, uint64_t *data, size_t batch, bool fwd) {
 int sr_ntt_fwd_batch(sr_ctx *c, uint64_t *data, size_t batch) { return host_inplace(c, data, batch, true); }
 int sr_ntt_inv_batch(sr_ctx *c, uint64_t *data, size_t batch) { return host_inplace(c, data, batch, false); }
 
-static int host_binary(sr_ctx *c, uint64_t *out, const uint64_t *a, const uint64_t *b, size_t batch, bool ring_mul) {
+enum { HB_POINTWISE = 0, HB_RING_MUL = 1, HB_ADD = 2, HB_SUB = 3 };
+static int host_binary(sr_ctx *c, uint64_t *out, const uint64_t *a, const uint64_t *b, size_t batch, int op) {
     if (int rc = check(c, out, a, b)) return rc;
     std::lock_guard<std::mutex> lk(c->mu);
     DeviceGuard g(c->device);
@@ -720,18 +781,22 @@ static int host_binary(sr_ctx *c, uint64_t *out, const uint64_t *a, const uint64
     if (int rc = ensure_stage(c, 1, bytes)) return rc;
     HIP_TRY(hipMemcpyAsync(c->stage[0], a, bytes, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemcpyAsync(c->stage[1], b, bytes, hipMemcpyHostToDevice, c->stream));
-    int rc = ring_mul ? dev_ring_mul(c, (uint64_t *)c->stage[0], (uint64_t *)c->stage[0], (uint64_t *)c->stage[1], batch, c->stream)
-                      : dev_pointwise(c, (uint64_t *)c->stage[0], (uint64_t *)c->stage[1], batch, c->stream);
+    uint64_t *s0 = (uint64_t *)c->stage[0], *s1 = (uint64_t *)c->stage[1];
+    int rc = op == HB_RING_MUL ? dev_ring_mul(c, s0, s0, s1, batch, c->stream)
+             : op == HB_POINTWISE ? dev_pointwise(c, s0, s1, batch, c->stream)
+                                  : dev_addsub(c, s0, s1, batch, op == HB_SUB, c->stream);
     if (rc) return rc;
     HIP_TRY(hipMemcpyAsync(out, c->stage[0], bytes, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return SR_OK;
 }
 int sr_pointwise_mul_batch(sr_ctx *c, uint64_t *lhs, const uint64_t *rhs, size_t batch) {
-    return host_binary(c, lhs, lhs, rhs, batch, false);
+    return host_binary(c, lhs, lhs, rhs, batch, HB_POINTWISE);
 }
+int sr_add_batch(sr_ctx *c, uint64_t *lhs, const uint64_t *rhs, size_t batch) { return host_binary(c, lhs, lhs, rhs, batch, HB_ADD); }
+int sr_sub_batch(sr_ctx *c, uint64_t *lhs, const uint64_t *rhs, size_t batch) { return host_binary(c, lhs, lhs, rhs, batch, HB_SUB); }
 int sr_ring_mul_batch(sr_ctx *c, uint64_t *out, const uint64_t *a, const uint64_t *b, size_t batch) {
-    return host_binary(c, out, a, b, batch, true);
+    return host_binary(c, out, a, b, batch, HB_RING_MUL);
 }
 int sr_reduce_batch(sr_ctx *c, const uint64_t *in, size_t in_len, uint64_t *out, size_t batch) {
     if (int rc = check(c, in, out)) return rc;

@@ -195,6 +195,40 @@ __global__ void pointwise_kernel(typename F::storage *lhs, const typename F::sto
         F::store(lhs + i, F::mul_boundary(F::load(lhs + i), F::load(rhs + i)));
 }
 
+// lhs[i] = lhs[i] +- rhs[i] coefficient-wise: RqNTT / RqPoly Add and Sub (ntt_form.rs:227-285, 588-638; coeff_form.rs
+// operator impls) -- the same in either form and for every ring, the slots being Fp-vector spaces
+template <class F, bool SUB>
+__global__ void addsub_kernel(typename F::storage *lhs, const typename F::storage *rhs, size_t n) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        typename F::elem a = F::load(lhs + i), b = F::load(rhs + i);
+        F::store(lhs + i, SUB ? F::sub(a, b) : F::add(a, b));
+    }
+}
+
+// y[r] = sum_c M[r][c] * v[c] over ring elements in CRT/NTT form of a fully split ring (slot-wise Fp products and sums):
+// Matrix<RqNTT>::checked_mul_vec (crates/linear_algebra/src/matrix.rs:168-178), one fused pass over M.
+// Lane = one slot; a workgroup row-block of RB rows shares each v[c] slot it loads.  M is streamed once (HBM-bound).
+template <class F, int RB>
+__global__ __launch_bounds__(256) void matvec_kernel(typename F::storage *y, const typename F::storage *m,
+                                                     const typename F::storage *v, size_t nrows, size_t ncols, int k) {
+    const size_t d = (size_t)1 << k;
+    const size_t slot = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    const size_t r0 = (size_t)blockIdx.y * RB;
+    if (slot >= d) return;
+    typename F::elem acc[RB];
+#pragma unroll
+    for (int r = 0; r < RB; r++) acc[r] = F::zero();
+    for (size_t c = 0; c < ncols; c++) {
+        const typename F::elem x = F::load(v + (c << k) + slot);
+#pragma unroll
+        for (int r = 0; r < RB; r++)
+            if (r0 + r < nrows) acc[r] = F::add(acc[r], F::mul_boundary(F::load(m + (((r0 + r) * ncols + c) << k) + slot), x));
+    }
+#pragma unroll
+    for (int r = 0; r < RB; r++)
+        if (r0 + r < nrows) F::store(y + ((r0 + r) << k) + slot, acc[r]);
+}
+
 // out[e][i] = in[e][i] - in[e][D + i]   (stark_prime/mod.rs:40-47); in_len <= 2D per element
 template <class F>
 __global__ void reduce_pow2_kernel(const typename F::storage *in, size_t in_len, typename F::storage *out, int k,

@@ -119,6 +119,20 @@ class CyclotomicRing:
         self._check(self._lib.sr_pointwise_mul_batch(self._ctx, _np_ptr(lhs), _np_ptr(rhs), self._batch_of(lhs.size)))
         return lhs
 
+    def add(self, lhs, rhs):
+        """lhs += rhs element-wise (ntt_form.rs:227-285 / coeff_form.rs Add), in place on lhs."""
+        if lhs.size != rhs.size:
+            raise RingError("operand lengths differ")
+        self._check(self._lib.sr_add_batch(self._ctx, _np_ptr(lhs), _np_ptr(rhs), self._batch_of(lhs.size)))
+        return lhs
+
+    def sub(self, lhs, rhs):
+        """lhs -= rhs element-wise (ntt_form.rs:588-638), in place on lhs."""
+        if lhs.size != rhs.size:
+            raise RingError("operand lengths differ")
+        self._check(self._lib.sr_sub_batch(self._ctx, _np_ptr(lhs), _np_ptr(rhs), self._batch_of(lhs.size)))
+        return lhs
+
     def mul(self, a, b, out=None):
         """Coefficient-form product a * b (coeff_form.rs:250-258) via icrt(crt(a) * crt(b))."""
         if a.size != b.size:
@@ -170,6 +184,34 @@ class CyclotomicRing:
             raise RingError("operand lengths differ")
         self._check(self._lib.sr_pointwise_mul_batch_dev(self._ctx, pl, pr, self._batch_of(n), self._stream(stream)))
         return lhs
+
+    def add_dev(self, lhs, rhs, stream=None):
+        pl, n = self._dev(lhs)
+        pr, m = self._dev(rhs)
+        if n != m:
+            raise RingError("operand lengths differ")
+        self._check(self._lib.sr_add_batch_dev(self._ctx, pl, pr, self._batch_of(n), self._stream(stream)))
+        return lhs
+
+    def sub_dev(self, lhs, rhs, stream=None):
+        pl, n = self._dev(lhs)
+        pr, m = self._dev(rhs)
+        if n != m:
+            raise RingError("operand lengths differ")
+        self._check(self._lib.sr_sub_batch_dev(self._ctx, pl, pr, self._batch_of(n), self._stream(stream)))
+        return lhs
+
+    def matvec_ntt_dev(self, y, m, v, nrows, ncols, stream=None):
+        """y = M v for M (nrows x ncols ring elements, row-major) and v (ncols elements), all in CRT/NTT form:
+        Matrix<RqNTT>::checked_mul_vec (linear_algebra/src/matrix.rs:168-178); the reference returns None on a length
+        mismatch, here RingError is raised."""
+        py, ny = self._dev(y)
+        pm, nm = self._dev(m)
+        pv, nv = self._dev(v)
+        if nm != nrows * ncols * self.words_per_elem or nv != ncols * self.words_per_elem or ny != nrows * self.words_per_elem:
+            raise RingError("matvec: DifferentLengths")
+        self._check(self._lib.sr_matvec_ntt_dev(self._ctx, py, pm, pv, nrows, ncols, self._stream(stream)))
+        return y
 
     def mul_dev(self, out, a, b, stream=None):
         """out = a * b; b is clobbered (holds crt(b)) when D exceeds one LDS tile; out may be a."""

@@ -62,6 +62,18 @@ static void pow2_suite(sr_ring ring, int field, int log2d, size_t batch) {
         EXPECT(std::equal(sb.begin(), sb.end(), direct.words().begin()));
     }
 
+    // crt is linear: crt(a + b) == crt(a) + crt(b); (a + b) - b == a   (Add / Sub of both forms)
+    {
+        RqPolyVec sum(cfg, a);
+        sum += RqPolyVec(cfg, b);
+        RqNTTVec lhs = std::move(sum).elementwise_crt();
+        RqNTTVec rhs = RqPolyVec(cfg, a).elementwise_crt();
+        rhs += RqPolyVec(cfg, b).elementwise_crt();
+        EXPECT(lhs == rhs);
+        rhs -= RqPolyVec(cfg, b).elementwise_crt();
+        EXPECT(std::move(rhs).elementwise_icrt() == orig);
+    }
+
     // flatten / promote (flatten.rs:128-138)
     auto flat = flatten_to_coeffs(RqPolyVec(cfg, a));
     EXPECT(flat == a);

@@ -384,3 +384,51 @@ def test_full_size_properties(torch_cuda, name, k, batch):
     to = torch.empty_like(ta)
     ring.mul_dev(to, ta, tb)
     assert np.array_equal(to[:w].cpu().numpy().view(np.uint64), minus_one)
+
+
+# ----------------------------------------------------------------------------- add / sub, and the first "next" row: Matrix<RqNTT> * vec
+@pytest.mark.parametrize("name,k", [("goldilocks", 6), ("babybear", 6), ("stark", 4), ("goldilocks24", 0), ("babybear72", 0)])
+def test_add_sub_match_integer_arithmetic(torch_cuda, name, k):
+    base = {"goldilocks24": "goldilocks", "babybear72": "babybear"}.get(name, name)
+    F = O.FIELD_ID[base]
+    p = P.PRIMES[base][0]
+    ring = ring_for(name, k)
+    batch = 9
+    n = batch * ring.degree
+    a = O.fill_uniform(F, 41, 0, n)
+    b = O.fill_uniform(F, 42, 0, n)
+    a[:ring.words_per_elem] = O.to_mont(F, [p - 1] * ring.degree)      # force wrap-around on add, borrow on sub
+    sa, sb = O.from_mont(F, a), O.from_mont(F, b)
+    assert O.from_mont(F, ring.add(a.copy(), b)) == [(x + y) % p for x, y in zip(sa, sb)]
+    assert O.from_mont(F, ring.sub(a.copy(), b)) == [(x - y) % p for x, y in zip(sa, sb)]
+    assert np.array_equal(ring.sub(ring.add(a.copy(), b), b), a)
+
+
+@pytest.mark.parametrize("name,k,nrows,ncols", [("goldilocks", 5, 7, 9), ("babybear", 6, 5, 3), ("stark", 4, 6, 5), ("goldilocks", 12, 3, 4)])
+def test_matvec_ntt_matches_row_by_row_products(torch_cuda, name, k, nrows, ncols):
+    """Matrix<RqNTT>::checked_mul_vec (linear_algebra/src/matrix.rs:168-178; test_matrix_mul_vec :233-244):
+    y[r] = sum_c M[r][c] * v[c], against the oracle's slot products and integer sums."""
+    torch = torch_cuda
+    from stark_rings_amd import RingError
+
+    F = O.FIELD_ID[name]
+    L = O.LIMBS[F]
+    p = P.PRIMES[name][0]
+    ring = ring_for(name, k)
+    w = ring.words_per_elem
+    m = O.fill_uniform(F, 51, 0, nrows * ncols << k)
+    v = O.fill_uniform(F, 52, 0, ncols << k)
+    want = []
+    for r in range(nrows):
+        acc = [0] * (1 << k)
+        for c in range(ncols):
+            prod = O.from_mont(F, O.pow2_pointwise(F, m[(r * ncols + c) * w:(r * ncols + c + 1) * w], v[c * w:(c + 1) * w]))
+            acc = [(x + y) % p for x, y in zip(acc, prod)]
+        want += acc
+    tm = torch.from_numpy(m.view(np.int64)).cuda()
+    tv = torch.from_numpy(v.view(np.int64)).cuda()
+    ty = torch.empty(nrows * w, dtype=torch.int64, device="cuda")
+    ring.matvec_ntt_dev(ty, tm, tv, nrows, ncols)
+    assert O.from_mont(F, ty.cpu().numpy().view(np.uint64)) == want
+    with pytest.raises(RingError, match="DifferentLengths"):
+        ring.matvec_ntt_dev(ty, tm, tv, nrows, ncols + 1)
