@@ -200,6 +200,112 @@ __global__ __launch_bounds__(256) void strided_kernel(u64 *data, int k, int s_lo
 }
 
 // ------------------------------------------------------------------------------------------------
+// strided pass of EIGHT merged stages [s_lo, s_lo + 8) in one trip over HBM (used when D >= 2^20, where two
+// 4-stage passes would stream every operand twice): a workgroup owns 256 legs (stride S) x 16 consecutive
+// columns = 4096 coefficients.  Pass A: lane (col, rg) holds legs rg + 16 jj and runs stages 0..3 (leg distance
+// 128..16, twiddles wave-uniform); one exchange through the padded LDS tile (write pattern jj*256 + t, read
+// pattern rg'*256 + jj*16 + col: the same two conflict-free patterns as the rows kernel); pass B: legs 16 rg' + jj,
+// stages 4..7 (distance 8..1, 15 per-lane twiddles).  128-byte global segments (16 columns x 8 B).
+// grid.x = npoly * 2^s_lo * (S / 16).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int pad(int pos);  // defined with the rows kernel below
+
+template <int DIR, bool TWIST>
+__global__ __launch_bounds__(256, 4) void strided256_kernel(u64 *data, int k, int s_lo, const u64 *tw, const u64 *twist) {
+    __shared__ u64 lds[kLdsElems];
+    const int t = threadIdx.x;
+    const int ls = k - s_lo - 8;  // log2 S
+    const unsigned chunks = 1u << (ls - 4);
+    const unsigned ci = blockIdx.x & (chunks - 1u);
+    const unsigned rest = blockIdx.x >> (ls - 4);
+    const unsigned h = rest & ((1u << s_lo) - 1u);
+    const size_t poly = rest >> s_lo;
+    const int col = t & 15, rg = t >> 4;
+    const unsigned i = ci * 16u + (unsigned)col;  // position inside the leg
+    u64 *base = data + (poly << k) + ((size_t)h << (k - s_lo)) + i;
+    const int base2 = rg * 256 + col;
+    u64 x[16];
+
+    if (DIR == 0) {
+#pragma unroll
+        for (int jj = 0; jj < 16; jj++) x[jj] = base[(size_t)(rg + 16 * jj) << ls];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int half = 8 >> u;
+#pragma unroll
+            for (int jj = 0; jj < 16; jj++) {
+                if (jj & half) continue;
+                const u64 w = tw[(1u << (s_lo + u)) + (h << u) + (unsigned)(jj >> (4 - u))];
+                const u64 a = x[jj], v = G::mul(x[jj + half], w);
+                x[jj] = G::add(a, v);
+                x[jj + half] = G::sub(a, v);
+            }
+        }
+#pragma unroll
+        for (int jj = 0; jj < 16; jj++) lds[pad(jj * 256 + t)] = x[jj];
+        __syncthreads();
+#pragma unroll
+        for (int jj = 0; jj < 16; jj++) x[jj] = lds[pad(base2 + jj * 16)];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int half = 8 >> u;
+#pragma unroll
+            for (int jj = 0; jj < 16; jj++) {
+                if (jj & half) continue;
+                const u64 w = tw[(1u << (s_lo + 4 + u)) + (h << (4 + u)) + ((unsigned)rg << u) + (unsigned)(jj >> (4 - u))];
+                const u64 a = x[jj], v = G::mul(x[jj + half], w);
+                x[jj] = G::add(a, v);
+                x[jj + half] = G::sub(a, v);
+            }
+        }
+#pragma unroll
+        for (int jj = 0; jj < 16; jj++) {
+            u64 v = x[jj];
+            if (TWIST) v = G::mul(v, twist[((size_t)((h << 8) + (unsigned)(16 * rg + jj)) << 12) + i]);
+            base[(size_t)(16 * rg + jj) << ls] = v;
+        }
+    } else {
+#pragma unroll
+        for (int jj = 0; jj < 16; jj++) {
+            u64 v = base[(size_t)(16 * rg + jj) << ls];
+            if (TWIST) v = G::mul(v, twist[((size_t)((h << 8) + (unsigned)(16 * rg + jj)) << 12) + i]);
+            x[jj] = v;
+        }
+#pragma unroll
+        for (int u = 3; u >= 0; u--) {
+            const int half = 8 >> u;
+#pragma unroll
+            for (int jj = 0; jj < 16; jj++) {
+                if (jj & half) continue;
+                const u64 w = tw[(1u << (s_lo + 4 + u)) + (h << (4 + u)) + ((unsigned)rg << u) + (unsigned)(jj >> (4 - u))];
+                const u64 a = x[jj], b = x[jj + half];
+                x[jj] = G::add(a, b);
+                x[jj + half] = G::mul(G::sub(a, b), w);
+            }
+        }
+#pragma unroll
+        for (int jj = 0; jj < 16; jj++) lds[pad(base2 + jj * 16)] = x[jj];
+        __syncthreads();
+#pragma unroll
+        for (int jj = 0; jj < 16; jj++) x[jj] = lds[pad(jj * 256 + t)];
+#pragma unroll
+        for (int u = 3; u >= 0; u--) {
+            const int half = 8 >> u;
+#pragma unroll
+            for (int jj = 0; jj < 16; jj++) {
+                if (jj & half) continue;
+                const u64 w = tw[(1u << (s_lo + u)) + (h << u) + (unsigned)(jj >> (4 - u))];
+                const u64 a = x[jj], b = x[jj + half];
+                x[jj] = G::add(a, b);
+                x[jj + half] = G::mul(G::sub(a, b), w);
+            }
+        }
+#pragma unroll
+        for (int jj = 0; jj < 16; jj++) base[(size_t)(rg + 16 * jj) << ls] = x[jj];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // rows kernel: one workgroup = one 4096-coefficient tile, 256 lanes x 16 coefficients
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ int pad(int pos) { return pos + (pos >> 4); }
@@ -426,14 +532,28 @@ inline int gl_launch_strided(const GoldilocksFastTables &f, int M, uint64_t *dat
     }
     return hipGetLastError() != hipSuccess;
 }
-// split the c = k - 12 strided stages into register passes of at most 4 stages each
+template <int DIR, bool TWIST>
+inline int gl_launch_strided256(const GoldilocksFastTables &f, uint64_t *data, int k, int s_lo, size_t npoly,
+                                const uint64_t *tw, const uint64_t *twist, hipStream_t st) {
+    GlProfScope ps(f, DIR == 0 ? 0 : 2, st);
+    const size_t S = (size_t)1 << (k - s_lo - 8);
+    const size_t blocks = npoly * ((size_t)1 << s_lo) * (S >> 4);
+    if (blocks == 0 || blocks > 0x7FFFFFFFull) return 1;
+    hipLaunchKernelGGL((gl::strided256_kernel<DIR, TWIST>), dim3((unsigned)blocks), dim3(256), 0, st, data, k, s_lo, tw, twist);
+    return hipGetLastError() != hipSuccess;
+}
+// split the c = k - 12 strided stages into passes: 8 = one 256-leg pass through LDS (D >= 2^20), otherwise
+// register passes of at most 4 stages.  The 256-leg pass, when present, is the one next to the rows kernel.
 inline int gl_plan(int c, int *ms) {
     int n = 0;
+    const bool big = c >= 8;
+    if (big) c -= 8;
     while (c > 0) {
-        int m = c > 4 ? (c >= 8 ? 4 : (c + 1) / 2) : c;
+        int m = c > 4 ? (c + 1) / 2 : c;
         ms[n++] = m;
         c -= m;
     }
+    if (big) ms[n++] = 8;
     if (n == 0) ms[n++] = 0;  // D = 4096: twist-only pass
     return n;
 }
@@ -443,7 +563,12 @@ inline int gl_strided_fwd(const GoldilocksFastTables &f, uint64_t *d, size_t npo
     int s_lo = 0;
     for (int p = 0; p < n; p++) {
         const bool last = p == n - 1;
-        int rc = last ? gl_launch_strided<0, true>(f, ms[p], d, f.k, s_lo, npoly, f.t.tw, f.t.twist_f, st)
+        int rc;
+        if (ms[p] == 8)
+            rc = last ? gl_launch_strided256<0, true>(f, d, f.k, s_lo, npoly, f.t.tw, f.t.twist_f, st)
+                      : gl_launch_strided256<0, false>(f, d, f.k, s_lo, npoly, f.t.tw, nullptr, st);
+        else
+            rc = last ? gl_launch_strided<0, true>(f, ms[p], d, f.k, s_lo, npoly, f.t.tw, f.t.twist_f, st)
                       : gl_launch_strided<0, false>(f, ms[p], d, f.k, s_lo, npoly, f.t.tw, nullptr, st);
         if (rc) return rc;
         s_lo += ms[p];
@@ -454,11 +579,16 @@ inline int gl_strided_inv(const GoldilocksFastTables &f, uint64_t *d, size_t npo
     int ms[8];
     const int n = gl_plan(f.k - 12, ms);
     int s_lo = f.k - 12;
+    const uint64_t *tw_i = fused ? f.t.twist_i_mul : f.t.twist_i_plain;
     for (int p = n - 1; p >= 0; p--) {
         s_lo -= ms[p];
         const bool first = p == n - 1;
-        int rc = first ? gl_launch_strided<1, true>(f, ms[p], d, f.k, s_lo, npoly, f.t.itw,
-                                                    fused ? f.t.twist_i_mul : f.t.twist_i_plain, st)
+        int rc;
+        if (ms[p] == 8)
+            rc = first ? gl_launch_strided256<1, true>(f, d, f.k, s_lo, npoly, f.t.itw, tw_i, st)
+                       : gl_launch_strided256<1, false>(f, d, f.k, s_lo, npoly, f.t.itw, nullptr, st);
+        else
+            rc = first ? gl_launch_strided<1, true>(f, ms[p], d, f.k, s_lo, npoly, f.t.itw, tw_i, st)
                        : gl_launch_strided<1, false>(f, ms[p], d, f.k, s_lo, npoly, f.t.itw, nullptr, st);
         if (rc) return rc;
     }
