@@ -188,6 +188,21 @@ def main():
     except (OSError, ValueError, KeyError, IndexError):
         pass
 
+    # integer-VALU issue roofline of the same kernel: dynamic VALU instructions per wave (SQ counter pass committed
+    # under profiles/) x waves per launch / measured duration, against one wave-instruction per 4 cycles per SIMD
+    valu = None
+    try:
+        vj = json.load(open(os.path.join(ROOT, "profiles", rounds[-1], "valu.json")))
+        if vj.get("workload") == args.workload and batch == vj.get("batch") and dom_tag in vj["kernels"]:
+            kv = vj["kernels"][dom_tag]
+            rate = kv["waves_per_launch"] * kv["valu_per_wave"] / (dom_avg_ms * 1e-3)
+            peak = 256 * 4 * 2.4e9 / 4
+            valu = {"bound": "valu-issue", "achieved": rate, "peak": peak, "unit": "wave-instructions/s", "frac": rate / peak,
+                    "valu_instructions_per_wave": kv["valu_per_wave"], "waves_per_launch": kv["waves_per_launch"],
+                    "note": "supplementary: the path is integer-VALU-bound, see DESIGN.md section 6"}
+    except (OSError, ValueError, KeyError, IndexError, NameError):
+        pass
+
     out = {
         "metric": "ring-muls/sec (Goldilocks, deg 2^16, batch 2^14)" if args.workload == "goldilocks_d65536_b16384"
                   else "ring-muls/sec (%s)" % args.workload,
@@ -212,6 +227,9 @@ def main():
                      "whole_step_achieved_per_gpu": step_gbs, "whole_step_frac": step_gbs / HBM_PEAK_GBS,
                      "per_kernel_ms_per_step": {t: v["ms"] / args.steps for t, v in kern.items()}},
     }
+
+    if valu is not None:
+        out["integer_valu"] = valu
 
     if world == 1 and not args.no_cpu_baseline:
         cores = usable_cores()

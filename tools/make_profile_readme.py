@@ -52,6 +52,28 @@ tj = {"workload": "goldilocks_d65536_b16384", "batch": 16384, "unit": "bytes of 
       "bytes_per_launch": {t: int(sum(2 * agg["FETCH_SIZE"][k] + agg["WRITE_SIZE"].get(k, 0) for k in ks) * 1024 / max(1, len(ks)))
                            for t, ks in tags.items() if ks}}
 json.dump(tj, open(os.path.join(d, "traffic.json"), "w"), indent=1)
+# integer-VALU issue roofline inputs: dynamic VALU instructions per wave from the SQ counter pass
+sq_path = os.path.join(d, "pmc_SQ_counters.csv")
+if os.path.exists(sq_path):
+    dd = collections.defaultdict(lambda: collections.defaultdict(list))
+    for r in csv.DictReader(open(sq_path)):
+        dd[r["Kernel_Name"].split("(")[0].replace("void ", "")][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    vj = {"workload": "goldilocks_d65536_b16384", "batch": 16384,
+          "note": "SQ_INSTS_VALU / SQ_WAVES per dispatch (rocprofv3 --pmc, own pass); waves per launch = SQ_WAVES",
+          "kernels": {}}
+    out.append("## VALU instructions per wave (pmc_SQ_counters.csv)\n")
+    out.append("| kernel | SQ_WAVES per launch | SQ_INSTS_VALU per wave | SQ_INSTS_SALU per wave |\n|---|---|---|---|")
+    for t, ks in tags.items():
+        for k in ks:
+            if k in dd and "SQ_WAVES" in dd[k]:
+                waves = sum(dd[k]["SQ_WAVES"]) / len(dd[k]["SQ_WAVES"])
+                valu = sum(dd[k]["SQ_INSTS_VALU"]) / len(dd[k]["SQ_INSTS_VALU"]) / waves
+                salu = sum(dd[k].get("SQ_INSTS_SALU", [0])) / max(1, len(dd[k].get("SQ_INSTS_SALU", [0]))) / waves
+                vj["kernels"][t] = {"waves_per_launch": int(waves), "valu_per_wave": round(valu, 1)}
+                out.append("| `%s` | %d | %.0f | %.0f |" % (k, waves, valu, salu))
+    out.append("\nIssue roofline used by bench.py (`integer_valu`): 256 CUs x 4 SIMDs x one wave-instruction per 4 cycles x 2.4 GHz = 6.14e11 wave-instructions/s")
+    out.append("(valu_issue_rates_gfx950*.txt: carries, compares, v_cndmask, multiplies, 64-bit ops issue every ~4 cycles per SIMD; plain 32-bit add/logic every ~2).\n")
+    json.dump(vj, open(os.path.join(d, "valu.json"), "w"), indent=1)
 extra = os.path.join(d, "NOTES.md")
 if os.path.exists(extra):
     out.append(open(extra).read())
