@@ -369,13 +369,21 @@ __global__ __launch_bounds__(256, SR_ROWS_WAVES) void rows_kernel(u64 *a, const 
     const size_t base = (size_t)blockIdx.x * kTile;
     u64 A[16];
     if (MODE == 1) {
+        // lane-contiguous global load, then an exchange into the 16-contiguous-per-lane layout of the first pass
 #pragma unroll
-        for (int j = 0; j < 16; j++) A[j] = a[base + 16 * t + j];
+        for (int j = 0; j < 16; j++) lds[pad(j * 256 + t)] = a[base + j * 256 + t];
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 16; j++) A[j] = lds[17 * t + j];
     } else {
         tile_fwd(a + base, lds, t, T, A);
         if (MODE == 0) {
+            // results sit 16-contiguous per lane; one more exchange makes the global store lane-contiguous
 #pragma unroll
-            for (int j = 0; j < 16; j++) a[base + 16 * t + j] = A[j];
+            for (int j = 0; j < 16; j++) lds[17 * t + j] = A[j];  // own pass-3 slots
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < 16; j++) a[base + j * 256 + t] = lds[pad(j * 256 + t)];
             return;
         }
         u64 B[16];

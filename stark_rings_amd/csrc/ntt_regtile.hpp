@@ -155,17 +155,25 @@ __global__ __launch_bounds__(256, 4) void rows_kernel(const typename View<F, VI>
         if (MODE == 2) load_tw16<F>(wn, p.itw, p.c + 8, blk3);  // first inverse pass
         fwd16<F>(x, w);
         if (MODE == 0) {
+            // results sit 16-contiguous per lane; one more exchange makes the global store lane-contiguous
 #pragma unroll
-            for (int j = 0; j < 16; j++) Out::st(out + base + 16 * t + j, x[j]);
+            for (int j = 0; j < 16; j++) la[17 * t + j] = x[j];  // own pass-3 slots
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < 16; j++) Out::st(out + base + j * 256 + t, la[pad(j * 256 + t)]);
             return;
         }
         fwd16<F>(y, w);
 #pragma unroll
         for (int j = 0; j < 16; j++) x[j] = F::mul_tw(x[j], y[j]);
     } else {
+        // lane-contiguous global load, then an exchange into the 16-contiguous-per-lane layout of the first pass
 #pragma unroll
-        for (int j = 0; j < 16; j++) x[j] = In::ld(a + base + 16 * t + j);
+        for (int j = 0; j < 16; j++) la[pad(j * 256 + t)] = In::ld(a + base + j * 256 + t);
         load_tw16<F>(wn, p.itw, p.c + 8, blk3);
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 16; j++) x[j] = la[17 * t + j];
     }
 
     // inverse: stages c+11 .. c
