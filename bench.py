@@ -114,22 +114,20 @@ def main():
     ring.fill_uniform_dev(b, 0x5EED0002, first)
     torch.cuda.synchronize()
 
-    # ---- parity gate: one untimed step, sampled elements checked bit-for-bit against the oracle ----
-    import oracle_lib as O
-
-    F = O.FIELD_ID[ring_name]
+    # ---- property gate (no oracle here: the oracle is only used inside the cpu_baseline leg below): one untimed step,
+    #      outputs canonical, icrt(crt(c)) == c on the result, sampled outputs kept for the cpu_baseline leg's bit-exact check
+    wpe = ring.words_per_elem
     ring.mul_dev(a, a, b)
     torch.cuda.synchronize()
-    sample = sorted({0, batch // 3, batch - 1})
-    wpe = ring.words_per_elem
-    for e in sample:
-        ea = O.fill_uniform(F, 0x5EED0001, first + e * d, d)
-        eb = O.fill_uniform(F, 0x5EED0002, first + e * d, d)
-        want = O.pow2_ring_mul(F, ea, eb, k)
-        got = a[e * wpe:(e + 1) * wpe].cpu().numpy().view(np.uint64)
-        if not np.array_equal(got, want):
-            raise SystemExit("PARITY FAILURE rank %d element %d: GPU result differs from the oracle" % (rank, e))
     assert ring.count_noncanonical_dev(a) == 0, "non-canonical outputs"
+    sample = sorted({0, batch // 3, batch - 1})
+    sample_out = {e: a[e * wpe:(e + 1) * wpe].cpu().numpy().view(np.uint64).copy() for e in sample}
+    rt = a[:min(batch, 8) * wpe].clone()
+    ring.elementwise_crt_dev(rt)
+    ring.elementwise_icrt_dev(rt)
+    if not torch.equal(rt, a[:rt.numel()]):
+        raise SystemExit("PROPERTY FAILURE rank %d: icrt(crt(c)) != c" % rank)
+    del rt
 
     def barrier():
         torch.cuda.synchronize()
@@ -232,6 +230,15 @@ def main():
         out["integer_valu"] = valu
 
     if world == 1 and not args.no_cpu_baseline:
+        import oracle_lib as O  # test infrastructure; used here as CHECKER of the sampled GPU outputs and as the timed CPU baseline
+
+        F = O.FIELD_ID[ring_name]
+        for e in sample:
+            ea = O.fill_uniform(F, 0x5EED0001, first + e * d, d)
+            eb = O.fill_uniform(F, 0x5EED0002, first + e * d, d)
+            if not np.array_equal(sample_out[e], O.pow2_ring_mul(F, ea, eb, k)):
+                raise SystemExit("PARITY FAILURE element %d: GPU result differs from the oracle" % e)
+        out["parity"] = "bit-exact vs oracle on elements %s of the first step; all outputs canonical; icrt(crt(c)) == c" % sample
         cores = usable_cores()
         n0 = max(cores, 8)
         ea = O.fill_uniform(F, 1, 0, n0 * d)
