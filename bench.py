@@ -31,6 +31,7 @@ WORKLOADS = {
     "goldilocks_d1048576_b8192": ("goldilocks", 20, 1 << 13, 8),  # configs[3] per-GPU shard (2^16 / 8)
     "stark_d4096_b4096": ("stark", 12, 1 << 12, 32),              # configs[4]
     "goldilocks_d1024_b1": ("goldilocks", 10, 1, 8),              # configs[0] plumbing
+    "goldilocks_d1024_b1048576": ("goldilocks", 10, 1 << 20, 8),  # configs[0]'s degree at a GPU-sized batch (informational)
 }
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 

@@ -5,7 +5,8 @@
 // outputs bit-identical -- but decomposed for the gfx950 integer pipe, where a 64x64 product is four
 // quarter-rate v_mad_u64_u32 and dominates everything else:
 //
-//   D = 2^c * 4096.
+//   D = 2^c * 4096 (for 256 <= D <= 4096 there are no strided passes: a tile holds 4096 / D whole ring elements, the rows
+//   kernel applies the twist itself and skips the radix-16 stages that would mix them -- one fused launch).
 //   (1) strided passes: the first c merged negacyclic radix-2 stages, 2^M legs per lane in registers,
 //       twiddles tw[2^s + b] wave-uniform (scalar loads); the last pass multiplies block b, position i
 //       by gamma_b^i (gamma_b = psi^(2 brv_c(b) + 1)), which turns every 4096-block into a plain
@@ -128,6 +129,24 @@ SR_HD void dft16_inv(u64 *x) {
     dit_stage<2, (kW16Exp * 4) % 192>(x, std::make_integer_sequence<int, 4>{});
     dit_stage<4, (kW16Exp * 2) % 192>(x, std::make_integer_sequence<int, 2>{});
     dit_stage<8, kW16Exp>(x, std::make_integer_sequence<int, 1>{});
+}
+
+// Q leading stages skipped: 2^Q independent cyclic DFTs of size 16 >> Q on consecutive register groups (used when
+// D < 4096 and a tile holds 2^Q ring elements: the stride-256 pass must not mix them); same twiddles as the tail
+// of the full network because omega_(16 >> Q) = omega_16^(2^Q)
+template <int Q>
+SR_HD void dft16_fwd_q(u64 *x) {
+    if constexpr (Q <= 0) dif_stage<8, kW16Exp>(x, std::make_integer_sequence<int, 1>{});
+    if constexpr (Q <= 1) dif_stage<4, (kW16Exp * 2) % 192>(x, std::make_integer_sequence<int, 2>{});
+    if constexpr (Q <= 2) dif_stage<2, (kW16Exp * 4) % 192>(x, std::make_integer_sequence<int, 4>{});
+    if constexpr (Q <= 3) dif_stage<1, (kW16Exp * 8) % 192>(x, std::make_integer_sequence<int, 8>{});
+}
+template <int Q>
+SR_HD void dft16_inv_q(u64 *x) {
+    if constexpr (Q <= 3) dit_stage<1, (kW16Exp * 8) % 192>(x, std::make_integer_sequence<int, 8>{});
+    if constexpr (Q <= 2) dit_stage<2, (kW16Exp * 4) % 192>(x, std::make_integer_sequence<int, 4>{});
+    if constexpr (Q <= 1) dit_stage<4, (kW16Exp * 2) % 192>(x, std::make_integer_sequence<int, 2>{});
+    if constexpr (Q <= 0) dit_stage<8, kW16Exp>(x, std::make_integer_sequence<int, 1>{});
 }
 
 struct Tables {
@@ -310,13 +329,31 @@ __global__ __launch_bounds__(256, 4) void strided256_kernel(u64 *data, int k, in
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ int pad(int pos) { return pos + (pos >> 4); }
 
-// forward cyclic DFT_4096 of the tile at src; x[] returns positions 16 t .. 16 t + 15 of the result
-__device__ __forceinline__ void tile_fwd(const u64 *__restrict__ src, u64 *lds, const int t, const Tables &T, u64 *x) {
+// Forward transform of one tile; x[] returns positions 16 t .. 16 t + 15 of the result.
+//   Q = 0, TW = false: D >= 8192, the tile is one 4096-block already twisted by the strided pass: cyclic DFT_4096.
+//   TW = true (D = 4096 >> Q <= 4096): the tile holds 2^Q whole ring elements; the negacyclic twist psi^i is applied on
+//   load, the stride-256 pass runs the last 4 - Q stages of the radix-16 only, and nvalid (a multiple of D) guards a
+//   ragged last tile.
+template <int Q, bool TW>
+__device__ __forceinline__ void tile_fwd(const u64 *__restrict__ src, u64 *lds, const int t, const Tables &T, u64 *x,
+                                         int nvalid, unsigned dmask) {
 #pragma unroll
-    for (int j = 0; j < 16; j++) x[j] = src[j * 256 + t];
-    dft16_fwd(x);
+    for (int j = 0; j < 16; j++) {
+        const int pos = j * 256 + t;
+        if (TW) {
+            // ragged last tile: out-of-range lanes re-read the last valid coefficient (their results belong to ring
+            // elements that do not exist and are never stored; no pass mixes ring elements), so no branch is needed
+            const int src_pos = pos < nvalid ? pos : nvalid - 1;
+            x[j] = G::mul(src[src_pos], T.twist_f[pos & dmask]);
+        } else {
+            x[j] = src[pos];
+        }
+    }
+    dft16_fwd_q<Q>(x);
+    if (Q < 4) {
 #pragma unroll
-    for (int r = 1; r < 16; r++) x[r] = G::mul(x[r], T.w1f[r * 256 + t]);
+        for (int r = 1; r < 16; r++) x[r] = G::mul(x[r], T.w1f[r * 256 + t]);
+    }
 #pragma unroll
     for (int r = 0; r < 16; r++) lds[pad(r * 256 + t)] = x[r];
     __syncthreads();
@@ -334,8 +371,12 @@ __device__ __forceinline__ void tile_fwd(const u64 *__restrict__ src, u64 *lds, 
     dft16_fwd(x);
 }
 
-// inverse of tile_fwd (unnormalised: 4096 x); x[] holds positions 16 t .. 16 t + 15 on entry
-__device__ __forceinline__ void tile_inv(u64 *x, u64 *lds, const int t, const Tables &T, u64 *__restrict__ dst) {
+// inverse of tile_fwd; x[] holds positions 16 t .. 16 t + 15 on entry.  With TW the result is multiplied by
+// twist_i (psi^-i * D^-1, times 2^-64 for the fused product); otherwise it is 4096 x the cyclic inverse and the
+// strided inverse pass finishes the job.
+template <int Q, bool TW>
+__device__ __forceinline__ void tile_inv(u64 *x, u64 *lds, const int t, const Tables &T, const u64 *twist_i,
+                                         u64 *__restrict__ dst, int nvalid, unsigned dmask) {
     dft16_inv(x);
 #pragma unroll
     for (int j = 0; j < 16; j++) lds[17 * t + j] = x[j];
@@ -351,49 +392,71 @@ __device__ __forceinline__ void tile_inv(u64 *x, u64 *lds, const int t, const Ta
     __syncthreads();
 #pragma unroll
     for (int r = 0; r < 16; r++) x[r] = lds[pad(r * 256 + t)];
+    if (Q < 4) {
 #pragma unroll
-    for (int r = 1; r < 16; r++) x[r] = G::mul(x[r], T.w1i[r * 256 + t]);
-    dft16_inv(x);
+        for (int r = 1; r < 16; r++) x[r] = G::mul(x[r], T.w1i[r * 256 + t]);
+    }
+    dft16_inv_q<Q>(x);
 #pragma unroll
-    for (int j = 0; j < 16; j++) dst[j * 256 + t] = x[j];
+    for (int j = 0; j < 16; j++) {
+        const int pos = j * 256 + t;
+        if (TW) {
+            if (pos < nvalid) dst[pos] = G::mul(x[j], twist_i[pos & dmask]);
+        } else {
+            dst[pos] = x[j];
+        }
+    }
 }
 
-// MODE_FWD: a -> a (in place); MODE_INV: a -> a; MODE_MUL: out = a (.) b in the transformed domain and back
-template <int MODE>
+// MODE 0: a -> crt(a) in place; 1: a -> icrt(a) in place; 2: out = icrt(crt(a) (.) crt(b)) tile by tile.
+// n_total = flat coefficient count of the batch (only consulted when TW: ragged last tile).
 #ifndef SR_ROWS_WAVES
 #define SR_ROWS_WAVES 4
 #endif
-__global__ __launch_bounds__(256, SR_ROWS_WAVES) void rows_kernel(u64 *a, const u64 *b, u64 *out, Tables T) {
+#ifndef SR_ROWS_WAVES_TW
+#define SR_ROWS_WAVES_TW 3
+#endif
+template <int MODE, int Q, bool TW>
+__global__ __launch_bounds__(256, TW ? SR_ROWS_WAVES_TW : SR_ROWS_WAVES) void rows_kernel(u64 *a, const u64 *b, u64 *out, Tables T, const u64 *twist_i,
+                                                                   size_t n_total, unsigned dmask) {
     __shared__ u64 lds[kLdsElems];
     const int t = threadIdx.x;
     const size_t base = (size_t)blockIdx.x * kTile;
+    int nvalid = kTile;
+    if (TW) nvalid = n_total - base < (size_t)kTile ? (int)(n_total - base) : kTile;
     u64 A[16];
     if (MODE == 1) {
         // lane-contiguous global load, then an exchange into the 16-contiguous-per-lane layout of the first pass
 #pragma unroll
-        for (int j = 0; j < 16; j++) lds[pad(j * 256 + t)] = a[base + j * 256 + t];
+        for (int j = 0; j < 16; j++) {
+            const int pos = j * 256 + t;
+            lds[pad(pos)] = a[base + ((!TW || pos < nvalid) ? pos : nvalid - 1)];
+        }
         __syncthreads();
 #pragma unroll
         for (int j = 0; j < 16; j++) A[j] = lds[17 * t + j];
     } else {
-        tile_fwd(a + base, lds, t, T, A);
+        tile_fwd<Q, TW>(a + base, lds, t, T, A, nvalid, dmask);
         if (MODE == 0) {
             // results sit 16-contiguous per lane; one more exchange makes the global store lane-contiguous
 #pragma unroll
             for (int j = 0; j < 16; j++) lds[17 * t + j] = A[j];  // own pass-3 slots
             __syncthreads();
 #pragma unroll
-            for (int j = 0; j < 16; j++) a[base + j * 256 + t] = lds[pad(j * 256 + t)];
+            for (int j = 0; j < 16; j++) {
+                const int pos = j * 256 + t;
+                if (!TW || pos < nvalid) a[base + pos] = lds[pad(pos)];
+            }
             return;
         }
         u64 B[16];
         __syncthreads();  // everyone has read its pass-3 slots of a before b's pass-1 writes land
-        tile_fwd(b + base, lds, t, T, B);
+        tile_fwd<Q, TW>(b + base, lds, t, T, B, nvalid, dmask);
 #pragma unroll
         for (int j = 0; j < 16; j++) A[j] = G::mul(A[j], B[j]);
         __syncthreads();
     }
-    tile_inv(A, lds, t, T, out + base);
+    tile_inv<Q, TW>(A, lds, t, T, twist_i, out + base, nvalid, dmask);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -407,25 +470,32 @@ __device__ __forceinline__ u64 pow_from_bits(const u64 *pw, unsigned e, int k) {
 }
 __global__ void build_tables_kernel(int k, const u64 *pows, const u64 *ipows, u64 dinv, u64 dinv_mul, u64 *twist_f,
                                     u64 *twist_i_plain, u64 *twist_i_mul, u64 *w1f, u64 *w1i, u64 *w2f, u64 *w2i) {
-    const int c = k - 12;
+    const int c = k > 12 ? k - 12 : 0;   // strided stages
+    const int q = k < 12 ? 12 - k : 0;   // log2 of ring elements per tile
     const size_t d = (size_t)1 << k;
+    const size_t n = d > 4096 ? d : 4096;
     const unsigned mask2d = (unsigned)(2 * d - 1);
-    for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < d; idx += (size_t)gridDim.x * blockDim.x) {
-        unsigned b = (unsigned)(idx >> 12), i = (unsigned)(idx & 4095);
-        unsigned e = (unsigned)(((unsigned long long)(2 * bitrev(b, c) + 1) * i) & mask2d);
-        twist_f[idx] = pow_from_bits(pows, e, k);
-        u64 inv = pow_from_bits(ipows, e, k);
-        twist_i_plain[idx] = G::mul(inv, dinv);
-        twist_i_mul[idx] = G::mul(inv, dinv_mul);
+    for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < n; idx += (size_t)gridDim.x * blockDim.x) {
+        if (idx < d) {
+            unsigned b = (unsigned)(idx >> 12), i = (unsigned)(idx & 4095);
+            unsigned e = (unsigned)(((unsigned long long)(2 * bitrev(b, c) + 1) * i) & mask2d);
+            twist_f[idx] = pow_from_bits(pows, e, k);
+            u64 inv = pow_from_bits(ipows, e, k);
+            twist_i_plain[idx] = G::mul(inv, dinv);
+            twist_i_mul[idx] = G::mul(inv, dinv_mul);
+        }
         if (idx < 4096) {
+            // omega_N^(i0 * m0), N = min(D, 4096) = the cyclic size the stride-256 pass starts; slot r of a lane belongs to
+            // ring element r >> (4 - q) of the tile and carries output index brv_(4-q)(r mod 2^(4-q)) of its sub-DFT
             unsigned r = (unsigned)(idx >> 8), i0 = (unsigned)(idx & 255);
-            unsigned e1 = (unsigned)((((unsigned long long)i0 * bitrev(r, 4)) << (c + 1)) & mask2d);  // omega_4096 = psi^(2^(c+1))
+            unsigned m0 = bitrev(r & ((1u << (4 - q)) - 1u), 4 - q);
+            unsigned e1 = (unsigned)((((unsigned long long)i0 * m0) << (c + 1)) & mask2d);  // omega_N = psi^(2D/N) = psi^(2^(c+1))
             w1f[idx] = pow_from_bits(pows, e1, k);
             w1i[idx] = pow_from_bits(ipows, e1, k);
         }
         if (idx < 256) {
             unsigned s = (unsigned)(idx >> 4), i0 = (unsigned)(idx & 15);
-            unsigned e2 = (unsigned)((((unsigned long long)i0 * bitrev(s, 4)) << (c + 5)) & mask2d);  // omega_256 = psi^(2^(c+5))
+            unsigned e2 = (unsigned)((((unsigned long long)i0 * bitrev(s, 4)) << (k - 7)) & mask2d);  // omega_256 = psi^(2D/256)
             w2f[idx] = pow_from_bits(pows, e2, k);
             w2i[idx] = pow_from_bits(ipows, e2, k);
         }
@@ -463,7 +533,7 @@ struct GlProfScope {
 
 inline bool gl_fast_supported(const GoldilocksFastTables &f) { return f.ready; }
 inline size_t gl_fast_extra_bytes(int k) {
-    if (k < 12 || k > 22) return 0;
+    if (k < 8 || k > 22) return 0;  // D = 256 .. 2^22
     return (((size_t)3 << k) + 2 * 4096 + 2 * 256) * sizeof(uint64_t);
 }
 // extra = device memory of gl_fast_extra_bytes(k) bytes, placed right behind [tw | itw] in the context's
@@ -487,7 +557,7 @@ inline int gl_fast_init(GoldilocksFastTables &f, int k, const uint64_t *tw, cons
     if (hipMalloc(&d_pows, 2 * (k + 1) * sizeof(uint64_t)) != hipSuccess) return 1;
     if (hipMemcpy(d_pows, host_pows, (k + 1) * 8, hipMemcpyHostToDevice) != hipSuccess) return 1;
     if (hipMemcpy(d_pows + k + 1, host_ipows, (k + 1) * 8, hipMemcpyHostToDevice) != hipSuccess) return 1;
-    unsigned blocks = (unsigned)((d + 255) / 256);
+    unsigned blocks = (unsigned)(((d > 4096 ? d : 4096) + 255) / 256);
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(gl::build_tables_kernel, dim3(blocks), dim3(256), 0, st, k, d_pows, d_pows + k + 1, dinv, dinv_mul,
                        twist_f, twist_ip, twist_im, w1f, w1i, w2f, w2i);
@@ -562,12 +632,11 @@ inline int gl_plan(int c, int *ms) {
         c -= m;
     }
     if (big) ms[n++] = 8;
-    if (n == 0) ms[n++] = 0;  // D = 4096: twist-only pass
-    return n;
+    return n;  // 0 passes for D <= 4096: the rows kernel applies the twist itself
 }
 inline int gl_strided_fwd(const GoldilocksFastTables &f, uint64_t *d, size_t npoly, hipStream_t st) {
     int ms[8];
-    const int n = gl_plan(f.k - 12, ms);
+    const int n = gl_plan(f.k > 12 ? f.k - 12 : 0, ms);
     int s_lo = 0;
     for (int p = 0; p < n; p++) {
         const bool last = p == n - 1;
@@ -585,8 +654,8 @@ inline int gl_strided_fwd(const GoldilocksFastTables &f, uint64_t *d, size_t npo
 }
 inline int gl_strided_inv(const GoldilocksFastTables &f, uint64_t *d, size_t npoly, bool fused, hipStream_t st) {
     int ms[8];
-    const int n = gl_plan(f.k - 12, ms);
-    int s_lo = f.k - 12;
+    const int n = gl_plan(f.k > 12 ? f.k - 12 : 0, ms);
+    int s_lo = f.k > 12 ? f.k - 12 : 0;
     const uint64_t *tw_i = fused ? f.t.twist_i_mul : f.t.twist_i_plain;
     for (int p = n - 1; p >= 0; p--) {
         s_lo -= ms[p];
@@ -604,27 +673,42 @@ inline int gl_strided_inv(const GoldilocksFastTables &f, uint64_t *d, size_t npo
 }
 template <int MODE>
 inline int gl_launch_rows(const GoldilocksFastTables &f, uint64_t *a, const uint64_t *b, uint64_t *out, size_t npoly,
-                          hipStream_t st) {
-    const size_t tiles = npoly << (f.k - 12);
+                          bool fused, hipStream_t st) {
+    const size_t n_total = npoly << f.k;
+    const size_t tiles = (n_total + gl::kTile - 1) / gl::kTile;
     if (tiles == 0 || tiles > 0x7FFFFFFFull) return 1;
     GlProfScope ps(f, 1, st);
-    hipLaunchKernelGGL((gl::rows_kernel<MODE>), dim3((unsigned)tiles), dim3(256), 0, st, a, b, out, f.t);
+    const uint64_t *tw_i = fused ? f.t.twist_i_mul : f.t.twist_i_plain;
+    const unsigned dmask = (unsigned)(((size_t)1 << f.k) - 1);
+    dim3 g((unsigned)tiles), blk(256);
+#define SR_GL_ROWS(QQ, TT) hipLaunchKernelGGL((gl::rows_kernel<MODE, QQ, TT>), g, blk, 0, st, a, b, out, f.t, tw_i, n_total, dmask)
+    switch (f.k) {
+        case 8: SR_GL_ROWS(4, true); break;
+        case 9: SR_GL_ROWS(3, true); break;
+        case 10: SR_GL_ROWS(2, true); break;
+        case 11: SR_GL_ROWS(1, true); break;
+        case 12: SR_GL_ROWS(0, true); break;
+        default: SR_GL_ROWS(0, false); break;
+    }
+#undef SR_GL_ROWS
     return hipGetLastError() != hipSuccess;
 }
 inline int gl_fast_fwd(const GoldilocksFastTables &f, uint64_t *d, size_t batch, hipStream_t st) {
     if (batch == 0) return 0;
     if (gl_strided_fwd(f, d, batch, st)) return 1;
-    return gl_launch_rows<0>(f, d, nullptr, d, batch, st);
+    return gl_launch_rows<0>(f, d, nullptr, d, batch, false, st);
 }
 inline int gl_fast_inv(const GoldilocksFastTables &f, uint64_t *d, size_t batch, hipStream_t st) {
     if (batch == 0) return 0;
-    if (gl_launch_rows<1>(f, d, nullptr, d, batch, st)) return 1;
+    if (gl_launch_rows<1>(f, d, nullptr, d, batch, false, st)) return 1;
     return gl_strided_inv(f, d, batch, false, st);
 }
 // out = a * b (ring product on in-memory images); b is overwritten with its strided-pass image.
 inline int gl_fast_ring_mul(const GoldilocksFastTables &f, uint64_t *out, const uint64_t *a, uint64_t *b, size_t batch,
                             hipStream_t st) {
     if (batch == 0) return 0;
+    if (f.k <= 12)  // whole ring elements per tile: one fused launch, a and b only read
+        return gl_launch_rows<2>(f, const_cast<uint64_t *>(a), b, out, batch, true, st);
     const size_t chunk = f.chunk_polys ? f.chunk_polys : batch;
     const size_t stride = (size_t)1 << f.k;
     const bool lanes = f.n_lanes > 1 && chunk < batch;
@@ -642,7 +726,7 @@ inline int gl_fast_ring_mul(const GoldilocksFastTables &f, uint64_t *out, const 
         if (o != aa && hipMemcpyAsync(o, aa, n * stride * 8, hipMemcpyDeviceToDevice, s) != hipSuccess) return 1;
         if (gl_strided_fwd(f, o, n, s)) return 1;
         if (gl_strided_fwd(f, bb, n, s)) return 1;
-        if (gl_launch_rows<2>(f, o, bb, o, n, s)) return 1;
+        if (gl_launch_rows<2>(f, o, bb, o, n, true, s)) return 1;
         if (gl_strided_inv(f, o, n, true, s)) return 1;
     }
     if (lanes) {

@@ -232,10 +232,11 @@ def test_small_rings_match_oracle(torch_cuda, name):
 
 
 # ----------------------------------------------------------------------------- tuned Goldilocks path
-@pytest.mark.parametrize("k,batch", [(12, 7), (14, 3), (15, 2), (17, 2), (18, 1), (20, 1)])
+@pytest.mark.parametrize("k,batch", [(8, 21), (9, 13), (10, 5), (11, 3), (12, 7), (14, 3), (15, 2), (17, 2), (18, 1), (20, 1)])
 def test_goldilocks_tuned_path_all_plans(torch_cuda, k, batch):
-    """D = 2^c * 4096 for every strided-pass plan (c = 0, single pass, two passes), vs the oracle
-    and vs the generic kernels (SR_GOLDILOCKS_GENERIC=1 routes the same ring through them)."""
+    """Every plan of the tuned path: 256 <= D <= 4096 (several ring elements per tile, ragged last tile, twist inside the
+    rows kernel) and D = 2^c * 4096 (one or two strided register passes, the 256-leg pass), vs the oracle and vs the
+    generic kernels (SR_GOLDILOCKS_GENERIC=1 routes the same ring through them)."""
     import os
 
     from stark_rings_amd import CyclotomicRing

@@ -35,3 +35,17 @@ def test_decomposition_equals_reference_transform():
         got = M.fast_fwd(a, k, T)
         assert got == want
         assert M.fast_inv(got, k, T) == a
+
+
+def test_small_degree_mode_equals_reference_transform():
+    """D = 4096 >> q: 2^q ring elements per tile, twist applied by the rows kernel, leading radix-16 stages skipped."""
+    rng = random.Random(5)
+    p = P.GOLDILOCKS_P
+    for k in (8, 9, 11):
+        T = M.small_tables(k)
+        D = 1 << k
+        tile = [rng.randrange(p) for _ in range(4096)]
+        got = M.small_fwd(tile, T)
+        for e in range(4096 // D):
+            assert got[e * D:(e + 1) * D] == P.pow2_fwd("goldilocks", tile[e * D:(e + 1) * D], k)
+        assert M.small_inv(got, T) == tile

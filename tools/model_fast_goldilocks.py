@@ -185,6 +185,91 @@ def fast_inv(A, k, T):
     return [v * s % p for v in a]
 
 
+# ---------------------------------------------------------------- D = 4096 >> q <= 4096: 2^q ring elements per tile
+def dft16_fwd_q(x, q):
+    """the last 4 - q DIF stages only: 2^q independent cyclic DFTs of size 16 >> q on consecutive groups"""
+    x = list(x)
+    half, step = 8, W16_EXP
+    while half >= 1:
+        if half <= (8 >> q):
+            for base in range(0, 16, 2 * half):
+                for j in range(half):
+                    a, b = x[base + j], x[base + j + half]
+                    x[base + j] = (a + b) % p
+                    x[base + j + half] = (a - b) * pow(2, (step * j) % 192, p) % p
+        half //= 2
+        step = (step * 2) % 192
+    return x
+
+
+def dft16_inv_q(x, q):
+    x = list(x)
+    steps = {1: (W16_EXP * 8) % 192, 2: (W16_EXP * 4) % 192, 4: (W16_EXP * 2) % 192, 8: W16_EXP}
+    half = 1
+    while half <= (8 >> q):
+        step = steps[half]
+        for base in range(0, 16, 2 * half):
+            for j in range(half):
+                u, v = x[base + j], x[base + j + half] * pow(2, (192 - (step * j) % 192) % 192, p) % p
+                x[base + j] = (u + v) % p
+                x[base + j + half] = (u - v) % p
+        half *= 2
+    return x
+
+
+def small_tables(k):
+    q = 12 - k
+    D = 1 << k
+    psi = P.psi("goldilocks", k)
+    wD = pow(psi, 2, p)                      # omega_D: the cyclic size the stride-256 pass starts is D itself
+    w256 = pow(psi, 2 * D // 256, p)
+    T = {"q": q, "D": D}
+    T["twist_f"] = [pow(psi, i, p) for i in range(D)]
+    inv = lambda v: pow(v, -1, p)
+    T["twist_i"] = [inv(v) * inv(D) % p for v in T["twist_f"]]
+    m0 = lambda r: brv(r & ((1 << (4 - q)) - 1), 4 - q)
+    T["W1f"] = [[pow(wD, i0 * m0(r), p) for i0 in range(256)] for r in range(16)]
+    T["W2f"] = [[pow(w256, i0 * brv(s, 4), p) for i0 in range(16)] for s in range(16)]
+    T["W1i"] = [[inv(v) for v in row] for row in T["W1f"]]
+    T["W2i"] = [[inv(v) for v in row] for row in T["W2f"]]
+    return T
+
+
+def small_fwd(tile, T):
+    """tile: 4096 coefficients = 2^q ring elements of degree D, element-major; returns their transforms"""
+    q, D = T["q"], T["D"]
+    y = [v * T["twist_f"][pos & (D - 1)] % p for pos, v in enumerate(tile)]
+    for t in range(256):
+        x = dft16_fwd_q([y[j * 256 + t] for j in range(16)], q)
+        for r in range(16):
+            y[r * 256 + t] = x[r] * T["W1f"][r][t] % p
+    for t in range(256):
+        rho, i0 = t >> 4, t & 15
+        x = dft16_fwd([y[rho * 256 + j * 16 + i0] for j in range(16)])
+        for s_ in range(16):
+            y[rho * 256 + s_ * 16 + i0] = x[s_] * T["W2f"][s_][i0] % p
+    for t in range(256):
+        y[16 * t:16 * t + 16] = dft16_fwd(y[16 * t:16 * t + 16])
+    return y
+
+
+def small_inv(tile, T):
+    q, D = T["q"], T["D"]
+    y = list(tile)
+    for t in range(256):
+        y[16 * t:16 * t + 16] = dft16_inv(y[16 * t:16 * t + 16])
+    for t in range(256):
+        rho, i0 = t >> 4, t & 15
+        x = dft16_inv([y[rho * 256 + s_ * 16 + i0] * T["W2i"][s_][i0] % p for s_ in range(16)])
+        for j in range(16):
+            y[rho * 256 + j * 16 + i0] = x[j]
+    for t in range(256):
+        x = dft16_inv_q([y[r * 256 + t] * T["W1i"][r][t] % p for r in range(16)], q)
+        for j in range(16):
+            y[j * 256 + t] = x[j]
+    return [v * T["twist_i"][pos & (D - 1)] % p for pos, v in enumerate(y)]
+
+
 if __name__ == "__main__":
     rng = random.Random(3)
     # radix-16 networks
@@ -211,4 +296,13 @@ if __name__ == "__main__":
     assert one == two
     back = strided_inv(strided_inv(one, k, 1, 1, T, True), k, 0, 1, T, False)
     assert back == strided_inv(one, k, 0, 2, T, True)
+    for k in (8, 10, 11):
+        T = small_tables(k)
+        D = 1 << k
+        tile = [rng.randrange(p) for _ in range(4096)]
+        got = small_fwd(tile, T)
+        for e in range(4096 // D):
+            assert got[e * D:(e + 1) * D] == P.pow2_fwd("goldilocks", tile[e * D:(e + 1) * D], k), "small fwd k=%d" % k
+        assert small_inv(got, T) == tile
+        print("small k=%d ok" % k)
     print("model OK")
