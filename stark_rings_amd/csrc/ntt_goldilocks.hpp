@@ -149,11 +149,30 @@ SR_HD void dft16_inv_q(u64 *x) {
     if constexpr (Q <= 0) dit_stage<8, kW16Exp>(x, std::make_integer_sequence<int, 1>{});
 }
 
+// x * 2^E for any compile-time E in [0, 192): 2^96 = -1
+template <int E>
+SR_HD u64 mul_pow2_signed(u64 x) {
+    if constexpr (E == 0) return x;
+    else if constexpr (E < 96) return mul_pow2<E>(x);
+    else if constexpr (E == 96) return G::neg(x);
+    else return G::neg(mul_pow2<E - 96>(x));
+}
+// Row part of the negacyclic twist when D = 4096 >> Q: register slot J of a lane is row J mod (16 >> Q) of its ring element and
+// psi^256 = 2^(39 * 2^(Q+1)) (because psi^(2D/64) = omega_64 = 2^39), so (psi^256)^row is a compile-time shift.
+constexpr int twist_exp(int q) { return (39 << (q + 1)) % 192; }
+template <int Q, bool INVERSE, int... Js>
+SR_HD void twist_rows(u64 *x, std::integer_sequence<int, Js...>) {
+    ((x[Js] = mul_pow2_signed<INVERSE ? (192 - (twist_exp(Q) * (Js & ((16 >> Q) - 1))) % 192) % 192
+                                      : (twist_exp(Q) * (Js & ((16 >> Q) - 1))) % 192>(x[Js])),
+     ...);
+}
+
 struct Tables {
     const u64 *tw, *itw;                     // merged-stage twiddles (shared with the generic path)
     const u64 *twist_f;                      // [b * 4096 + i] = gamma_b^i
     const u64 *twist_i_plain, *twist_i_mul;  // gamma_b^-i * D^-1   (and * 2^-64 for the fused product)
-    const u64 *w1f, *w1i;                    // [rho * 256 + i0] = omega_4096^(+- i0 brv4(rho))
+    const u64 *w1f, *w1i, *w1i_mul;          // [rho * 256 + i0] = omega_N^(+- i0 m0(rho)), N = min(D, 4096); for D <= 4096 they also carry
+                                             // the column part psi^(+-i0) of the twist and (inverse) D^-1 (w1i_mul: times 2^-64)
     const u64 *w2f, *w2i;                    // [sigma * 16 + i0] = omega_256^(+- i0 brv4(sigma))
 };
 
@@ -331,29 +350,25 @@ __device__ __forceinline__ int pad(int pos) { return pos + (pos >> 4); }
 
 // Forward transform of one tile; x[] returns positions 16 t .. 16 t + 15 of the result.
 //   Q = 0, TW = false: D >= 8192, the tile is one 4096-block already twisted by the strided pass: cyclic DFT_4096.
-//   TW = true (D = 4096 >> Q <= 4096): the tile holds 2^Q whole ring elements; the negacyclic twist psi^i is applied on
-//   load, the stride-256 pass runs the last 4 - Q stages of the radix-16 only, and nvalid (a multiple of D) guards a
-//   ragged last tile.
+//   TW = true (D = 4096 >> Q <= 4096): the tile holds 2^Q whole ring elements; the stride-256 pass runs the last 4 - Q stages
+//   of the radix-16 only; the negacyclic twist psi^(256 row + t) is split into a compile-time shift per register slot
+//   ((psi^256)^row, twist_rows) and the column factor psi^t, which commutes with that pass and lives in the w1 table;
+//   nvalid (a multiple of D) guards a ragged last tile.
 template <int Q, bool TW>
 __device__ __forceinline__ void tile_fwd(const u64 *__restrict__ src, u64 *lds, const int t, const Tables &T, u64 *x,
-                                         int nvalid, unsigned dmask) {
+                                         int nvalid) {
 #pragma unroll
     for (int j = 0; j < 16; j++) {
         const int pos = j * 256 + t;
-        if (TW) {
-            // ragged last tile: out-of-range lanes re-read the last valid coefficient (their results belong to ring
-            // elements that do not exist and are never stored; no pass mixes ring elements), so no branch is needed
-            const int src_pos = pos < nvalid ? pos : nvalid - 1;
-            x[j] = G::mul(src[src_pos], T.twist_f[pos & dmask]);
-        } else {
-            x[j] = src[pos];
-        }
+        // ragged last tile (TW only): out-of-range lanes re-read the last valid coefficient; their results belong to ring
+        // elements that do not exist and are never stored, and no pass mixes ring elements, so no branch is needed
+        x[j] = src[(!TW || pos < nvalid) ? pos : nvalid - 1];
     }
+    if (TW) twist_rows<Q, false>(x, std::make_integer_sequence<int, 16>{});
     dft16_fwd_q<Q>(x);
-    if (Q < 4) {
+    if (TW) x[0] = G::mul(x[0], T.w1f[t]);  // psi^t: with the twist merged in, slot 0 is no longer multiplied by 1
 #pragma unroll
-        for (int r = 1; r < 16; r++) x[r] = G::mul(x[r], T.w1f[r * 256 + t]);
-    }
+    for (int r = 1; r < 16; r++) x[r] = G::mul(x[r], T.w1f[r * 256 + t]);
 #pragma unroll
     for (int r = 0; r < 16; r++) lds[pad(r * 256 + t)] = x[r];
     __syncthreads();
@@ -371,12 +386,11 @@ __device__ __forceinline__ void tile_fwd(const u64 *__restrict__ src, u64 *lds, 
     dft16_fwd(x);
 }
 
-// inverse of tile_fwd; x[] holds positions 16 t .. 16 t + 15 on entry.  With TW the result is multiplied by
-// twist_i (psi^-i * D^-1, times 2^-64 for the fused product); otherwise it is 4096 x the cyclic inverse and the
-// strided inverse pass finishes the job.
+// inverse of tile_fwd; x[] holds positions 16 t .. 16 t + 15 on entry.  w1i is the plain or the fused-product table.
+// Without TW the result is 4096 x the cyclic inverse and the strided inverse pass finishes the job.
 template <int Q, bool TW>
-__device__ __forceinline__ void tile_inv(u64 *x, u64 *lds, const int t, const Tables &T, const u64 *twist_i,
-                                         u64 *__restrict__ dst, int nvalid, unsigned dmask) {
+__device__ __forceinline__ void tile_inv(u64 *x, u64 *lds, const int t, const Tables &T, const u64 *w1i,
+                                         u64 *__restrict__ dst, int nvalid) {
     dft16_inv(x);
 #pragma unroll
     for (int j = 0; j < 16; j++) lds[17 * t + j] = x[j];
@@ -392,19 +406,15 @@ __device__ __forceinline__ void tile_inv(u64 *x, u64 *lds, const int t, const Ta
     __syncthreads();
 #pragma unroll
     for (int r = 0; r < 16; r++) x[r] = lds[pad(r * 256 + t)];
-    if (Q < 4) {
+    if (TW) x[0] = G::mul(x[0], w1i[t]);  // psi^-t * D^-1
 #pragma unroll
-        for (int r = 1; r < 16; r++) x[r] = G::mul(x[r], T.w1i[r * 256 + t]);
-    }
+    for (int r = 1; r < 16; r++) x[r] = G::mul(x[r], w1i[r * 256 + t]);
     dft16_inv_q<Q>(x);
+    if (TW) twist_rows<Q, true>(x, std::make_integer_sequence<int, 16>{});
 #pragma unroll
     for (int j = 0; j < 16; j++) {
         const int pos = j * 256 + t;
-        if (TW) {
-            if (pos < nvalid) dst[pos] = G::mul(x[j], twist_i[pos & dmask]);
-        } else {
-            dst[pos] = x[j];
-        }
+        if (!TW || pos < nvalid) dst[pos] = x[j];
     }
 }
 
@@ -417,8 +427,8 @@ __device__ __forceinline__ void tile_inv(u64 *x, u64 *lds, const int t, const Ta
 #define SR_ROWS_WAVES_TW 3
 #endif
 template <int MODE, int Q, bool TW>
-__global__ __launch_bounds__(256, TW ? SR_ROWS_WAVES_TW : SR_ROWS_WAVES) void rows_kernel(u64 *a, const u64 *b, u64 *out, Tables T, const u64 *twist_i,
-                                                                   size_t n_total, unsigned dmask) {
+__global__ __launch_bounds__(256, TW ? SR_ROWS_WAVES_TW : SR_ROWS_WAVES) void rows_kernel(u64 *a, const u64 *b, u64 *out, Tables T, const u64 *w1i,
+                                                                   size_t n_total) {
     __shared__ u64 lds[kLdsElems];
     const int t = threadIdx.x;
     const size_t base = (size_t)blockIdx.x * kTile;
@@ -436,7 +446,7 @@ __global__ __launch_bounds__(256, TW ? SR_ROWS_WAVES_TW : SR_ROWS_WAVES) void ro
 #pragma unroll
         for (int j = 0; j < 16; j++) A[j] = lds[17 * t + j];
     } else {
-        tile_fwd<Q, TW>(a + base, lds, t, T, A, nvalid, dmask);
+        tile_fwd<Q, TW>(a + base, lds, t, T, A, nvalid);
         if (MODE == 0) {
             // results sit 16-contiguous per lane; one more exchange makes the global store lane-contiguous
 #pragma unroll
@@ -451,12 +461,12 @@ __global__ __launch_bounds__(256, TW ? SR_ROWS_WAVES_TW : SR_ROWS_WAVES) void ro
         }
         u64 B[16];
         __syncthreads();  // everyone has read its pass-3 slots of a before b's pass-1 writes land
-        tile_fwd<Q, TW>(b + base, lds, t, T, B, nvalid, dmask);
+        tile_fwd<Q, TW>(b + base, lds, t, T, B, nvalid);
 #pragma unroll
         for (int j = 0; j < 16; j++) A[j] = G::mul(A[j], B[j]);
         __syncthreads();
     }
-    tile_inv<Q, TW>(A, lds, t, T, twist_i, out + base, nvalid, dmask);
+    tile_inv<Q, TW>(A, lds, t, T, w1i, out + base, nvalid);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -469,7 +479,8 @@ __device__ __forceinline__ u64 pow_from_bits(const u64 *pw, unsigned e, int k) {
     return acc;
 }
 __global__ void build_tables_kernel(int k, const u64 *pows, const u64 *ipows, u64 dinv, u64 dinv_mul, u64 *twist_f,
-                                    u64 *twist_i_plain, u64 *twist_i_mul, u64 *w1f, u64 *w1i, u64 *w2f, u64 *w2i) {
+                                    u64 *twist_i_plain, u64 *twist_i_mul, u64 *w1f, u64 *w1i, u64 *w1i_mul, u64 *w2f,
+                                    u64 *w2i) {
     const int c = k > 12 ? k - 12 : 0;   // strided stages
     const int q = k < 12 ? 12 - k : 0;   // log2 of ring elements per tile
     const size_t d = (size_t)1 << k;
@@ -490,8 +501,11 @@ __global__ void build_tables_kernel(int k, const u64 *pows, const u64 *ipows, u6
             unsigned r = (unsigned)(idx >> 8), i0 = (unsigned)(idx & 255);
             unsigned m0 = bitrev(r & ((1u << (4 - q)) - 1u), 4 - q);
             unsigned e1 = (unsigned)((((unsigned long long)i0 * m0) << (c + 1)) & mask2d);  // omega_N = psi^(2D/N) = psi^(2^(c+1))
+            if (k <= 12) e1 = (e1 + i0) & mask2d;  // column part psi^i0 of the twist, merged (tile_fwd)
             w1f[idx] = pow_from_bits(pows, e1, k);
-            w1i[idx] = pow_from_bits(ipows, e1, k);
+            const u64 inv1 = pow_from_bits(ipows, e1, k);
+            w1i[idx] = k <= 12 ? G::mul(inv1, dinv) : inv1;
+            w1i_mul[idx] = k <= 12 ? G::mul(inv1, dinv_mul) : inv1;
         }
         if (idx < 256) {
             unsigned s = (unsigned)(idx >> 4), i0 = (unsigned)(idx & 15);
@@ -534,7 +548,7 @@ struct GlProfScope {
 inline bool gl_fast_supported(const GoldilocksFastTables &f) { return f.ready; }
 inline size_t gl_fast_extra_bytes(int k) {
     if (k < 8 || k > 22) return 0;  // D = 256 .. 2^22
-    return (((size_t)3 << k) + 2 * 4096 + 2 * 256) * sizeof(uint64_t);
+    return (((size_t)3 << k) + 3 * 4096 + 2 * 256) * sizeof(uint64_t);
 }
 // extra = device memory of gl_fast_extra_bytes(k) bytes, placed right behind [tw | itw] in the context's
 // twiddle block so that one broadcast ships everything.
@@ -551,6 +565,7 @@ inline int gl_fast_init(GoldilocksFastTables &f, int k, const uint64_t *tw, cons
     uint64_t *twist_im = p;           p += d;
     uint64_t *w1f = p;                p += 4096;
     uint64_t *w1i = p;                p += 4096;
+    uint64_t *w1im = p;               p += 4096;
     uint64_t *w2f = p;                p += 256;
     uint64_t *w2i = p;
     uint64_t *d_pows = nullptr;
@@ -560,11 +575,11 @@ inline int gl_fast_init(GoldilocksFastTables &f, int k, const uint64_t *tw, cons
     unsigned blocks = (unsigned)(((d > 4096 ? d : 4096) + 255) / 256);
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(gl::build_tables_kernel, dim3(blocks), dim3(256), 0, st, k, d_pows, d_pows + k + 1, dinv, dinv_mul,
-                       twist_f, twist_ip, twist_im, w1f, w1i, w2f, w2i);
+                       twist_f, twist_ip, twist_im, w1f, w1i, w1im, w2f, w2i);
     if (hipGetLastError() != hipSuccess) return 1;
     if (hipStreamSynchronize(st) != hipSuccess) return 1;
     (void)hipFree(d_pows);
-    f.t = gl::Tables{tw, itw, twist_f, twist_ip, twist_im, w1f, w1i, w2f, w2i};
+    f.t = gl::Tables{tw, itw, twist_f, twist_ip, twist_im, w1f, w1i, w1im, w2f, w2i};
     const char *env = getenv("SR_CHUNK_POLYS");
     f.chunk_polys = env ? (size_t)strtoull(env, nullptr, 10) : 0;
     env = getenv("SR_LANES");
@@ -678,10 +693,9 @@ inline int gl_launch_rows(const GoldilocksFastTables &f, uint64_t *a, const uint
     const size_t tiles = (n_total + gl::kTile - 1) / gl::kTile;
     if (tiles == 0 || tiles > 0x7FFFFFFFull) return 1;
     GlProfScope ps(f, 1, st);
-    const uint64_t *tw_i = fused ? f.t.twist_i_mul : f.t.twist_i_plain;
-    const unsigned dmask = (unsigned)(((size_t)1 << f.k) - 1);
+    const uint64_t *w1i = fused ? f.t.w1i_mul : f.t.w1i;
     dim3 g((unsigned)tiles), blk(256);
-#define SR_GL_ROWS(QQ, TT) hipLaunchKernelGGL((gl::rows_kernel<MODE, QQ, TT>), g, blk, 0, st, a, b, out, f.t, tw_i, n_total, dmask)
+#define SR_GL_ROWS(QQ, TT) hipLaunchKernelGGL((gl::rows_kernel<MODE, QQ, TT>), g, blk, 0, st, a, b, out, f.t, w1i, n_total)
     switch (f.k) {
         case 8: SR_GL_ROWS(4, true); break;
         case 9: SR_GL_ROWS(3, true); break;

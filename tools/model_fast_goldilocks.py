@@ -217,6 +217,11 @@ def dft16_inv_q(x, q):
     return x
 
 
+def twist_exp(q):
+    """psi^256 = 2^twist_exp(q) for D = 4096 >> q:  psi^(2D/64) = omega_64 = 2^39, so psi^256 = 2^(39 * 2^(q+1))"""
+    return (39 << (q + 1)) % 192
+
+
 def small_tables(k):
     q = 12 - k
     D = 1 << k
@@ -224,13 +229,13 @@ def small_tables(k):
     wD = pow(psi, 2, p)                      # omega_D: the cyclic size the stride-256 pass starts is D itself
     w256 = pow(psi, 2 * D // 256, p)
     T = {"q": q, "D": D}
-    T["twist_f"] = [pow(psi, i, p) for i in range(D)]
+    assert pow(psi, 256, p) == pow(2, twist_exp(q), p)
     inv = lambda v: pow(v, -1, p)
-    T["twist_i"] = [inv(v) * inv(D) % p for v in T["twist_f"]]
     m0 = lambda r: brv(r & ((1 << (4 - q)) - 1), 4 - q)
-    T["W1f"] = [[pow(wD, i0 * m0(r), p) for i0 in range(256)] for r in range(16)]
+    # the column part psi^t of the twist psi^(256 j' + t) commutes with the stride-256 sub-DFT: merged into W1
+    T["W1f"] = [[pow(wD, i0 * m0(r), p) * pow(psi, i0, p) % p for i0 in range(256)] for r in range(16)]
     T["W2f"] = [[pow(w256, i0 * brv(s, 4), p) for i0 in range(16)] for s in range(16)]
-    T["W1i"] = [[inv(v) for v in row] for row in T["W1f"]]
+    T["W1i"] = [[inv(v) * inv(D) % p for v in row] for row in T["W1f"]]   # carries psi^-t and D^-1
     T["W2i"] = [[inv(v) for v in row] for row in T["W2f"]]
     return T
 
@@ -238,9 +243,12 @@ def small_tables(k):
 def small_fwd(tile, T):
     """tile: 4096 coefficients = 2^q ring elements of degree D, element-major; returns their transforms"""
     q, D = T["q"], T["D"]
-    y = [v * T["twist_f"][pos & (D - 1)] % p for pos, v in enumerate(tile)]
+    y = list(tile)
+    E = twist_exp(q)
     for t in range(256):
-        x = dft16_fwd_q([y[j * 256 + t] for j in range(16)], q)
+        # row part of the twist: (psi^256)^j' = 2^(E j'), j' = row index inside the ring element: shifts
+        x = [y[j * 256 + t] * pow(2, (E * (j & ((16 >> q) - 1))) % 192, p) % p for j in range(16)]
+        x = dft16_fwd_q(x, q)
         for r in range(16):
             y[r * 256 + t] = x[r] * T["W1f"][r][t] % p
     for t in range(256):
@@ -265,9 +273,10 @@ def small_inv(tile, T):
             y[rho * 256 + j * 16 + i0] = x[j]
     for t in range(256):
         x = dft16_inv_q([y[r * 256 + t] * T["W1i"][r][t] % p for r in range(16)], q)
+        E = twist_exp(q)
         for j in range(16):
-            y[j * 256 + t] = x[j]
-    return [v * T["twist_i"][pos & (D - 1)] % p for pos, v in enumerate(y)]
+            y[j * 256 + t] = x[j] * pow(2, (192 - (E * (j & ((16 >> q) - 1))) % 192) % 192, p) % p
+    return y
 
 
 if __name__ == "__main__":
