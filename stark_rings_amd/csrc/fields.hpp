@@ -106,19 +106,53 @@ struct Goldilocks {
         return r >= P ? r - P : r;
     }
 #else
+#if defined(__HIP_DEVICE_COMPILE__)
+    // a - b for any u64 a and b < 2^32 (+ p on borrow).  The high word of b is an opaque zero register: with a literal 0 the
+    // combiner rewrites subcarry(x, 0, c) as x - zext(c) and spends a v_cndmask on materialising c.
+    static __device__ __forceinline__ uint64_t sub_small(uint64_t a, uint32_t b) {
+        uint32_t z = 0, c, br;
+        SR_OPAQUE(z);
+        uint32_t d0 = __builtin_subc((uint32_t)a, b, 0u, &c);
+        uint32_t d1 = __builtin_subc((uint32_t)(a >> 32), z, c, &br);
+        SR_OPAQUE(d1);
+        uint32_t m = 0u - br;
+        uint32_t e0 = __builtin_subc(d0, m, 0u, &c);
+        uint32_t e1 = __builtin_subc(d1, 0u, c, &c);
+        return (uint64_t)e0 | ((uint64_t)e1 << 32);
+    }
+    // canonical (l2 + hl * EPS) for l2 + hl * EPS < 2^64 + p.  v_mad_u64_u32 delivers the 65th bit as its carry-out, which C++
+    // cannot name (the compiler adds the product with v_lshl_add_u64 and recovers the carry with a 64-bit compare), so the
+    // multiply-add and the conditional + EPS are two small asm statements: 1 + 4 VALU instead of 3 + 4.  The s_nop covers the
+    // 2 wait states between a VALU write of an SGPR carry and the VALU read of it.
+    static __device__ __forceinline__ elem mad_eps_fix(uint64_t l2, uint32_t hl) {
+        uint64_t t, cy, tmp;
+        uint32_t r0, r1;
+        asm("v_mad_u64_u32 %0, %1, %2, -1, %3" : "=v"(t), "=s"(cy) : "v"(hl), "v"(l2));
+        const uint32_t t0 = (uint32_t)t, t1 = (uint32_t)(t >> 32);
+        asm("v_add_co_u32_e64 %0, %2, -1, %3\n\t"   // u = t + EPS = t - p (mod 2^64); carry <=> t >= p
+            "s_nop 1\n\t"
+            "v_addc_co_u32_e64 %1, %2, 0, %4, %2\n\t"
+            "s_or_b64 %2, %2, %5\n\t"               // or the multiply-add overflowed (then u < p)
+            "v_cndmask_b32_e64 %0, %3, %0, %2\n\t"
+            "v_cndmask_b32_e64 %1, %4, %1, %2"
+            : "=&v"(r0), "=&v"(r1), "=&s"(tmp)
+            : "v"(t0), "v"(t1), "s"(cy));
+        return (uint64_t)r0 | ((uint64_t)r1 << 32);
+    }
+    static __device__ __forceinline__ elem reduce128(uint64_t lo, uint64_t hi) {
+        return mad_eps_fix(sub_small(lo, (uint32_t)(hi >> 32)), (uint32_t)hi);
+    }
+#else
     SR_HD static elem reduce128(uint64_t lo, uint64_t hi) {
         uint32_t hh = (uint32_t)(hi >> 32), hl = (uint32_t)hi;
         uint64_t l2 = sub(lo, (uint64_t)hh);                      // any u64; borrow fixed by + p (never overflows: hh < 2^32)
         unsigned __int128 w = (unsigned __int128)l2 + (uint64_t)hl * EPS;
         uint64_t t = (uint64_t)w;
         bool c1 = (uint64_t)(w >> 64) != 0;                       // then t <= 2^64 - 2^33 and t + EPS < p
-        uint32_t c, c2, t0 = (uint32_t)t, t1 = (uint32_t)(t >> 32);
-        SR_OPAQUE(t1);
-        uint32_t u0 = __builtin_addc(t0, 0xFFFFFFFFu, 0u, &c);
-        uint32_t u1 = __builtin_addc(t1, 0u, c, &c2);             // c2 <=> t >= p (when c1 = 0)
-        bool fix = c1 | (c2 != 0);
-        return (uint64_t)(fix ? u0 : t0) | ((uint64_t)(fix ? u1 : t1) << 32);
+        if (c1 || t >= P) t += EPS;
+        return t;
     }
+#endif
 #endif
     SR_HD static elem mul(elem a, elem b) {
         unsigned __int128 x = (unsigned __int128)a * b;

@@ -174,6 +174,7 @@ struct Tables {
     const u64 *w1f, *w1i, *w1i_mul;          // [rho * 256 + i0] = omega_N^(+- i0 m0(rho)), N = min(D, 4096); for D <= 4096 they also carry
                                              // the column part psi^(+-i0) of the twist and (inverse) D^-1 (w1i_mul: times 2^-64)
     const u64 *w2f, *w2i;                    // [sigma * 16 + i0] = omega_256^(+- i0 brv4(sigma))
+    const u64 *wcf, *wci;                    // [h * 16 + rg] = theta^(+- (2 brv4(h) + 1) rg), theta = psi^(D/256)  (cols256_kernel)
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -348,7 +349,109 @@ __global__ __launch_bounds__(256, 4) void strided256_kernel(u64 *data, int k, in
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ int pad(int pos) { return pos + (pos >> 4); }
 
-// Forward transform of one tile; x[] returns positions 16 t .. 16 t + 15 of the result.
+// ------------------------------------------------------------------------------------------------
+// cols256: the first EIGHT merged stages of a whole ring element (s_lo = 0, D = 256 * N2, N2 >= 256) with shift-only
+// butterflies.  Same tile and exchange as strided256_kernel (256 legs of stride N2 x 16 consecutive columns), same
+// result bit for bit, about a third fewer VALU instructions:
+//   pass A  stages 0..3: their twiddles tw[2^u + b] = psi^brv_k(2^u + b) are 4th..32nd roots of unity, and
+//           psi^(D/32) = omega_64 = 2^39, so tw[i] = 2^(39 brv_5(i)) for i < 32: compile-time shifts.
+//   W layer block h (register slot) of the 16 blocks pass A leaves is a twisted-cyclic problem with root
+//           gamma'_h = psi^(2 brv_4(h) + 1); leg rg of it is multiplied by gamma'_h^(rg N2) = theta^((2 brv_4(h) + 1) rg)
+//           (theta = psi^(D/256) = 7^((p-1)/512) whatever D), the leg part of its twist, from a 256-entry table.
+//   pass B  cyclic DFT_16 over the legs of one block (shift-only radix-16, like the rows kernel), output bit-reversed:
+//           slot sigma is final block b = 16 h + sigma; its twist gamma_b^i (the rest of the twist times the four-step
+//           cross twiddle: the same table the 4096-point rows kernels use, N2 entries per block) is applied on the way out.
+// DIR 1 is the mirror image (unnormalised; D^-1 sits in the inverse twist table).  grid.x = npoly * N2 / 16.
+// tools/model_fast_goldilocks.py: cols256_fwd / cols256_inv.
+// ------------------------------------------------------------------------------------------------
+constexpr int brv5(int i) { return ((i & 1) << 4) | ((i & 2) << 2) | (i & 4) | ((i & 8) >> 2) | ((i & 16) >> 4); }
+constexpr int cols_tw_exp(int i) { return (39 * brv5(i)) % 192; }
+template <int U, int J>
+SR_HD void cols_bf_fwd(u64 *x) {
+    if constexpr ((J & (8 >> U)) == 0) bf_dit<cols_tw_exp((1 << U) + (J >> (4 - U)))>(x[J], x[J + (8 >> U)]);
+}
+template <int U, int J>
+SR_HD void cols_bf_inv(u64 *x) {
+    if constexpr ((J & (8 >> U)) == 0) bf_dif<(192 - cols_tw_exp((1 << U) + (J >> (4 - U)))) % 192>(x[J], x[J + (8 >> U)]);
+}
+template <int U, int... Js>
+SR_HD void cols_stage_fwd(u64 *x, std::integer_sequence<int, Js...>) {
+    (cols_bf_fwd<U, Js>(x), ...);
+}
+template <int U, int... Js>
+SR_HD void cols_stage_inv(u64 *x, std::integer_sequence<int, Js...>) {
+    (cols_bf_inv<U, Js>(x), ...);
+}
+
+template <int DIR>
+__global__ __launch_bounds__(256, 4) void cols256_kernel(u64 *data, int k, const u64 *__restrict__ wc,
+                                                         const u64 *__restrict__ twist) {
+    __shared__ u64 lds[kLdsElems];
+    const int t = threadIdx.x;
+    const int ls = k - 8;  // log2 N2
+    const unsigned ci = blockIdx.x & ((1u << (ls - 4)) - 1u);
+    const size_t poly = blockIdx.x >> (ls - 4);
+    const int col = t & 15, rg = t >> 4;
+    const unsigned i = ci * 16u + (unsigned)col;  // column = position inside a leg
+    // wave-uniform base + 32-bit byte offsets (a ring element is at most 8 MiB): one v_add_u32 per access
+    char *pb = reinterpret_cast<char *>(data + (poly << k));
+    const char *tb = reinterpret_cast<const char *>(twist);
+    const unsigned leg = 8u << ls;                                      // bytes between consecutive legs
+    const unsigned offA = (((unsigned)rg << ls) + i) * 8u;              // leg rg (+ 16 jj)
+    const unsigned offB = (((unsigned)rg << (ls + 4)) + i) * 8u;        // leg 16 rg (+ sigma) = final block b
+    const int base2 = rg * 256 + col;
+    using seq16 = std::make_integer_sequence<int, 16>;
+    u64 x[16];
+
+    if (DIR == 0) {
+#pragma unroll
+        for (int jj = 0; jj < 16; jj++) x[jj] = *reinterpret_cast<const u64 *>(pb + (offA + (unsigned)jj * 16u * leg));
+        cols_stage_fwd<0>(x, seq16{});
+        cols_stage_fwd<1>(x, seq16{});
+        cols_stage_fwd<2>(x, seq16{});
+        cols_stage_fwd<3>(x, seq16{});
+#pragma unroll
+        for (int h = 0; h < 16; h++) x[h] = G::mul(x[h], wc[h * 16 + rg]);
+#pragma unroll
+        for (int h = 0; h < 16; h++) lds[pad(h * 256 + t)] = x[h];  // leg 16 h + rg, column col
+        __syncthreads();
+        u64 tw[16];
+#pragma unroll
+        for (int sg = 0; sg < 16; sg++) tw[sg] = *reinterpret_cast<const u64 *>(tb + (offB + (unsigned)sg * leg));
+#pragma unroll
+        for (int j = 0; j < 16; j++) x[j] = lds[pad(base2 + j * 16)];  // block rg, leg j
+        dft16_fwd(x);
+#pragma unroll
+        for (int sg = 0; sg < 16; sg++)
+            *reinterpret_cast<u64 *>(pb + (offB + (unsigned)sg * leg)) = G::mul(x[sg], tw[sg]);
+    } else {
+        u64 tw[16];
+#pragma unroll
+        for (int sg = 0; sg < 16; sg++) {
+            x[sg] = *reinterpret_cast<const u64 *>(pb + (offB + (unsigned)sg * leg));
+            tw[sg] = *reinterpret_cast<const u64 *>(tb + (offB + (unsigned)sg * leg));
+        }
+#pragma unroll
+        for (int sg = 0; sg < 16; sg++) x[sg] = G::mul(x[sg], tw[sg]);
+        dft16_inv(x);
+#pragma unroll
+        for (int j = 0; j < 16; j++) lds[pad(base2 + j * 16)] = x[j];
+        __syncthreads();
+#pragma unroll
+        for (int h = 0; h < 16; h++) x[h] = lds[pad(h * 256 + t)];
+#pragma unroll
+        for (int h = 0; h < 16; h++) x[h] = G::mul(x[h], wc[h * 16 + rg]);
+        cols_stage_inv<3>(x, seq16{});
+        cols_stage_inv<2>(x, seq16{});
+        cols_stage_inv<1>(x, seq16{});
+        cols_stage_inv<0>(x, seq16{});
+#pragma unroll
+        for (int jj = 0; jj < 16; jj++) *reinterpret_cast<u64 *>(pb + (offA + (unsigned)jj * 16u * leg)) = x[jj];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// rows kernel (4096-coefficient tiles), continued: the tile transforms
 //   Q = 0, TW = false: D >= 8192, the tile is one 4096-block already twisted by the strided pass: cyclic DFT_4096.
 //   TW = true (D = 4096 >> Q <= 4096): the tile holds 2^Q whole ring elements; the stride-256 pass runs the last 4 - Q stages
 //   of the radix-16 only; the negacyclic twist psi^(256 row + t) is split into a compile-time shift per register slot
@@ -464,9 +567,75 @@ __global__ __launch_bounds__(256, TW ? SR_ROWS_WAVES_TW : SR_ROWS_WAVES) void ro
         tile_fwd<Q, TW>(b + base, lds, t, T, B, nvalid);
 #pragma unroll
         for (int j = 0; j < 16; j++) A[j] = G::mul(A[j], B[j]);
-        __syncthreads();
+        // no barrier: tile_inv first writes the lane's own slots 17 t + j, which only this lane has just read
     }
     tile_inv<Q, TW>(A, lds, t, T, w1i, out + base, nvalid);
+}
+
+// ------------------------------------------------------------------------------------------------
+// rows256: D = 2^16 behind cols256 -- a tile is 16 twisted blocks of 256 coefficients, each a cyclic DFT_256 = 16 x 16:
+// the last two register passes of the 4096-point kernel, one LDS exchange per transform.  Lane (rho, i0) works on block
+// rho; global accesses are 128-byte segments (16 lanes x 8 B).  MODE as rows_kernel.
+// tools/model_fast_goldilocks.py: rows256_fwd / rows256_inv.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void tile256_fwd(const u64 *__restrict__ src, u64 *lds, const int t, const Tables &T, u64 *x) {
+    const int i0 = t & 15, base2 = (t >> 4) * 256 + i0;
+#pragma unroll
+    for (int j = 0; j < 16; j++) x[j] = src[base2 + j * 16];
+    dft16_fwd(x);
+#pragma unroll
+    for (int s = 1; s < 16; s++) x[s] = G::mul(x[s], T.w2f[s * 16 + i0]);
+#pragma unroll
+    for (int s = 0; s < 16; s++) lds[pad(base2 + s * 16)] = x[s];
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 16; j++) x[j] = lds[17 * t + j];
+    dft16_fwd(x);
+}
+__device__ __forceinline__ void tile256_inv(u64 *x, u64 *lds, const int t, const Tables &T, u64 *__restrict__ dst) {
+    const int i0 = t & 15, base2 = (t >> 4) * 256 + i0;
+    dft16_inv(x);
+#pragma unroll
+    for (int j = 0; j < 16; j++) lds[17 * t + j] = x[j];
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < 16; s++) x[s] = lds[pad(base2 + s * 16)];
+#pragma unroll
+    for (int s = 1; s < 16; s++) x[s] = G::mul(x[s], T.w2i[s * 16 + i0]);
+    dft16_inv(x);
+#pragma unroll
+    for (int j = 0; j < 16; j++) dst[base2 + j * 16] = x[j];
+}
+template <int MODE>
+__global__ __launch_bounds__(256, 4) void rows256_kernel(u64 *a, const u64 *b, u64 *out, Tables T) {
+    __shared__ u64 lds[kLdsElems];
+    const int t = threadIdx.x;
+    const size_t base = (size_t)blockIdx.x * kTile;
+    u64 A[16];
+    if (MODE == 1) {
+        // the inverse starts from 16 consecutive slots per lane: lane-contiguous load, one exchange
+#pragma unroll
+        for (int j = 0; j < 16; j++) lds[pad(j * 256 + t)] = a[base + j * 256 + t];
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 16; j++) A[j] = lds[17 * t + j];  // own slots from here on: no barrier before tile256_inv's writes
+    } else {
+        tile256_fwd(a + base, lds, t, T, A);
+        if (MODE == 0) {
+#pragma unroll
+            for (int j = 0; j < 16; j++) lds[17 * t + j] = A[j];  // own slots
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < 16; j++) a[base + j * 256 + t] = lds[pad(j * 256 + t)];
+            return;
+        }
+        u64 B[16];
+        __syncthreads();  // every lane has read a's exchange before b's lands
+        tile256_fwd(b + base, lds, t, T, B);
+#pragma unroll
+        for (int j = 0; j < 16; j++) A[j] = G::mul(A[j], B[j]);
+    }
+    tile256_inv(A, lds, t, T, out + base);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -478,17 +647,17 @@ __device__ __forceinline__ u64 pow_from_bits(const u64 *pw, unsigned e, int k) {
         if ((e >> j) & 1u) acc = G::mul(acc, pw[j]);
     return acc;
 }
-__global__ void build_tables_kernel(int k, const u64 *pows, const u64 *ipows, u64 dinv, u64 dinv_mul, u64 *twist_f,
+// c = number of merged stages the column passes run = log2 of the number of twisted blocks (of N2 = D >> c coefficients)
+__global__ void build_tables_kernel(int k, int c, const u64 *pows, const u64 *ipows, u64 dinv, u64 dinv_mul, u64 *twist_f,
                                     u64 *twist_i_plain, u64 *twist_i_mul, u64 *w1f, u64 *w1i, u64 *w1i_mul, u64 *w2f,
-                                    u64 *w2i) {
-    const int c = k > 12 ? k - 12 : 0;   // strided stages
-    const int q = k < 12 ? 12 - k : 0;   // log2 of ring elements per tile
+                                    u64 *w2i, u64 *wcf, u64 *wci) {
+    const int q = 12 - (k - c);          // log2 of (ring elements | twisted blocks) per 4096-coefficient tile
     const size_t d = (size_t)1 << k;
     const size_t n = d > 4096 ? d : 4096;
     const unsigned mask2d = (unsigned)(2 * d - 1);
     for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < n; idx += (size_t)gridDim.x * blockDim.x) {
         if (idx < d) {
-            unsigned b = (unsigned)(idx >> 12), i = (unsigned)(idx & 4095);
+            unsigned b = (unsigned)(idx >> (k - c)), i = (unsigned)(idx & ((d >> c) - 1));
             unsigned e = (unsigned)(((unsigned long long)(2 * bitrev(b, c) + 1) * i) & mask2d);
             twist_f[idx] = pow_from_bits(pows, e, k);
             u64 inv = pow_from_bits(ipows, e, k);
@@ -496,8 +665,8 @@ __global__ void build_tables_kernel(int k, const u64 *pows, const u64 *ipows, u6
             twist_i_mul[idx] = G::mul(inv, dinv_mul);
         }
         if (idx < 4096) {
-            // omega_N^(i0 * m0), N = min(D, 4096) = the cyclic size the stride-256 pass starts; slot r of a lane belongs to
-            // ring element r >> (4 - q) of the tile and carries output index brv_(4-q)(r mod 2^(4-q)) of its sub-DFT
+            // omega_N^(i0 * m0), N = D >> c = the cyclic size the stride-256 pass starts; slot r of a lane belongs to
+            // ring element (block) r >> (4 - q) of the tile and carries output index brv_(4-q)(r mod 2^(4-q)) of its sub-DFT
             unsigned r = (unsigned)(idx >> 8), i0 = (unsigned)(idx & 255);
             unsigned m0 = bitrev(r & ((1u << (4 - q)) - 1u), 4 - q);
             unsigned e1 = (unsigned)((((unsigned long long)i0 * m0) << (c + 1)) & mask2d);  // omega_N = psi^(2D/N) = psi^(2^(c+1))
@@ -512,6 +681,10 @@ __global__ void build_tables_kernel(int k, const u64 *pows, const u64 *ipows, u6
             unsigned e2 = (unsigned)((((unsigned long long)i0 * bitrev(s, 4)) << (k - 7)) & mask2d);  // omega_256 = psi^(2D/256)
             w2f[idx] = pow_from_bits(pows, e2, k);
             w2i[idx] = pow_from_bits(ipows, e2, k);
+            // cols256 W layer: theta^((2 brv4(h) + 1) rg), theta = psi^(D/256)
+            unsigned e3 = (unsigned)((((unsigned long long)(2 * bitrev(s, 4) + 1) * i0) << (k - 8)) & mask2d);
+            wcf[idx] = pow_from_bits(pows, e3, k);
+            wci[idx] = pow_from_bits(ipows, e3, k);
         }
     }
 }
@@ -521,6 +694,8 @@ __global__ void build_tables_kernel(int k, const u64 *pows, const u64 *ipows, u6
 // ---- host side ------------------------------------------------------------------------------------
 struct GoldilocksFastTables {
     int k = -1;
+    int c = 0;               // merged stages run by the column passes; the rows kernels see blocks of D >> c coefficients
+    bool cols256 = false;    // c == 8 in one cols256 launch (2^16 <= D <= 2^20)
     bool ready = false;
     gl::Tables t{};
     size_t chunk_polys = 0;  // 0 = whole batch per launch
@@ -548,7 +723,7 @@ struct GlProfScope {
 inline bool gl_fast_supported(const GoldilocksFastTables &f) { return f.ready; }
 inline size_t gl_fast_extra_bytes(int k) {
     if (k < 8 || k > 22) return 0;  // D = 256 .. 2^22
-    return (((size_t)3 << k) + 3 * 4096 + 2 * 256) * sizeof(uint64_t);
+    return (((size_t)3 << k) + 3 * 4096 + 4 * 256) * sizeof(uint64_t);
 }
 // extra = device memory of gl_fast_extra_bytes(k) bytes, placed right behind [tw | itw] in the context's
 // twiddle block so that one broadcast ships everything.
@@ -567,19 +742,26 @@ inline int gl_fast_init(GoldilocksFastTables &f, int k, const uint64_t *tw, cons
     uint64_t *w1i = p;                p += 4096;
     uint64_t *w1im = p;               p += 4096;
     uint64_t *w2f = p;                p += 256;
-    uint64_t *w2i = p;
+    uint64_t *w2i = p;                p += 256;
+    uint64_t *wcf = p;                p += 256;
+    uint64_t *wci = p;
+    // plan: 2^16 <= D <= 2^20 runs all its column stages (8) in one shift-only cols256 launch and leaves D / 256-point
+    // rows; otherwise the rows are 4096 points (or whole ring elements, D <= 4096).  SR_GL_COLS256=0: the older plan.
+    const char *env256 = getenv("SR_GL_COLS256");
+    f.cols256 = k >= 16 && k <= 20 && !(env256 && atoi(env256) == 0);
+    f.c = f.cols256 ? 8 : (k > 12 ? k - 12 : 0);
     uint64_t *d_pows = nullptr;
     if (hipMalloc(&d_pows, 2 * (k + 1) * sizeof(uint64_t)) != hipSuccess) return 1;
     if (hipMemcpy(d_pows, host_pows, (k + 1) * 8, hipMemcpyHostToDevice) != hipSuccess) return 1;
     if (hipMemcpy(d_pows + k + 1, host_ipows, (k + 1) * 8, hipMemcpyHostToDevice) != hipSuccess) return 1;
     unsigned blocks = (unsigned)(((d > 4096 ? d : 4096) + 255) / 256);
     if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(gl::build_tables_kernel, dim3(blocks), dim3(256), 0, st, k, d_pows, d_pows + k + 1, dinv, dinv_mul,
-                       twist_f, twist_ip, twist_im, w1f, w1i, w1im, w2f, w2i);
+    hipLaunchKernelGGL(gl::build_tables_kernel, dim3(blocks), dim3(256), 0, st, k, f.c, d_pows, d_pows + k + 1, dinv, dinv_mul,
+                       twist_f, twist_ip, twist_im, w1f, w1i, w1im, w2f, w2i, wcf, wci);
     if (hipGetLastError() != hipSuccess) return 1;
     if (hipStreamSynchronize(st) != hipSuccess) return 1;
     (void)hipFree(d_pows);
-    f.t = gl::Tables{tw, itw, twist_f, twist_ip, twist_im, w1f, w1i, w1im, w2f, w2i};
+    f.t = gl::Tables{tw, itw, twist_f, twist_ip, twist_im, w1f, w1i, w1im, w2f, w2i, wcf, wci};
     const char *env = getenv("SR_CHUNK_POLYS");
     f.chunk_polys = env ? (size_t)strtoull(env, nullptr, 10) : 0;
     env = getenv("SR_LANES");
@@ -649,7 +831,17 @@ inline int gl_plan(int c, int *ms) {
     if (big) ms[n++] = 8;
     return n;  // 0 passes for D <= 4096: the rows kernel applies the twist itself
 }
+template <int DIR>
+inline int gl_launch_cols256(const GoldilocksFastTables &f, uint64_t *data, size_t npoly, const uint64_t *wc,
+                             const uint64_t *twist, hipStream_t st) {
+    GlProfScope ps(f, DIR == 0 ? 0 : 2, st);
+    const size_t blocks = npoly << (f.k - 12);  // N2 / 16 per ring element
+    if (blocks == 0 || blocks > 0x7FFFFFFFull) return 1;
+    hipLaunchKernelGGL((gl::cols256_kernel<DIR>), dim3((unsigned)blocks), dim3(256), 0, st, data, f.k, wc, twist);
+    return hipGetLastError() != hipSuccess;
+}
 inline int gl_strided_fwd(const GoldilocksFastTables &f, uint64_t *d, size_t npoly, hipStream_t st) {
+    if (f.cols256) return gl_launch_cols256<0>(f, d, npoly, f.t.wcf, f.t.twist_f, st);
     int ms[8];
     const int n = gl_plan(f.k > 12 ? f.k - 12 : 0, ms);
     int s_lo = 0;
@@ -668,10 +860,11 @@ inline int gl_strided_fwd(const GoldilocksFastTables &f, uint64_t *d, size_t npo
     return 0;
 }
 inline int gl_strided_inv(const GoldilocksFastTables &f, uint64_t *d, size_t npoly, bool fused, hipStream_t st) {
+    const uint64_t *tw_i = fused ? f.t.twist_i_mul : f.t.twist_i_plain;
+    if (f.cols256) return gl_launch_cols256<1>(f, d, npoly, f.t.wci, tw_i, st);
     int ms[8];
     const int n = gl_plan(f.k > 12 ? f.k - 12 : 0, ms);
     int s_lo = f.k > 12 ? f.k - 12 : 0;
-    const uint64_t *tw_i = fused ? f.t.twist_i_mul : f.t.twist_i_plain;
     for (int p = n - 1; p >= 0; p--) {
         s_lo -= ms[p];
         const bool first = p == n - 1;
@@ -696,13 +889,16 @@ inline int gl_launch_rows(const GoldilocksFastTables &f, uint64_t *a, const uint
     const uint64_t *w1i = fused ? f.t.w1i_mul : f.t.w1i;
     dim3 g((unsigned)tiles), blk(256);
 #define SR_GL_ROWS(QQ, TT) hipLaunchKernelGGL((gl::rows_kernel<MODE, QQ, TT>), g, blk, 0, st, a, b, out, f.t, w1i, n_total)
-    switch (f.k) {
-        case 8: SR_GL_ROWS(4, true); break;
-        case 9: SR_GL_ROWS(3, true); break;
-        case 10: SR_GL_ROWS(2, true); break;
-        case 11: SR_GL_ROWS(1, true); break;
-        case 12: SR_GL_ROWS(0, true); break;
-        default: SR_GL_ROWS(0, false); break;
+    const bool tw = f.c == 0;  // whole ring elements per tile: the rows kernel applies the twist itself
+    switch (f.k - f.c) {       // log2 of the cyclic size
+        case 8:
+            if (tw) SR_GL_ROWS(4, true);
+            else hipLaunchKernelGGL((gl::rows256_kernel<MODE>), g, blk, 0, st, a, b, out, f.t);
+            break;
+        case 9: if (tw) SR_GL_ROWS(3, true); else SR_GL_ROWS(3, false); break;
+        case 10: if (tw) SR_GL_ROWS(2, true); else SR_GL_ROWS(2, false); break;
+        case 11: if (tw) SR_GL_ROWS(1, true); else SR_GL_ROWS(1, false); break;
+        default: if (tw) SR_GL_ROWS(0, true); else SR_GL_ROWS(0, false); break;
     }
 #undef SR_GL_ROWS
     return hipGetLastError() != hipSuccess;

@@ -279,6 +279,129 @@ def small_inv(tile, T):
     return y
 
 
+# ---------------------------------------------------------------- D = 256 * N2, N2 >= 256: one 8-stage column pass (cols256)
+THETA_EXP_NOTE = "theta = psi^(D/256) = 7^((p-1)/512) does not depend on D"
+
+
+def cols_tables(k):
+    """tables of the 8-stage column pass and the twist it leaves for N2-point cyclic rows, D = 256 * N2"""
+    D = 1 << k
+    N2 = D >> 8
+    psi = P.psi("goldilocks", k)
+    theta = pow(psi, N2, p)
+    assert theta == pow(7, (p - 1) // 512, p)
+    inv = lambda v: pow(v, -1, p)
+    T = {"k": k, "N2": N2}
+    T["tw"] = [pow(psi, brv(i, k), p) for i in range(32)]          # stages 0..3 only: 4th .. 32nd roots of unity = shifts
+    T["tw_exp"] = []
+    for v in T["tw"]:
+        e = [e for e in range(192) if pow(2, e, p) == v]
+        T["tw_exp"].append(e[0] if e else None)
+    assert all(e is not None for e in T["tw_exp"][1:16])           # index 2^u + b, u < 4: every one a power of two
+    # W layer between the two register passes: block h (after 4 stages), leg rg: gamma'_h^(rg N2), gamma'_h = psi^(2 brv4(h) + 1)
+    T["Wcf"] = [[pow(theta, (2 * brv(h, 4) + 1) * rg, p) for rg in range(16)] for h in range(16)]
+    T["Wci"] = [[inv(v) for v in row] for row in T["Wcf"]]
+    T["twist_f"] = [[pow(psi, (2 * brv(b, 8) + 1) * i, p) for i in range(N2)] for b in range(256)]
+    T["twist_i"] = [[inv(v) * inv(D) % p for v in row] for row in T["twist_f"]]   # carries D^-1: every network is unnormalised
+    w256 = pow(psi, 2 * D // 256, p)
+    T["W2f"] = [[pow(w256, i0 * brv(s_, 4), p) for i0 in range(16)] for s_ in range(16)]
+    T["W2i"] = [[inv(v) for v in row] for row in T["W2f"]]
+    return T
+
+
+def cols256_fwd(a, T):
+    k, N2 = T["k"], T["N2"]
+    a = list(a)
+    for i2 in range(N2):
+        col = [a[i1 * N2 + i2] for i1 in range(256)]
+        # pass A: lane rg holds legs rg + 16 jj; stages 0..3 of the merged negacyclic network, twiddles = compile-time shifts
+        for rg in range(16):
+            x = [col[rg + 16 * jj] for jj in range(16)]
+            for u in range(4):
+                half = 8 >> u
+                for jj in range(16):
+                    if jj & half:
+                        continue
+                    e = T["tw_exp"][(1 << u) + (jj >> (4 - u))]
+                    t = x[jj + half] * pow(2, e, p) % p
+                    x[jj], x[jj + half] = (x[jj] + t) % p, (x[jj] - t) % p
+            for h in range(16):
+                col[rg + 16 * h] = x[h] * T["Wcf"][h][rg] % p      # block h, leg rg: position 16 h + rg ("s*16 + rg")
+        # pass B: lane rg' = block h holds its 16 legs: cyclic DFT_16, bit-reversed out; then the twist of final block b = 16 h + sigma
+        for h in range(16):
+            x = dft16_fwd([col[16 * h + rg] for rg in range(16)])
+            for sg in range(16):
+                b = 16 * h + sg
+                a[b * N2 + i2] = x[sg] * T["twist_f"][b][i2] % p
+    return a
+
+
+def cols256_inv(a, T):
+    k, N2 = T["k"], T["N2"]
+    a = list(a)
+    for i2 in range(N2):
+        col = [0] * 256
+        for h in range(16):
+            x = dft16_inv([a[(16 * h + sg) * N2 + i2] * T["twist_i"][16 * h + sg][i2] % p for sg in range(16)])
+            for rg in range(16):
+                col[16 * h + rg] = x[rg]
+        for rg in range(16):
+            x = [col[rg + 16 * h] * T["Wci"][h][rg] % p for h in range(16)]
+            for u in range(3, -1, -1):
+                half = 8 >> u
+                for jj in range(16):
+                    if jj & half:
+                        continue
+                    e = (192 - T["tw_exp"][(1 << u) + (jj >> (4 - u))]) % 192
+                    s_, d = (x[jj] + x[jj + half]) % p, (x[jj] - x[jj + half]) * pow(2, e, p) % p
+                    x[jj], x[jj + half] = s_, d
+            for jj in range(16):
+                a[(rg + 16 * jj) * N2 + i2] = x[jj]
+    return a
+
+
+def rows256_fwd(row, T):
+    """cyclic DFT_256, natural in, bit-reversed out: passes 2 and 3 of rows_fwd"""
+    y = list(row)
+    for i0 in range(16):
+        x = dft16_fwd([y[j * 16 + i0] for j in range(16)])
+        for s_ in range(16):
+            y[s_ * 16 + i0] = x[s_] * T["W2f"][s_][i0] % p
+    for t in range(16):
+        y[16 * t:16 * t + 16] = dft16_fwd(y[16 * t:16 * t + 16])
+    return y
+
+
+def rows256_inv(row, T):
+    y = list(row)
+    for t in range(16):
+        y[16 * t:16 * t + 16] = dft16_inv(y[16 * t:16 * t + 16])
+    for i0 in range(16):
+        x = dft16_inv([y[s_ * 16 + i0] * T["W2i"][s_][i0] % p for s_ in range(16)])
+        for j in range(16):
+            y[j * 16 + i0] = x[j]
+    return y
+
+
+def check_cols256(k=16, seed=5):
+    rng = random.Random(seed)
+    T = cols_tables(k)
+    D, N2 = 1 << k, T["N2"]
+    a = [rng.randrange(p) for _ in range(D)]
+    want = P.pow2_fwd("goldilocks", a, k)
+    mid = cols256_fwd(a, T)
+    assert N2 == 256
+    got = []
+    for b in range(256):
+        got += rows256_fwd(mid[b * 256:(b + 1) * 256], T)
+    assert got == want, "cols256 forward mismatch"
+    back = []
+    for b in range(256):
+        back += rows256_inv(got[b * 256:(b + 1) * 256], T)
+    assert cols256_inv(back, T) == a, "cols256 inverse mismatch"
+    return True
+
+
 if __name__ == "__main__":
     rng = random.Random(3)
     # radix-16 networks
@@ -314,4 +437,6 @@ if __name__ == "__main__":
             assert got[e * D:(e + 1) * D] == P.pow2_fwd("goldilocks", tile[e * D:(e + 1) * D], k), "small fwd k=%d" % k
         assert small_inv(got, T) == tile
         print("small k=%d ok" % k)
+    check_cols256(16)
+    print("cols256 + rows256 k=16 ok")
     print("model OK")
