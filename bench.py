@@ -157,6 +157,28 @@ def main():
     prof = ring.profile_read()
     ring.profile_enable(False)
 
+    # ---- achievable streaming bandwidth on this box (SURVEY.md 8d asks for the fraction against it as well as against the
+    #      8 TB/s spec): a plain device-to-device copy of one operand, read + write counted ----
+    copy_gbs = copy_kind = None
+    if rank == 0:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+
+        def stream_rate(fn, nbytes):
+            fn()
+            torch.cuda.synchronize()
+            ev0.record()
+            for _ in range(4):
+                fn()
+            ev1.record()
+            torch.cuda.synchronize()
+            return 4 * nbytes / (ev0.elapsed_time(ev1) * 1e-3) / 1e9
+
+        nb = a.numel() * 8
+        rates = {"hipMemcpy device-to-device (1 read + 1 write stream)": stream_rate(lambda: b.copy_(a), 2 * nb),
+                 "element-wise ring add a += b (2 read + 1 write streams)": stream_rate(lambda: ring.add_dev(b, a), 3 * nb)}
+        copy_kind = max(rates, key=rates.get)
+        copy_gbs = rates[copy_kind]
+
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
@@ -221,6 +243,8 @@ def main():
                    "parallelism": "batch-sharded x%d, twiddle broadcast only" % world},
         "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic,
+                     "copy_measured": copy_gbs, "copy_measured_kind": copy_kind,
+                     "frac_of_copy_measured": achieved_gbs / copy_gbs if copy_gbs else None,
                      "kernel": dom_tag, "kernel_avg_ms": dom_avg_ms, "launches_per_step": launches_per_step,
                      "algorithmic_bytes_per_ring_mul": bytes_per_mul,
                      "whole_step_achieved_per_gpu": step_gbs, "whole_step_frac": step_gbs / HBM_PEAK_GBS,
@@ -265,6 +289,14 @@ def main():
             "single_thread_value": n1 / cpu_t1,
         }
         out["gpu_over_cpu"] = value / (n / cpu_t)
+        # what `RqPoly * RqPoly` really runs in the reference (coeff_form.rs:54-67): O(D^2) schoolbook + reduce, one thread,
+        # timed on one element at D' = min(D, 4096) and scaled by (D / D')^2 -- reported separately, never the headline
+        ds = min(d, 4096)
+        t1 = time.perf_counter()
+        O.schoolbook(F, ea[:ds * O.LIMBS[F]], eb[:ds * O.LIMBS[F]], ds)
+        sb = time.perf_counter() - t1
+        out["cpu_baseline"]["schoolbook"] = {"degree": ds, "seconds_per_product": sb,
+                                             "ring_muls_per_s_scaled_to_workload_degree": 1.0 / (sb * (d / ds) ** 2)}
     print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

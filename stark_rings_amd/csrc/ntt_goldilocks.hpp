@@ -47,7 +47,11 @@ SR_HD u64 mul_pow2(u64 x) {
     const u64 xs = x << r;                                  // low 64 bits of x * 2^r
     const u32 y2 = r ? (u32)(x >> (64 - r)) : 0u;           // bits 64.. of x * 2^r
     if constexpr (q == 0) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        return G::mad_eps_fix(xs, y2);  // xs + y2 * EPS: nothing to subtract (reduce128 with a zero top word)
+#else
         return G::reduce128(xs, (u64)y2);
+#endif
     } else if constexpr (q == 1) {
         return G::reduce128(xs << 32, (xs >> 32) | ((u64)y2 << 32));
     } else {

@@ -232,11 +232,12 @@ def test_small_rings_match_oracle(torch_cuda, name):
 
 
 # ----------------------------------------------------------------------------- tuned Goldilocks path
-@pytest.mark.parametrize("k,batch", [(8, 21), (9, 13), (10, 5), (11, 3), (12, 7), (14, 3), (15, 2), (17, 2), (18, 1), (20, 1)])
+@pytest.mark.parametrize("k,batch", [(8, 21), (9, 13), (10, 5), (11, 3), (12, 7), (14, 3), (15, 2), (16, 3), (17, 2), (18, 1), (19, 1),
+                                      (20, 1)])
 def test_goldilocks_tuned_path_all_plans(torch_cuda, k, batch):
     """Every plan of the tuned path: 256 <= D <= 4096 (several ring elements per tile, ragged last tile, twist inside the
-    rows kernel) and D = 2^c * 4096 (one or two strided register passes, the 256-leg pass), vs the oracle and vs the
-    generic kernels (SR_GOLDILOCKS_GENERIC=1 routes the same ring through them)."""
+    rows kernel), D = 2^13..2^15 (strided register passes + 4096-point rows) and 2^16 <= D <= 2^20 (the shift-only 8-stage
+    column pass + 256..4096-point rows), vs the oracle and vs the generic kernels (SR_GOLDILOCKS_GENERIC=1 routes the same ring through them)."""
     import os
 
     from stark_rings_amd import CyclotomicRing
@@ -258,6 +259,32 @@ def test_goldilocks_tuned_path_all_plans(torch_cuda, k, batch):
     assert np.array_equal(generic.elementwise_crt(a.copy()), fa)
     assert np.array_equal(generic.mul(a, b), want)
     generic.close()
+
+
+@pytest.mark.parametrize("k,batch", [(16, 3), (17, 2), (20, 1)])
+def test_goldilocks_older_plan_equals_cols256_plan(torch_cuda, k, batch):
+    """SR_GL_COLS256=0 selects the plan these sizes ran before the shift-only column pass existed (register strided
+    passes / the general-twiddle 256-leg pass + 4096-point rows): same bytes out."""
+    import os
+
+    from stark_rings_amd import CyclotomicRing
+
+    F = O.GOLDILOCKS
+    a = edge_and_random(F, k, batch, 0xE0 + k)
+    b = O.fill_uniform(F, 0xF0 + k, 0, batch << k)
+    ring = ring_for("goldilocks", k)
+    os.environ["SR_GL_COLS256"] = "0"
+    try:
+        older = CyclotomicRing("goldilocks", k, device=0)
+    finally:
+        del os.environ["SR_GL_COLS256"]
+    fa = ring.elementwise_crt(a.copy())
+    assert np.array_equal(older.elementwise_crt(a.copy()), fa)
+    assert np.array_equal(older.elementwise_icrt(fa.copy()), a)
+    want = O.pow2_ring_mul(F, a, b, k, batch, 4)
+    assert np.array_equal(ring.mul(a, b), want)
+    assert np.array_equal(older.mul(a, b), want)
+    older.close()
 
 
 def test_goldilocks_chunked_launches_equal_single_launch(torch_cuda):

@@ -49,3 +49,9 @@ def test_small_degree_mode_equals_reference_transform():
         for e in range(4096 // D):
             assert got[e * D:(e + 1) * D] == P.pow2_fwd("goldilocks", tile[e * D:(e + 1) * D], k)
         assert M.small_inv(got, T) == tile
+
+
+def test_cols256_plus_rows256_equals_reference_transform():
+    """D = 2^16 = 256 x 256: shift-only 8-stage column pass (compile-time twiddles 2^(39 brv5(i)), theta W layer, cyclic DFT_16,
+    block twist) followed by 256-point cyclic rows."""
+    assert M.check_cols256(16, seed=6)

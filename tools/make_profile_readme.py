@@ -15,16 +15,34 @@ out.append("    rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_o
 out.append("    rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/prof/pmc_fetch -o r1 -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline")
 out.append("    rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/prof/pmc_write -o r1 -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline\n")
 out.append("## kernel_stats (%s)\n" % stats)
-out.append("| kernel | calls | avg ms | share of GPU time |\n|---|---|---|---|")
+# kernel_stats averages over every call, including the tiny launches of bench.py's property gate: the last column is the
+# average over the full-batch launches alone, from the kernel trace of the same run
+trace = collections.defaultdict(list)
+tpath = os.path.join(d, stats.replace("kernel_stats", "kernel_trace"))
+if os.path.exists(tpath):
+    for r in csv.DictReader(open(tpath)):
+        trace[r["Kernel_Name"]].append((int(r["Grid_Size_X"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
+out.append("| kernel | calls | avg ms (all calls) | share of GPU time | full-batch launches | avg ms (full-batch) |\n|---|---|---|---|---|---|")
 for r in csv.DictReader(open(os.path.join(d, stats))):
     if "sr::" in r["Name"] and "build" not in r["Name"]:
-        out.append("| `%s` | %s | %.3f | %s %% |" % (r["Name"].split("(")[0].replace("void ", ""), r["Calls"],
-                                                    float(r["AverageNs"]) / 1e6, r["Percentage"]))
+        tr = trace.get(r["Name"], [])
+        g = max([x[0] for x in tr], default=0)
+        fl = [x[1] for x in tr if x[0] == g]
+        out.append("| `%s` | %s | %.3f | %s %% | %d | %.3f |" % (r["Name"].split("(")[0].replace("void ", ""), r["Calls"],
+                                                             float(r["AverageNs"]) / 1e6, r["Percentage"], len(fl),
+                                                             sum(fl) / max(1, len(fl)) / 1e6))
 agg = {}
 for name, cn in (("pmc_FETCH_SIZE", "FETCH_SIZE"), ("pmc_WRITE_SIZE", "WRITE_SIZE")):
     dd = collections.defaultdict(list)
-    for r in csv.DictReader(open(os.path.join(d, name + ".csv"))):
-        dd[r["Kernel_Name"].split("(")[0].replace("void ", "")].append(float(r["Counter_Value"]))
+    rows = list(csv.DictReader(open(os.path.join(d, name + ".csv"))))
+    full = collections.defaultdict(int)  # only the full-batch launches count (bench.py's property gate also runs tiny ones)
+    for r in rows:
+        kn = r["Kernel_Name"].split("(")[0].replace("void ", "")
+        full[kn] = max(full[kn], int(r["Grid_Size"]))
+    for r in rows:
+        kn = r["Kernel_Name"].split("(")[0].replace("void ", "")
+        if int(r["Grid_Size"]) == full[kn]:
+            dd[kn].append(float(r["Counter_Value"]))
     agg[cn] = {k: sum(v) / len(v) for k, v in dd.items()}
 out.append("\n## HBM traffic per launch (PMC counters; the CSVs are in KiB)\n")
 out.append("FETCH_SIZE is doubled, as MI355X_MICROARCH.md (HBM section) prescribes for gfx950 streaming reads; the calibration")
@@ -37,17 +55,17 @@ total = 0.0
 for k in sorted(agg["FETCH_SIZE"]):
     if "sr::gl::" not in k or "build" in k:
         continue
-    per_step = 2 if "strided_kernel" in k and ", 0, " in k else 1
+    per_step = 2 if "cols256_kernel<0>" in k else 1
     f, w = 2 * agg["FETCH_SIZE"][k] / 2**20, agg["WRITE_SIZE"].get(k, 0) / 2**20
     total += per_step * (f + w)
     out.append("| `%s` | %d | %.2f | %.2f |" % (k, per_step, f, w))
 out.append("\nWhole step: %.1f GiB of HBM traffic for 16384 ring-muls = %.2f MB per ring-mul = %.2fx the algorithmic 3*D*8 = 1 572 864 B."
            % (total, total * 2**30 / 16384 / 1e6, total * 2**30 / 16384 / 1572864))
-out.append("Algorithmic bytes: rows kernel 24 GiB per launch (read a, read b, write c); each strided launch 16 GiB (read + write one operand).\n")
+out.append("Algorithmic bytes: rows256 kernel 24 GiB per launch (read a, read b, write c); each cols256 launch 16 GiB (read + write one operand).\n")
 import json
-tags = {"rows": [k for k in agg["FETCH_SIZE"] if "gl::rows_kernel<2>" in k],
-        "fwd_cols": [k for k in agg["FETCH_SIZE"] if "strided_kernel" in k and ", 0, " in k],
-        "inv_cols": [k for k in agg["FETCH_SIZE"] if "strided_kernel" in k and ", 1, " in k]}
+tags = {"rows": [k for k in agg["FETCH_SIZE"] if "gl::rows256_kernel<2>" in k],
+        "fwd_cols": [k for k in agg["FETCH_SIZE"] if "cols256_kernel<0>" in k],
+        "inv_cols": [k for k in agg["FETCH_SIZE"] if "cols256_kernel<1>" in k]}
 tj = {"workload": "goldilocks_d65536_b16384", "batch": 16384, "unit": "bytes of HBM traffic per launch (2*FETCH_SIZE + WRITE_SIZE)",
       "bytes_per_launch": {t: int(sum(2 * agg["FETCH_SIZE"][k] + agg["WRITE_SIZE"].get(k, 0) for k in ks) * 1024 / max(1, len(ks)))
                            for t, ks in tags.items() if ks}}
@@ -56,8 +74,15 @@ json.dump(tj, open(os.path.join(d, "traffic.json"), "w"), indent=1)
 sq_path = os.path.join(d, "pmc_SQ_counters.csv")
 if os.path.exists(sq_path):
     dd = collections.defaultdict(lambda: collections.defaultdict(list))
-    for r in csv.DictReader(open(sq_path)):
-        dd[r["Kernel_Name"].split("(")[0].replace("void ", "")][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    rows = list(csv.DictReader(open(sq_path)))
+    full = collections.defaultdict(int)
+    for r in rows:
+        kn = r["Kernel_Name"].split("(")[0].replace("void ", "")
+        full[kn] = max(full[kn], int(r["Grid_Size"]))
+    for r in rows:
+        kn = r["Kernel_Name"].split("(")[0].replace("void ", "")
+        if int(r["Grid_Size"]) == full[kn]:
+            dd[kn][r["Counter_Name"]].append(float(r["Counter_Value"]))
     vj = {"workload": "goldilocks_d65536_b16384", "batch": 16384,
           "note": "SQ_INSTS_VALU / SQ_WAVES per dispatch (rocprofv3 --pmc, own pass); waves per launch = SQ_WAVES",
           "kernels": {}}
