@@ -103,6 +103,22 @@ int sr_sub_batch_dev(sr_ctx *ctx, uint64_t *d_lhs_inout, const uint64_t *d_rhs, 
  * crates/linear_algebra/src/matrix.rs:168-178 -- as one fused multiply-accumulate pass over M.  Power-of-two
  * (fully split) rings only; d_y must not alias d_m or d_v. */
 int sr_matvec_ntt_dev(sr_ctx *ctx, uint64_t *d_y, const uint64_t *d_m, const uint64_t *d_v, size_t nrows, size_t ncols, void *stream);
+/* y = S * v for a sparse nrows x ncols matrix in CSR form: d_vals[j] one ring element (CRT/NTT form), d_cols[j] its column,
+ * d_row_ptr[r] .. d_row_ptr[r+1] the stored entries of row r -- SparseMatrix<RqNTT>::checked_mul_vec,
+ * crates/linear_algebra/src/sparse_matrix.rs:201-211 (its Vec<Vec<(R, usize)>> rows, flattened; an empty row gives zero).
+ * An entry with column >= ncols (the reference panics on v[col]) is skipped and counted; sr_spmv_bad_index_count reads
+ * and clears that count (synchronises the stream).  The host-pointer form validates the indices and returns SR_E_INVALID. */
+int sr_spmv_ntt_dev(sr_ctx *ctx, uint64_t *d_y, const uint64_t *d_vals, const uint32_t *d_cols, const uint64_t *d_row_ptr,
+                    const uint64_t *d_v, size_t nrows, size_t ncols, void *stream);
+int sr_spmv_bad_index_count(sr_ctx *ctx, unsigned long long *out, void *stream);
+/* Y (n x p) = A (n x m) * B (m x p), dense row-major, CRT/NTT form -- Matrix<RqNTT>::checked_mul_mat,
+ * crates/linear_algebra/src/matrix.rs:148-166.  d_y must not alias d_a or d_b. */
+int sr_matmul_ntt_dev(sr_ctx *ctx, uint64_t *d_y, const uint64_t *d_a, const uint64_t *d_b, size_t n, size_t m, size_t p, void *stream);
+/* Host-pointer forms of the three linear-algebra entry points (temporaries allocated per call). */
+int sr_matvec_ntt(sr_ctx *ctx, uint64_t *y, const uint64_t *m, const uint64_t *v, size_t nrows, size_t ncols);
+int sr_spmv_ntt(sr_ctx *ctx, uint64_t *y, const uint64_t *vals, const uint32_t *cols, const uint64_t *row_ptr, const uint64_t *v,
+                size_t nrows, size_t ncols);
+int sr_matmul_ntt(sr_ctx *ctx, uint64_t *y, const uint64_t *a, const uint64_t *b, size_t n, size_t m, size_t p);
 /* d_b is used as scratch and holds crt(b) afterwards when D exceeds one LDS tile; d_out may alias d_a. */
 int sr_ring_mul_batch_dev(sr_ctx *ctx, uint64_t *d_out, const uint64_t *d_a, uint64_t *d_b, size_t batch, void *stream);
 int sr_reduce_batch_dev(sr_ctx *ctx, const uint64_t *d_in, size_t in_len_per_elem, uint64_t *d_out, size_t batch, void *stream);

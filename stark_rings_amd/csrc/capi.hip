@@ -353,6 +353,33 @@ int matvec_dev(sr_ctx *c, uint64_t *y, const uint64_t *m, const uint64_t *v, siz
     return SR_OK;
 }
 template <class F>
+int spmv_dev(sr_ctx *c, uint64_t *y, const uint64_t *vals, const uint32_t *cols, const uint64_t *row_ptr, const uint64_t *v,
+             size_t nrows, size_t ncols, hipStream_t st) {
+    using S = typename F::storage;
+    if (nrows == 0) return SR_OK;
+    if (nrows > 65535) return fail(SR_E_INVALID, "spmv: too many rows for one launch");
+    ProfScope ps(c, st, K_OTHER);
+    hipLaunchKernelGGL((sr::spmv_kernel<F>), dim3((unsigned)((c->degree + 255) / 256), (unsigned)nrows), dim3(256), 0, st,
+                       reinterpret_cast<S *>(y), reinterpret_cast<const S *>(vals), cols, row_ptr, reinterpret_cast<const S *>(v),
+                       ncols, c->k, c->d_counter + 1);
+    HIP_TRY(hipGetLastError());
+    return SR_OK;
+}
+template <class F>
+int matmul_dev(sr_ctx *c, uint64_t *y, const uint64_t *a, const uint64_t *b, size_t n, size_t m, size_t p, hipStream_t st) {
+    using S = typename F::storage;
+    if (n == 0 || p == 0) return SR_OK;
+    constexpr int RB = 4, CB = 2;
+    const size_t by = (n + RB - 1) / RB, bz = (p + CB - 1) / CB;
+    if (by > 65535 || bz > 65535) return fail(SR_E_INVALID, "matmul: too many rows or columns for one launch");
+    ProfScope ps(c, st, K_OTHER);
+    hipLaunchKernelGGL((sr::matmul_kernel<F, RB, CB>), dim3((unsigned)((c->degree + 255) / 256), (unsigned)by, (unsigned)bz),
+                       dim3(256), 0, st, reinterpret_cast<S *>(y), reinterpret_cast<const S *>(a), reinterpret_cast<const S *>(b),
+                       n, m, p, c->k);
+    HIP_TRY(hipGetLastError());
+    return SR_OK;
+}
+template <class F>
 int ring_mul_dev(sr_ctx *c, uint64_t *out, const uint64_t *a, uint64_t *b, size_t batch, hipStream_t st) {
     using S = typename F::storage;
     if (batch == 0) return SR_OK;
@@ -539,6 +566,13 @@ int dev_addsub(sr_ctx *c, uint64_t *l, const uint64_t *r, size_t batch, bool sub
         default: return addsub_dev<sr::Stark>(c, l, r, n, sub, st);
     }
 }
+int dev_spmv(sr_ctx *c, uint64_t *y, const uint64_t *vals, const uint32_t *cols, const uint64_t *row_ptr, const uint64_t *v,
+             size_t nrows, size_t ncols, hipStream_t st) {
+    DISPATCH_POW2(c, (spmv_dev<F>(c, y, vals, cols, row_ptr, v, nrows, ncols, st)));
+}
+int dev_matmul(sr_ctx *c, uint64_t *y, const uint64_t *a, const uint64_t *b, size_t n, size_t m, size_t p, hipStream_t st) {
+    DISPATCH_POW2(c, (matmul_dev<F>(c, y, a, b, n, m, p, st)));
+}
 int dev_matvec(sr_ctx *c, uint64_t *y, const uint64_t *m, const uint64_t *v, size_t nrows, size_t ncols, hipStream_t st) {
     DISPATCH_POW2(c, (matvec_dev<F>(c, y, m, v, nrows, ncols, st)));
 }
@@ -591,7 +625,9 @@ int sr_ctx_create(int ring, int log2_degree, int device, sr_ctx **out) {
         return code;
     };
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) return bail(fail(SR_E_HIP, "hipStreamCreate failed"));
-    if (hipMalloc(&c->d_counter, sizeof(unsigned long long)) != hipSuccess) return bail(fail(SR_E_ALLOC, "hipMalloc counter failed"));
+    // two words: [0] scratch counter of count_noncanonical, [1] out-of-range column indices seen by spmv (sticky until read)
+    if (hipMalloc(&c->d_counter, 2 * sizeof(unsigned long long)) != hipSuccess) return bail(fail(SR_E_ALLOC, "hipMalloc counter failed"));
+    if (hipMemset(c->d_counter, 0, 2 * sizeof(unsigned long long)) != hipSuccess) return bail(fail(SR_E_HIP, "hipMemset counter failed"));
     if (is_pow2_ring(ring)) {
         c->k = log2_degree;
         c->degree = (size_t)1 << log2_degree;
@@ -711,6 +747,109 @@ int sr_matvec_ntt_dev(sr_ctx *c, uint64_t *y, const uint64_t *m, const uint64_t 
     std::lock_guard<std::mutex> lk(c->mu);
     DeviceGuard g(c->device);
     return dev_matvec(c, y, m, v, nrows, ncols, (hipStream_t)stream);
+}
+int sr_spmv_ntt_dev(sr_ctx *c, uint64_t *y, const uint64_t *vals, const uint32_t *cols, const uint64_t *row_ptr, const uint64_t *v,
+                    size_t nrows, size_t ncols, void *stream) {
+    if (int rc = check(c, y, row_ptr, v)) return rc;
+    if (y == v || y == vals) return fail(SR_E_INVALID, "spmv: y must not alias the matrix or v");
+    std::lock_guard<std::mutex> lk(c->mu);
+    DeviceGuard g(c->device);
+    return dev_spmv(c, y, vals, cols, row_ptr, v, nrows, ncols, (hipStream_t)stream);
+}
+int sr_spmv_bad_index_count(sr_ctx *c, unsigned long long *out, void *stream) {
+    if (int rc = check(c, out)) return rc;
+    std::lock_guard<std::mutex> lk(c->mu);
+    DeviceGuard g(c->device);
+    hipStream_t st = (hipStream_t)stream;
+    HIP_TRY(hipMemcpyAsync(out, c->d_counter + 1, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemsetAsync(c->d_counter + 1, 0, sizeof(unsigned long long), st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return SR_OK;
+}
+int sr_matmul_ntt_dev(sr_ctx *c, uint64_t *y, const uint64_t *a, const uint64_t *b, size_t n, size_t m, size_t p, void *stream) {
+    if (int rc = check(c, y, a, b)) return rc;
+    if (y == a || y == b) return fail(SR_E_INVALID, "matmul: y must not alias A or B");
+    std::lock_guard<std::mutex> lk(c->mu);
+    DeviceGuard g(c->device);
+    return dev_matmul(c, y, a, b, n, m, p, (hipStream_t)stream);
+}
+
+// ---- host-pointer variants of the linear-algebra entry points: temporaries are allocated per call (these are
+// convenience entry points for callers that hold Vec<..> on the host; resident data uses the _dev forms)
+namespace {
+struct DevBuf {
+    void *p = nullptr;
+    ~DevBuf() {
+        if (p) (void)hipFree(p);
+    }
+    int alloc(size_t bytes) {
+        hipError_t e = hipMalloc(&p, bytes ? bytes : 8);
+        return e == hipSuccess ? SR_OK : fail(SR_E_ALLOC, std::string("hipMalloc: ") + hipGetErrorString(e));
+    }
+};
+}  // namespace
+int sr_matmul_ntt(sr_ctx *c, uint64_t *y, const uint64_t *a, const uint64_t *b, size_t n, size_t m, size_t p) {
+    if (int rc = check(c, y, a, b)) return rc;
+    std::lock_guard<std::mutex> lk(c->mu);
+    DeviceGuard g(c->device);
+    const size_t w = c->degree * c->limbs * 8;
+    DevBuf da, db, dy;
+    if (int rc = da.alloc(n * m * w)) return rc;
+    if (int rc = db.alloc(m * p * w)) return rc;
+    if (int rc = dy.alloc(n * p * w)) return rc;
+    if (n * m) HIP_TRY(hipMemcpyAsync(da.p, a, n * m * w, hipMemcpyHostToDevice, c->stream));
+    if (m * p) HIP_TRY(hipMemcpyAsync(db.p, b, m * p * w, hipMemcpyHostToDevice, c->stream));
+    if (int rc = dev_matmul(c, (uint64_t *)dy.p, (const uint64_t *)da.p, (const uint64_t *)db.p, n, m, p, c->stream)) return rc;
+    if (n * p) HIP_TRY(hipMemcpyAsync(y, dy.p, n * p * w, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return SR_OK;
+}
+int sr_matvec_ntt(sr_ctx *c, uint64_t *y, const uint64_t *m, const uint64_t *v, size_t nrows, size_t ncols) {
+    if (int rc = check(c, y, m, v)) return rc;
+    std::lock_guard<std::mutex> lk(c->mu);
+    DeviceGuard g(c->device);
+    const size_t w = c->degree * c->limbs * 8;
+    DevBuf dm, dv, dy;
+    if (int rc = dm.alloc(nrows * ncols * w)) return rc;
+    if (int rc = dv.alloc(ncols * w)) return rc;
+    if (int rc = dy.alloc(nrows * w)) return rc;
+    if (nrows * ncols) HIP_TRY(hipMemcpyAsync(dm.p, m, nrows * ncols * w, hipMemcpyHostToDevice, c->stream));
+    if (ncols) HIP_TRY(hipMemcpyAsync(dv.p, v, ncols * w, hipMemcpyHostToDevice, c->stream));
+    if (int rc = dev_matvec(c, (uint64_t *)dy.p, (const uint64_t *)dm.p, (const uint64_t *)dv.p, nrows, ncols, c->stream)) return rc;
+    if (nrows) HIP_TRY(hipMemcpyAsync(y, dy.p, nrows * w, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return SR_OK;
+}
+int sr_spmv_ntt(sr_ctx *c, uint64_t *y, const uint64_t *vals, const uint32_t *cols, const uint64_t *row_ptr, const uint64_t *v,
+                size_t nrows, size_t ncols) {
+    if (int rc = check(c, y, row_ptr, v)) return rc;
+    const size_t nnz = (size_t)row_ptr[nrows];
+    if (nnz && (!vals || !cols)) return fail(SR_E_INVALID, "null buffer");
+    for (size_t r = 0; r < nrows; r++)
+        if (row_ptr[r] > row_ptr[r + 1]) return fail(SR_E_INVALID, "spmv: row_ptr is not monotone");
+    for (size_t j = 0; j < nnz; j++)  // the reference indexes v[col] and panics when out of range (sparse_matrix.rs:208)
+        if (cols[j] >= ncols) return fail(SR_E_INVALID, "spmv: column index out of range");
+    std::lock_guard<std::mutex> lk(c->mu);
+    DeviceGuard g(c->device);
+    const size_t w = c->degree * c->limbs * 8;
+    DevBuf dvals, dcols, dptr, dv, dy;
+    if (int rc = dvals.alloc(nnz * w)) return rc;
+    if (int rc = dcols.alloc(nnz * 4)) return rc;
+    if (int rc = dptr.alloc((nrows + 1) * 8)) return rc;
+    if (int rc = dv.alloc(ncols * w)) return rc;
+    if (int rc = dy.alloc(nrows * w)) return rc;
+    if (nnz) {
+        HIP_TRY(hipMemcpyAsync(dvals.p, vals, nnz * w, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(dcols.p, cols, nnz * 4, hipMemcpyHostToDevice, c->stream));
+    }
+    HIP_TRY(hipMemcpyAsync(dptr.p, row_ptr, (nrows + 1) * 8, hipMemcpyHostToDevice, c->stream));
+    if (ncols) HIP_TRY(hipMemcpyAsync(dv.p, v, ncols * w, hipMemcpyHostToDevice, c->stream));
+    if (int rc = dev_spmv(c, (uint64_t *)dy.p, (const uint64_t *)dvals.p, (const uint32_t *)dcols.p, (const uint64_t *)dptr.p,
+                          (const uint64_t *)dv.p, nrows, ncols, c->stream))
+        return rc;
+    if (nrows) HIP_TRY(hipMemcpyAsync(y, dy.p, nrows * w, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return SR_OK;
 }
 int sr_ring_mul_batch_dev(sr_ctx *c, uint64_t *out, const uint64_t *a, uint64_t *b, size_t batch, void *stream) {
     if (int rc = check(c, out, a, b)) return rc;

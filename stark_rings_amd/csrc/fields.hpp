@@ -124,6 +124,19 @@ struct Goldilocks {
     // cannot name (the compiler adds the product with v_lshl_add_u64 and recovers the carry with a 64-bit compare), so the
     // multiply-add and the conditional + EPS are two small asm statements: 1 + 4 VALU instead of 3 + 4.  The s_nop covers the
     // 2 wait states between a VALU write of an SGPR carry and the VALU read of it.
+#if defined(SR_NO_MAD_ASM)  // plain C++ (A/B builds): the compiler recovers the carry with a 64-bit compare
+    static __device__ __forceinline__ elem mad_eps_fix(uint64_t l2, uint32_t hl) {
+        unsigned __int128 w = (unsigned __int128)l2 + (uint64_t)hl * EPS;
+        uint64_t t = (uint64_t)w;
+        bool c1 = (uint64_t)(w >> 64) != 0;
+        uint32_t c, c2, t0 = (uint32_t)t, t1 = (uint32_t)(t >> 32);
+        SR_OPAQUE(t1);
+        uint32_t u0 = __builtin_addc(t0, 0xFFFFFFFFu, 0u, &c);
+        uint32_t u1 = __builtin_addc(t1, 0u, c, &c2);
+        bool fix = c1 | (c2 != 0);
+        return (uint64_t)(fix ? u0 : t0) | ((uint64_t)(fix ? u1 : t1) << 32);
+    }
+#else
     static __device__ __forceinline__ elem mad_eps_fix(uint64_t l2, uint32_t hl) {
         uint64_t t, cy, tmp;
         uint32_t r0, r1;
@@ -136,9 +149,12 @@ struct Goldilocks {
             "v_cndmask_b32_e64 %0, %3, %0, %2\n\t"
             "v_cndmask_b32_e64 %1, %4, %1, %2"
             : "=&v"(r0), "=&v"(r1), "=&s"(tmp)
-            : "v"(t0), "v"(t1), "s"(cy));
+            : "v"(t0), "v"(t1), "s"(cy)
+            : "scc");  // s_or_b64 writes SCC: without the clobber the scheduler may (and did) drop this statement between an
+                       // s_add_u32 / s_addc_u32 address pair, corrupting the carry (a +2^32 address fault)
         return (uint64_t)r0 | ((uint64_t)r1 << 32);
     }
+#endif
     static __device__ __forceinline__ elem reduce128(uint64_t lo, uint64_t hi) {
         return mad_eps_fix(sub_small(lo, (uint32_t)(hi >> 32)), (uint32_t)hi);
     }

@@ -229,6 +229,64 @@ __global__ __launch_bounds__(256) void matvec_kernel(typename F::storage *y, con
         if (r0 + r < nrows) F::store(y + ((r0 + r) << k) + slot, acc[r]);
 }
 
+// y[r] = sum over the stored entries (val, col) of row r of val * v[col]: SparseMatrix<RqNTT>::checked_mul_vec
+// (crates/linear_algebra/src/sparse_matrix.rs:201-211; an empty row sums to zero).  CSR on the device: vals[j] is one ring
+// element, cols[j] its column, row_ptr[r] .. row_ptr[r + 1] the entries of row r.  Lane = one slot, blockIdx.y = row.
+// An entry whose column is >= ncols would index outside v (the reference panics there): it is skipped and counted in *bad.
+template <class F>
+__global__ __launch_bounds__(256) void spmv_kernel(typename F::storage *y, const typename F::storage *vals, const uint32_t *cols,
+                                                   const uint64_t *row_ptr, const typename F::storage *v, size_t ncols, int k,
+                                                   unsigned long long *bad) {
+    const size_t d = (size_t)1 << k;
+    const size_t slot = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    const size_t r = blockIdx.y;
+    if (slot >= d) return;
+    typename F::elem acc = F::zero();
+    const uint64_t j1 = row_ptr[r + 1];
+    for (uint64_t j = row_ptr[r]; j < j1; j++) {
+        const uint32_t c = cols[j];
+        if (c >= ncols) {
+            if (slot == 0) atomicAdd(bad, 1ull);
+            continue;
+        }
+        acc = F::add(acc, F::mul_boundary(F::load(vals + (j << k) + slot), F::load(v + ((size_t)c << k) + slot)));
+    }
+    F::store(y + (r << k) + slot, acc);
+}
+
+// Y (n x p) = A (n x m) * B (m x p), dense row-major matrices of ring elements in CRT/NTT form:
+// Matrix<RqNTT>::checked_mul_mat (crates/linear_algebra/src/matrix.rs:148-166).  Per slot this is a small Fp GEMM; a lane
+// keeps an RB x CB block of outputs, so each loaded A and B slot feeds CB resp. RB multiply-adds.
+template <class F, int RB, int CB>
+__global__ __launch_bounds__(256) void matmul_kernel(typename F::storage *y, const typename F::storage *a,
+                                                     const typename F::storage *b, size_t n, size_t m, size_t p, int k) {
+    const size_t d = (size_t)1 << k;
+    const size_t slot = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    const size_t r0 = (size_t)blockIdx.y * RB, c0 = (size_t)blockIdx.z * CB;
+    if (slot >= d) return;
+    typename F::elem acc[RB][CB];
+#pragma unroll
+    for (int r = 0; r < RB; r++)
+#pragma unroll
+        for (int c = 0; c < CB; c++) acc[r][c] = F::zero();
+    for (size_t t = 0; t < m; t++) {
+        typename F::elem av[RB], bv[CB];
+#pragma unroll
+        for (int r = 0; r < RB; r++) av[r] = r0 + r < n ? F::load(a + (((r0 + r) * m + t) << k) + slot) : F::zero();
+#pragma unroll
+        for (int c = 0; c < CB; c++) bv[c] = c0 + c < p ? F::load(b + ((t * p + c0 + c) << k) + slot) : F::zero();
+#pragma unroll
+        for (int r = 0; r < RB; r++)
+#pragma unroll
+            for (int c = 0; c < CB; c++) acc[r][c] = F::add(acc[r][c], F::mul_boundary(av[r], bv[c]));
+    }
+#pragma unroll
+    for (int r = 0; r < RB; r++)
+#pragma unroll
+        for (int c = 0; c < CB; c++)
+            if (r0 + r < n && c0 + c < p) F::store(y + (((r0 + r) * p + c0 + c) << k) + slot, acc[r][c]);
+}
+
 // out[e][i] = in[e][i] - in[e][D + i]   (stark_prime/mod.rs:40-47); in_len <= 2D per element
 template <class F>
 __global__ void reduce_pow2_kernel(const typename F::storage *in, size_t in_len, typename F::storage *out, int k,

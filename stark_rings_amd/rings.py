@@ -142,6 +142,54 @@ class CyclotomicRing:
         self._check(self._lib.sr_ring_mul_batch(self._ctx, _np_ptr(out), _np_ptr(a), _np_ptr(b), self._batch_of(a.size)))
         return out
 
+    def matvec_ntt(self, m, v, nrows, ncols):
+        """Host buffers: Matrix<RqNTT>::checked_mul_vec (matrix.rs:168-178); RingError where the reference returns None."""
+        w = self.words_per_elem
+        if m.size != nrows * ncols * w or v.size != ncols * w:
+            raise RingError("matvec: DifferentLengths")
+        y = np.empty(max(nrows * w, 1), dtype=np.uint64)[:nrows * w]
+        self._check(self._lib.sr_matvec_ntt(self._ctx, _np_ptr(y) if nrows else _np_ptr(np.zeros(1, dtype=np.uint64)),
+                                            _np_ptr(m) if m.size else _np_ptr(np.zeros(1, dtype=np.uint64)),
+                                            _np_ptr(v) if v.size else _np_ptr(np.zeros(1, dtype=np.uint64)), nrows, ncols))
+        return y
+
+    def spmv_ntt(self, rows, v, ncols):
+        """rows: the reference's SparseMatrix.coeffs -- a list (one per row) of lists of (ring element as uint64 words, column).
+        SparseMatrix<RqNTT>::checked_mul_vec (sparse_matrix.rs:201-211); an out-of-range column raises RingError (the
+        reference panics on v[col])."""
+        w = self.words_per_elem
+        if v.size != ncols * w:
+            raise RingError("spmv: DifferentLengths")
+        nrows = len(rows)
+        row_ptr = np.zeros(nrows + 1, dtype=np.uint64)
+        for r, row in enumerate(rows):
+            row_ptr[r + 1] = row_ptr[r] + len(row)
+        nnz = int(row_ptr[-1])
+        vals = np.zeros(max(nnz * w, 1), dtype=np.uint64)
+        cols = np.zeros(max(nnz, 1), dtype=np.uint32)
+        j = 0
+        for row in rows:
+            for elem, col in row:
+                vals[j * w:(j + 1) * w] = elem
+                cols[j] = col
+                j += 1
+        y = np.empty(max(nrows * w, 1), dtype=np.uint64)
+        vv = v if v.size else np.zeros(1, dtype=np.uint64)
+        self._check(self._lib.sr_spmv_ntt(self._ctx, _np_ptr(y), _np_ptr(vals), cols.ctypes.data_as(ctypes.c_void_p), _np_ptr(row_ptr), _np_ptr(vv),
+                                          nrows, ncols))
+        return y[:nrows * w]
+
+    def matmul_ntt(self, a, b, n, m, p):
+        """Host buffers: Matrix<RqNTT>::checked_mul_mat (matrix.rs:148-166)."""
+        w = self.words_per_elem
+        if a.size != n * m * w or b.size != m * p * w:
+            raise RingError("matmul: DifferentLengths")
+        y = np.empty(max(n * p * w, 1), dtype=np.uint64)
+        z = np.zeros(1, dtype=np.uint64)
+        self._check(self._lib.sr_matmul_ntt(self._ctx, _np_ptr(y), _np_ptr(a) if a.size else _np_ptr(z),
+                                            _np_ptr(b) if b.size else _np_ptr(z), n, m, p))
+        return y[:n * p * w]
+
     def reduce(self, coeffs, in_len_per_elem, batch):
         """CyclotomicConfig::reduce_in_place (ring_config.rs:23): (batch, in_len) -> (batch, D)."""
         if coeffs.size != batch * in_len_per_elem * self.limbs:
@@ -211,6 +259,43 @@ class CyclotomicRing:
         if nm != nrows * ncols * self.words_per_elem or nv != ncols * self.words_per_elem or ny != nrows * self.words_per_elem:
             raise RingError("matvec: DifferentLengths")
         self._check(self._lib.sr_matvec_ntt_dev(self._ctx, py, pm, pv, nrows, ncols, self._stream(stream)))
+        return y
+
+    def spmv_ntt_dev(self, y, vals, cols, row_ptr, v, nrows, ncols, stream=None):
+        """y = S v for a CSR sparse matrix of ring elements in CRT/NTT form: SparseMatrix<RqNTT>::checked_mul_vec
+        (linear_algebra/src/sparse_matrix.rs:201-211).  vals: nnz ring elements (int64 words), cols: int32 column of each,
+        row_ptr: int64 [nrows + 1].  Entries whose column is >= ncols are skipped and counted (spmv_bad_index_count)."""
+        import torch
+
+        py, ny = self._dev(y)
+        pv, nv = self._dev(v)
+        if cols.dtype != torch.int32 or row_ptr.dtype != torch.int64 or row_ptr.numel() != nrows + 1:
+            raise RingError("spmv: cols must be int32 and row_ptr int64 of length nrows + 1")
+        nnz = cols.numel()
+        if vals.numel() != nnz * self.words_per_elem or nv != ncols * self.words_per_elem or ny != nrows * self.words_per_elem:
+            raise RingError("spmv: DifferentLengths")
+        pvals = self._dev(vals)[0] if nnz else 0
+        self._check(self._lib.sr_spmv_ntt_dev(self._ctx, py, pvals, cols.data_ptr() if nnz else 0, row_ptr.data_ptr(), pv,
+                                              nrows, ncols, self._stream(stream)))
+        return y
+
+    def spmv_bad_index_count(self, stream=None):
+        import ctypes
+
+        n = ctypes.c_ulonglong(0)
+        self._check(self._lib.sr_spmv_bad_index_count(self._ctx, ctypes.byref(n), self._stream(stream)))
+        return int(n.value)
+
+    def matmul_ntt_dev(self, y, a, b, n, m, p, stream=None):
+        """Y (n x p) = A (n x m) B (m x p), dense row-major, CRT/NTT form: Matrix<RqNTT>::checked_mul_mat
+        (linear_algebra/src/matrix.rs:148-166)."""
+        py, ny = self._dev(y)
+        pa, na = self._dev(a)
+        pb, nb = self._dev(b)
+        w = self.words_per_elem
+        if na != n * m * w or nb != m * p * w or ny != n * p * w:
+            raise RingError("matmul: DifferentLengths")
+        self._check(self._lib.sr_matmul_ntt_dev(self._ctx, py, pa, pb, n, m, p, self._stream(stream)))
         return y
 
     def mul_dev(self, out, a, b, stream=None):

@@ -460,3 +460,98 @@ def test_matvec_ntt_matches_row_by_row_products(torch_cuda, name, k, nrows, ncol
     assert O.from_mont(F, ty.cpu().numpy().view(np.uint64)) == want
     with pytest.raises(RingError, match="DifferentLengths"):
         ring.matvec_ntt_dev(ty, tm, tv, nrows, ncols + 1)
+
+
+def _slot_products(F, p, k, w, pairs):
+    """sum of slot-wise products of (a, b) ring-element pairs through the oracle, as standard-form integers"""
+    acc = [0] * (1 << k)
+    for a, b in pairs:
+        prod = O.from_mont(F, O.pow2_pointwise(F, a, b))
+        acc = [(x + y) % p for x, y in zip(acc, prod)]
+    return acc
+
+
+@pytest.mark.parametrize("name,k,nrows,ncols", [("goldilocks", 5, 6, 9), ("babybear", 6, 4, 5), ("stark", 4, 5, 4)])
+def test_spmv_ntt_matches_oracle_row_sums(torch_cuda, name, k, nrows, ncols):
+    """SparseMatrix<RqNTT>::checked_mul_vec (linear_algebra/src/sparse_matrix.rs:201-211): per row the sum over its stored
+    (value, column) entries of value * v[column]; an empty row is zero; repeated columns in a row both count.  Device (CSR)
+    and host-pointer entry points against the oracle's slot products."""
+    torch = torch_cuda
+    from stark_rings_amd import RingError
+
+    F = O.FIELD_ID[name]
+    p = P.PRIMES[name][0]
+    ring = ring_for(name, k)
+    w = ring.words_per_elem
+    v = O.fill_uniform(F, 62, 0, ncols << k)
+    rng = np.random.default_rng(7 + k)
+    rows, seed = [], 100
+    for r in range(nrows):
+        nz = 0 if r == 2 else int(rng.integers(1, ncols + 2))      # row 2 is empty; some rows hold a column twice
+        row = []
+        for _ in range(nz):
+            seed += 1
+            row.append((O.fill_uniform(F, seed, 0, 1 << k), int(rng.integers(0, ncols))))
+        rows.append(row)
+    want = []
+    for row in rows:
+        want += _slot_products(F, p, k, w, [(val, v[c * w:(c + 1) * w]) for val, c in row])
+    got = ring.spmv_ntt(rows, v, ncols)
+    assert O.from_mont(F, got) == want
+    # device CSR
+    nnz = sum(len(r) for r in rows)
+    vals = np.concatenate([val for row in rows for val, _ in row]) if nnz else np.zeros(0, dtype=np.uint64)
+    cols = np.array([c for row in rows for _, c in row], dtype=np.int32)
+    ptr = np.zeros(nrows + 1, dtype=np.int64)
+    ptr[1:] = np.cumsum([len(r) for r in rows])
+    ty = torch.empty(nrows * w, dtype=torch.int64, device="cuda")
+    tv = torch.from_numpy(v.view(np.int64)).cuda()
+    tvals, tcols, tptr = torch.from_numpy(vals.view(np.int64)).cuda(), torch.from_numpy(cols).cuda(), torch.from_numpy(ptr).cuda()
+    ring.spmv_ntt_dev(ty, tvals, tcols, tptr, tv, nrows, ncols)
+    assert O.from_mont(F, ty.cpu().numpy().view(np.uint64)) == want
+    assert ring.spmv_bad_index_count() == 0
+    # out-of-range column: host form refuses (the reference panics on v[col]); device form skips the entry and counts it
+    bad_rows = [list(r) for r in rows]
+    bad_rows[0] = bad_rows[0] + [(O.fill_uniform(F, 999, 0, 1 << k), ncols)]
+    with pytest.raises(RingError, match="out of range"):
+        ring.spmv_ntt(bad_rows, v, ncols)
+    bad_cols = cols.copy()
+    bad_cols[0] = ncols + 3
+    ring.spmv_ntt_dev(ty, tvals, torch.from_numpy(bad_cols).cuda(), tptr, tv, nrows, ncols)
+    assert ring.spmv_bad_index_count() == 1 and ring.spmv_bad_index_count() == 0
+    with pytest.raises(RingError, match="DifferentLengths"):
+        ring.spmv_ntt(rows, v[w:], ncols)
+
+
+@pytest.mark.parametrize("name,k,n,m,p_", [("goldilocks", 5, 5, 7, 3), ("babybear", 6, 3, 4, 5), ("stark", 4, 4, 3, 2), ("goldilocks", 12, 2, 3, 2)])
+def test_matmul_ntt_matches_oracle(torch_cuda, name, k, n, m, p_):
+    """Matrix<RqNTT>::checked_mul_mat (linear_algebra/src/matrix.rs:148-166): Y[i][j] = sum_t A[i][t] * B[t][j], slot-wise."""
+    torch = torch_cuda
+    from stark_rings_amd import RingError
+
+    F = O.FIELD_ID[name]
+    p = P.PRIMES[name][0]
+    ring = ring_for(name, k)
+    w = ring.words_per_elem
+    a = O.fill_uniform(F, 71, 0, n * m << k)
+    b = O.fill_uniform(F, 72, 0, m * p_ << k)
+    want = []
+    for i in range(n):
+        for j in range(p_):
+            want += _slot_products(F, p, k, w, [(a[(i * m + t) * w:(i * m + t + 1) * w], b[(t * p_ + j) * w:(t * p_ + j + 1) * w])
+                                                for t in range(m)])
+    assert O.from_mont(F, ring.matmul_ntt(a, b, n, m, p_)) == want
+    ta, tb = torch.from_numpy(a.view(np.int64)).cuda(), torch.from_numpy(b.view(np.int64)).cuda()
+    ty = torch.empty(n * p_ * w, dtype=torch.int64, device="cuda")
+    ring.matmul_ntt_dev(ty, ta, tb, n, m, p_)
+    assert O.from_mont(F, ty.cpu().numpy().view(np.uint64)) == want
+    # a matrix times a one-column matrix is the matrix-vector product
+    tv = tb[:m * w].clone() if p_ == 1 else torch.from_numpy(O.fill_uniform(F, 73, 0, m << k).view(np.int64)).cuda()
+    y1 = torch.empty(n * w, dtype=torch.int64, device="cuda")
+    y2 = torch.empty(n * w, dtype=torch.int64, device="cuda")
+    ring.matmul_ntt_dev(y1, ta, tv, n, m, 1)
+    ring.matvec_ntt_dev(y2, ta, tv, n, m)
+    assert torch.equal(y1, y2)
+    assert np.array_equal(ring.matvec_ntt(a, tv.cpu().numpy().view(np.uint64), n, m), y2.cpu().numpy().view(np.uint64))
+    with pytest.raises(RingError, match="DifferentLengths"):
+        ring.matmul_ntt(a, b, n, m + 1, p_)
