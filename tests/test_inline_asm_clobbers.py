@@ -26,18 +26,30 @@ def asm_statements(text):
         i = j
 
 
-def test_inline_asm_declares_scc_and_vcc_clobbers():
-    seen = 0
-    for path in glob.glob(os.path.join(ROOT, "stark_rings_amd", "csrc", "*")):
-        text = open(path).read()
+def _violations(text, path="<text>"):
+    out, seen = [], 0
+    if True:
         for stmt in asm_statements(text):
-            body = "".join(re.findall(r'"((?:[^"\\]|\\.)*)"', stmt.split(":")[0]))
+            body = "".join(re.findall(r'"((?:[^"\\]|\\.)*)"', stmt.split(":")[0])).replace("\\n", "\n").replace("\\t", " ")
             if not body.strip():
                 continue  # empty optimisation barrier
             seen += 1
             clobbers = stmt.split(":")[3] if stmt.count(":") >= 3 else ""
-            if SCC_WRITERS.search(body):
-                assert '"scc"' in clobbers, "%s: asm with an SCC-writing SALU op lacks the scc clobber:\n%s" % (path, stmt)
-            if re.search(r"\bvcc\b", body):
-                assert '"vcc"' in clobbers, "%s: asm naming vcc lacks the vcc clobber:\n%s" % (path, stmt)
-    assert seen >= 4  # mac2, mac1, the two mad_eps_fix statements
+            if SCC_WRITERS.search(body) and '"scc"' not in clobbers:
+                out.append("%s: asm with an SCC-writing SALU op lacks the scc clobber:\n%s" % (path, stmt))
+            if re.search(r"\bvcc\b", body) and '"vcc"' not in clobbers:
+                out.append("%s: asm naming vcc lacks the vcc clobber:\n%s" % (path, stmt))
+    return out, seen
+
+
+def test_inline_asm_declares_scc_and_vcc_clobbers():
+    total = 0
+    for path in glob.glob(os.path.join(ROOT, "stark_rings_amd", "csrc", "*")):
+        bad, seen = _violations(open(path).read(), path)
+        assert not bad, "\n".join(bad)
+        total += seen
+    assert total >= 4  # mac2, mac1, the two mad_eps_fix statements
+    # negative control: the guard must notice the clobber going missing
+    fields = open(os.path.join(ROOT, "stark_rings_amd", "csrc", "fields.hpp")).read()
+    assert ': "scc");' in fields
+    assert _violations(fields.replace(': "scc");', ');'))[0]
