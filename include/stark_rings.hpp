@@ -21,6 +21,11 @@
 //   ICRT::elementwise_icrt               crt.rs:34-49                RqNTTVec::elementwise_icrt() &&
 //   Flatten::flatten_to_coeffs           flatten.rs:11-17            flatten_to_coeffs(Vec&&) -> std::vector<uint64_t>
 //   Flatten::promote_from_coeffs         flatten.rs:19-33            promote_from_coeffs(...) -> std::optional (nullopt if len % D != 0)
+//   Matrix<RqNTT> (linear_algebra)       matrix.rs:14-20             class MatrixNTT        (dense, row-major, flat)
+//     checked_mul_vec / try_mul_vec      matrix.rs:168-183             checked_mul_vec -> std::optional (nullopt: DifferentLengths), try_mul_vec throws
+//     checked_mul_mat                    matrix.rs:148-166             checked_mul_mat -> std::optional
+//   SparseMatrix<RqNTT>                  sparse_matrix.rs:17-22      class SparseMatrixNTT  (coeffs: rows of (element, column))
+//     checked_mul_vec / try_mul_vec      sparse_matrix.rs:201-216      same contract; an out-of-range column throws (the reference panics)
 //
 // What is deliberately narrowed: ring elements of degree 2^16 are 512 KiB, so the per-element `Copy` value type of
 // the reference (ring.rs:13-15) is not mirrored; the drop-in seam is the batch (hard part 4).
@@ -178,6 +183,91 @@ inline RqNTTVec RqPolyVec::elementwise_crt() && {
     CyclotomicConfig::check(sr_ntt_fwd_batch(cfg_.raw(), w_.data(), len()), "elementwise_crt");
     return RqNTTVec(cfg_, std::move(w_));
 }
+
+// Matrix<RqNTT> (crates/linear_algebra/src/matrix.rs): nrows x ncols ring elements in CRT/NTT form, row-major, flat
+class MatrixNTT {
+public:
+    MatrixNTT(CyclotomicConfig cfg, size_t nrows, size_t ncols, std::vector<uint64_t> words)
+        : cfg_(std::move(cfg)), nrows_(nrows), ncols_(ncols), w_(std::move(words)) {
+        if (w_.size() != nrows_ * ncols_ * cfg_.words_per_elem()) throw std::length_error("Wrong length");
+    }
+    size_t nrows() const { return nrows_; }
+    size_t ncols() const { return ncols_; }
+    const std::vector<uint64_t> &words() const { return w_; }
+    // matrix.rs:168-178: None when ncols != v.len()
+    std::optional<RqNTTVec> checked_mul_vec(const RqNTTVec &v) const {
+        if (v.len() != ncols_) return std::nullopt;
+        std::vector<uint64_t> y(nrows_ * cfg_.words_per_elem());
+        std::vector<uint64_t> dummy(1);
+        CyclotomicConfig::check(sr_matvec_ntt(cfg_.raw(), y.empty() ? dummy.data() : y.data(), w_.empty() ? dummy.data() : w_.data(),
+                                              v.words().empty() ? dummy.data() : v.words().data(), nrows_, ncols_),
+                                "Matrix * vec");
+        return RqNTTVec(cfg_, std::move(y));
+    }
+    RqNTTVec try_mul_vec(const RqNTTVec &v) const {  // matrix.rs:180-183: AlgebraError::DifferentLengths
+        auto r = checked_mul_vec(v);
+        if (!r) throw std::length_error("DifferentLengths");
+        return std::move(*r);
+    }
+    std::optional<MatrixNTT> checked_mul_mat(const MatrixNTT &m) const {  // matrix.rs:148-166
+        if (ncols_ != m.nrows_) return std::nullopt;
+        std::vector<uint64_t> y(nrows_ * m.ncols_ * cfg_.words_per_elem());
+        std::vector<uint64_t> dummy(1);
+        CyclotomicConfig::check(sr_matmul_ntt(cfg_.raw(), y.empty() ? dummy.data() : y.data(), w_.empty() ? dummy.data() : w_.data(),
+                                              m.w_.empty() ? dummy.data() : m.w_.data(), nrows_, ncols_, m.ncols_),
+                                "Matrix * Matrix");
+        return MatrixNTT(cfg_, nrows_, m.ncols_, std::move(y));
+    }
+
+private:
+    CyclotomicConfig cfg_;
+    size_t nrows_, ncols_;
+    std::vector<uint64_t> w_;
+};
+
+// SparseMatrix<RqNTT> (crates/linear_algebra/src/sparse_matrix.rs:17-22): coeffs[r] = the stored (element, column) pairs of row r
+class SparseMatrixNTT {
+public:
+    using Entry = std::pair<std::vector<uint64_t>, size_t>;
+    SparseMatrixNTT(CyclotomicConfig cfg, size_t nrows, size_t ncols, std::vector<std::vector<Entry>> coeffs)
+        : cfg_(std::move(cfg)), nrows_(nrows), ncols_(ncols) {
+        if (coeffs.size() != nrows_) throw std::length_error("Wrong length");
+        row_ptr_.assign(nrows_ + 1, 0);
+        for (size_t r = 0; r < nrows_; r++) {
+            row_ptr_[r + 1] = row_ptr_[r] + coeffs[r].size();
+            for (auto &e : coeffs[r]) {
+                if (e.first.size() != cfg_.words_per_elem()) throw std::length_error("Wrong length");
+                vals_.insert(vals_.end(), e.first.begin(), e.first.end());
+                cols_.push_back((uint32_t)e.second);
+                if (e.second > 0xFFFFFFFFull) throw std::length_error("column index does not fit 32 bits");
+            }
+        }
+    }
+    size_t nrows() const { return nrows_; }
+    size_t ncols() const { return ncols_; }
+    std::optional<RqNTTVec> checked_mul_vec(const RqNTTVec &v) const {  // sparse_matrix.rs:201-211
+        if (v.len() != ncols_) return std::nullopt;
+        std::vector<uint64_t> y(nrows_ * cfg_.words_per_elem());
+        std::vector<uint64_t> dummy(1);
+        std::vector<uint32_t> dummy32(1);
+        CyclotomicConfig::check(sr_spmv_ntt(cfg_.raw(), y.empty() ? dummy.data() : y.data(), vals_.empty() ? dummy.data() : vals_.data(),
+                                            cols_.empty() ? dummy32.data() : cols_.data(), row_ptr_.data(),
+                                            v.words().empty() ? dummy.data() : v.words().data(), nrows_, ncols_),
+                                "SparseMatrix * vec");
+        return RqNTTVec(cfg_, std::move(y));
+    }
+    RqNTTVec try_mul_vec(const RqNTTVec &v) const {  // sparse_matrix.rs:213-216
+        auto r = checked_mul_vec(v);
+        if (!r) throw std::length_error("DifferentLengths");
+        return std::move(*r);
+    }
+
+private:
+    CyclotomicConfig cfg_;
+    size_t nrows_, ncols_;
+    std::vector<uint64_t> vals_, row_ptr_;
+    std::vector<uint32_t> cols_;
+};
 
 // Flatten (flatten.rs:10-34): the flat coefficient vector IS the batch's storage; both directions are moves.
 template <class V>

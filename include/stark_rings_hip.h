@@ -119,6 +119,23 @@ int sr_matvec_ntt(sr_ctx *ctx, uint64_t *y, const uint64_t *m, const uint64_t *v
 int sr_spmv_ntt(sr_ctx *ctx, uint64_t *y, const uint64_t *vals, const uint32_t *cols, const uint64_t *row_ptr, const uint64_t *v,
                 size_t nrows, size_t ncols);
 int sr_matmul_ntt(sr_ctx *ctx, uint64_t *y, const uint64_t *a, const uint64_t *b, size_t n, size_t m, size_t p);
+/* Second "next" row: balanced gadget decomposition, coefficient-wise, of `batch` ring elements in COEFFICIENT
+ * form: digit j of element e is ring element e * padding_size + j of d_out (batch * padding_size elements) --
+ * GadgetDecompose for &[R] (crates/ring/src/balanced_decomposition/mod.rs:163-175) over Decompose for the ring
+ * (cyclotomic_ring/coeff_form.rs:587-605) over decompose_balanced_in_place (mod.rs:62-117; signed representative
+ * fq_convertible.rs:21-35, stark_prime/decomposition.rs:41-53).  basis: even, 2 <= basis <= 2^32 (the reference takes u128 and
+ * panics on 0, 1 and odd values: SR_E_INVALID here).  Every ring id; digits are field elements in the same Montgomery
+ * layout.  A coefficient that needs more than padding_size digits makes the reference panic (out[i] out of bounds): the
+ * device form writes the first padding_size digits and counts it (sr_decompose_overflow_count reads and clears the count,
+ * synchronising the stream); the host form returns SR_E_INVALID. */
+int sr_decompose_balanced_batch_dev(sr_ctx *ctx, uint64_t *d_out, const uint64_t *d_in, uint64_t basis, size_t padding_size,
+                                    size_t batch, void *stream);
+int sr_decompose_overflow_count(sr_ctx *ctx, unsigned long long *out, void *stream);
+/* GadgetRecompose (mod.rs:177-189, recompose :119-131): d_out[e] = sum_j basis^j * d_in[e * padding_size + j], batch_out elements */
+int sr_recompose_batch_dev(sr_ctx *ctx, uint64_t *d_out, const uint64_t *d_in, uint64_t basis, size_t padding_size,
+                           size_t batch_out, void *stream);
+int sr_decompose_balanced_batch(sr_ctx *ctx, uint64_t *out, const uint64_t *in, uint64_t basis, size_t padding_size, size_t batch);
+int sr_recompose_batch(sr_ctx *ctx, uint64_t *out, const uint64_t *in, uint64_t basis, size_t padding_size, size_t batch_out);
 /* d_b is used as scratch and holds crt(b) afterwards when D exceeds one LDS tile; d_out may alias d_a. */
 int sr_ring_mul_batch_dev(sr_ctx *ctx, uint64_t *d_out, const uint64_t *d_a, uint64_t *d_b, size_t batch, void *stream);
 int sr_reduce_batch_dev(sr_ctx *ctx, const uint64_t *d_in, size_t in_len_per_elem, uint64_t *d_out, size_t batch, void *stream);

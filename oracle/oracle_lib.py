@@ -43,6 +43,8 @@ def lib():
             "sro_pow2_pointwise": (i, [i, _u64p, _u64p, sz]),
             "sro_pow2_reduce": (i, [i, _u64p, sz, _u64p, i]),
             "sro_schoolbook": (i, [i, _u64p, _u64p, sz, _u64p]),
+            "sro_decompose_balanced": (i, [i, _u64p, sz, sz, ctypes.c_uint64, sz, _u64p]),
+            "sro_recompose": (i, [i, _u64p, sz, sz, ctypes.c_uint64, sz, _u64p]),
             "sro_pow2_ring_mul": (i, [i, _u64p, _u64p, _u64p, i]),
             "sro_pow2_fwd_batch": (i, [i, _u64p, i, sz, i]),
             "sro_pow2_inv_batch": (i, [i, _u64p, i, sz, i]),
@@ -151,6 +153,23 @@ def schoolbook(field, a, b, d):
     b = np.ascontiguousarray(b, dtype=np.uint64)
     out = np.empty((2 * d - 1) * LIMBS[field], dtype=np.uint64)
     assert lib().sro_schoolbook(field, ptr(a), ptr(b), d, ptr(out)) == 0
+    return out
+
+
+def decompose_balanced(field, a, d, batch, b, k):
+    """returns (digits, overflow): digits = batch * k ring elements, digit j of element e at index e * k + j"""
+    a = np.ascontiguousarray(a, dtype=np.uint64)
+    out = np.empty(batch * k * d * LIMBS[field], dtype=np.uint64)
+    rc = lib().sro_decompose_balanced(field, ptr(a), d, batch, b, k, ptr(out))
+    if rc < 0:
+        raise ValueError("bad decomposition basis")
+    return out, bool(rc)
+
+
+def recompose(field, digits, d, batch_out, b, k):
+    digits = np.ascontiguousarray(digits, dtype=np.uint64)
+    out = np.empty(batch_out * d * LIMBS[field], dtype=np.uint64)
+    assert lib().sro_recompose(field, ptr(digits), d, batch_out, b, k, ptr(out)) == 0
     return out
 
 

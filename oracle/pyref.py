@@ -386,3 +386,58 @@ def bb72_ntt_mul(x, y):
     for s in range(8):
         out += fq9_mul(x[9 * s:9 * s + 9], y[9 * s:9 * s + 9])
     return out
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# balanced (gadget) decomposition -- SURVEY 8f #2; plain-integer restatement of
+#   decompose_balanced_in_place   crates/ring/src/balanced_decomposition/mod.rs:62-117
+#   signed representative         balanced_decomposition/fq_convertible.rs:21-35, stark_prime/decomposition.rs:41-53
+#   rounded_div                   crates/linear_algebra/src/ops.rs:64-80
+#   recompose                     balanced_decomposition/mod.rs:119-131
+def signed_representative(x, p):
+    """[0, (p-1)/2] -> itself, ](p-1)/2, p[ -> x - p"""
+    return x - p if x > (p - 1) // 2 else x
+
+
+def _trunc_divmod(a, b):
+    """Rust / and % on signed integers: quotient rounds toward zero, remainder has the sign of the dividend"""
+    q = abs(a) // b
+    q = -q if a < 0 else q
+    return q, a - q * b
+
+
+def rounded_div(dividend, divisor):
+    if (dividend ^ divisor) >= 0:
+        return _trunc_divmod(dividend + divisor // 2, divisor)[0]
+    return _trunc_divmod(dividend - divisor // 2, divisor)[0]
+
+
+def decompose_balanced(x, p, b, k):
+    """k balanced base-b digits (signed integers) of the field element x (standard form); raises IndexError where the
+    reference indexes past `out` (more than k digits needed)"""
+    if b in (0, 1):
+        raise ValueError("cannot decompose in basis 0 or 1")
+    if b % 2:
+        raise ValueError("decomposition basis must be even")
+    curr = signed_representative(x, p)
+    out = [0] * k
+    i = 0
+    while True:
+        q, rem = _trunc_divmod(curr, b)
+        if abs(rem) <= b // 2:
+            out[i] = rem          # IndexError when i == k, like the reference's panic
+            curr = q
+        else:
+            out[i] = rem + b if rem < 0 else rem - b
+            curr = q + rounded_div(rem, b)
+        i += 1
+        if curr == 0:
+            break
+    return out
+
+
+def recompose(digits, b, p):
+    acc = 0
+    for d in reversed(digits):
+        acc = (acc * b + d) % p
+    return acc

@@ -228,6 +228,118 @@ void sro_from_mont(int field, const uint64_t *in, uint64_t *out, size_t n) {
     }
 }
 
+/* ======================================================================================
+ * Balanced (gadget) decomposition -- SURVEY 8f #2.
+ *   decompose_balanced_in_place  crates/ring/src/balanced_decomposition/mod.rs:62-117
+ *   signed representative        fq_convertible.rs:21-35 (Fp64), stark_prime/decomposition.rs:41-53 (Fp256):
+ *                                [0, (p-1)/2] stays, ](p-1)/2, p[ maps to x - p
+ *   rounded_div                  crates/linear_algebra/src/ops.rs:64-80
+ *   ring elements coefficient-wise  cyclotomic_ring/coeff_form.rs:587-605
+ *   gadget_decompose / recompose    balanced_decomposition/mod.rs:163-175, 119-131, 177-189
+ * The value is kept as sign + magnitude (the reference's i128 / BigInt): rem = curr % b has the sign of curr;
+ * |rem| <= b/2 keeps the digit and truncates; otherwise the digit is rem -+ b and curr/b moves one away from zero.
+ * ==================================================================================== */
+typedef struct { uint64_t l[4]; } mag4; /* 256-bit magnitude, little-endian u64 limbs */
+static int mag4_is_zero(const mag4 *m) { return (m->l[0] | m->l[1] | m->l[2] | m->l[3]) == 0; }
+static uint64_t mag4_divrem(mag4 *m, uint64_t b) { /* m /= b, returns m % b */
+    u128 rem = 0;
+    for (int i = 3; i >= 0; i--) {
+        u128 cur = (rem << 64) | m->l[i];
+        m->l[i] = (uint64_t)(cur / b);
+        rem = cur % b;
+    }
+    return (uint64_t)rem;
+}
+static void mag4_inc(mag4 *m) {
+    for (int i = 0; i < 4; i++)
+        if (++m->l[i]) break;
+}
+/* out digit j of coefficient i of element e at out[((e * k + j) * d + i) * limbs]; returns 0, -1 (bad basis), or 1 when some
+ * coefficient needed more than k digits (the reference indexes out[k] there and panics) */
+int sro_decompose_balanced(int field, const uint64_t *in, size_t d, size_t batch, uint64_t b, size_t k, uint64_t *out) {
+    if (b < 2 || (b & 1)) return -1; /* "cannot decompose in basis 0 or 1", "decomposition basis must be even" */
+    pthread_once(&g_once, init_all);
+    const int L = sro_limbs(field);
+    int overflow = 0;
+    for (size_t e = 0; e < batch; e++)
+        for (size_t i = 0; i < d; i++) {
+            mag4 m = {{0, 0, 0, 0}};
+            int neg = 0;
+            if (field == SRO_STARK) {
+                fe4 x, one = {{1, 0, 0, 0}}, half = STARK_P, t;
+                memcpy(&x, in + (e * d + i) * 4, 32);
+                fe4_mul(&x, &x, &one); /* standard form */
+                /* (p-1)/2 */
+                half.l[0] -= 1;
+                for (int q = 0; q < 4; q++) half.l[q] = (half.l[q] >> 1) | (q < 3 ? half.l[q + 1] << 63 : 0);
+                if (!fe4_geq(&half, &x)) { /* x > (p-1)/2 */
+                    fe4_sub_raw(&t, &STARK_P, &x);
+                    x = t;
+                    neg = 1;
+                }
+                memcpy(&m, &x, 32);
+            } else {
+                const fp64_cfg *c = cfg64(field);
+                uint64_t x = fp64_to_std(c, in[e * d + i]);
+                if (x > (c->p - 1) / 2) {
+                    x = c->p - x;
+                    neg = 1;
+                }
+                m.l[0] = x;
+            }
+            for (size_t j = 0; j < k; j++) {
+                uint64_t rem = mag4_divrem(&m, b), dig = rem;
+                int dneg = neg;
+                if (rem > b / 2) {
+                    dig = b - rem;
+                    dneg = !neg;
+                    mag4_inc(&m);
+                }
+                uint64_t *o = out + ((e * k + j) * d + i) * L;
+                if (field == SRO_STARK) {
+                    fe4 v;
+                    fe4_from_u64(&v, dig); /* Montgomery form of dig */
+                    if (dneg && dig) {
+                        fe4 t;
+                        fe4_sub_raw(&t, &STARK_P, &v);
+                        v = t;
+                    }
+                    memcpy(o, &v, 32);
+                } else {
+                    const fp64_cfg *c = cfg64(field);
+                    uint64_t v = fp64_from_std(c, dig);
+                    o[0] = dneg ? fp64_neg(c, v) : v;
+                }
+            }
+            if (!mag4_is_zero(&m)) overflow = 1;
+        }
+    return overflow;
+}
+/* out[e][i] = sum_j b^j in[e * k + j][i]  (Horner from the top digit, mod.rs:119-131) */
+int sro_recompose(int field, const uint64_t *in, size_t d, size_t batch_out, uint64_t b, size_t k, uint64_t *out) {
+    pthread_once(&g_once, init_all);
+    const int L = sro_limbs(field);
+    for (size_t e = 0; e < batch_out; e++)
+        for (size_t i = 0; i < d; i++) {
+            if (field == SRO_STARK) {
+                fe4 acc = {{0, 0, 0, 0}}, bb, v;
+                fe4_from_u64(&bb, b);
+                for (size_t j = k; j-- > 0;) {
+                    fe4_mul(&acc, &acc, &bb);
+                    memcpy(&v, in + ((e * k + j) * d + i) * 4, 32);
+                    fe4_add(&acc, &acc, &v);
+                }
+                memcpy(out + (e * d + i) * 4, &acc, 32);
+            } else {
+                const fp64_cfg *c = cfg64(field);
+                uint64_t acc = 0, bb = fp64_from_std(c, b);
+                for (size_t j = k; j-- > 0;) acc = fp64_add(c, fp64_mul(c, acc, bb), in[((e * k + j) * d + i) * L]);
+                out[e * d + i] = acc;
+            }
+        }
+    return 0;
+}
+
 static unsigned brv(unsigned x, int bits) {
     unsigned r = 0;
     for (int i = 0; i < bits; i++) {

@@ -37,6 +37,12 @@ int sro_pow2_fwd(int field, uint64_t *a, int log2d);                       /* cr
 int sro_pow2_inv(int field, uint64_t *a, int log2d);                       /* icrt_in_place */
 int sro_pow2_pointwise(int field, uint64_t *lhs, const uint64_t *rhs, size_t n_slots); /* ntt_form.rs:177-189 */
 int sro_pow2_reduce(int field, const uint64_t *in, size_t in_len, uint64_t *out, int log2d); /* stark_prime/mod.rs:40-47 */
+/* Balanced gadget decomposition of `batch` ring elements of d coefficients, coefficient-wise, basis b (even, >= 2), k digits:
+ * digit j of element e is ring element e * k + j of out (balanced_decomposition/mod.rs:62-117, 163-175; coeff_form.rs:587-605).
+ * Returns 0, -1 for a bad basis, 1 if a coefficient needs more than k digits (the reference panics). */
+int sro_decompose_balanced(int field, const uint64_t *in, size_t d, size_t batch, uint64_t b, size_t k, uint64_t *out);
+/* gadget_recompose (mod.rs:119-131, 177-189): out[e] = sum_j b^j in[e * k + j] */
+int sro_recompose(int field, const uint64_t *in, size_t d, size_t batch_out, uint64_t b, size_t k, uint64_t *out);
 int sro_schoolbook(int field, const uint64_t *a, const uint64_t *b, size_t d, uint64_t *out_2d_minus_1); /* coeff_form.rs:54-67 */
 int sro_pow2_ring_mul(int field, uint64_t *out, const uint64_t *a, const uint64_t *b, int log2d);
 /* batch of independent elements; nthreads >= 1 pthreads over the batch (mirrors cfg_iter!) */

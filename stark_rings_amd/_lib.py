@@ -39,6 +39,11 @@ SYMBOLS = {
     "sr_matvec_ntt": (_c.c_int, [_c.c_void_p] * 4 + [_c.c_size_t] * 2),
     "sr_spmv_ntt": (_c.c_int, [_c.c_void_p] * 6 + [_c.c_size_t] * 2),
     "sr_matmul_ntt": (_c.c_int, [_c.c_void_p] * 4 + [_c.c_size_t] * 3),
+    "sr_decompose_balanced_batch_dev": (_c.c_int, [_c.c_void_p] * 3 + [_c.c_uint64, _c.c_size_t, _c.c_size_t, _c.c_void_p]),
+    "sr_decompose_overflow_count": (_c.c_int, [_c.c_void_p, _c.POINTER(_c.c_ulonglong), _c.c_void_p]),
+    "sr_recompose_batch_dev": (_c.c_int, [_c.c_void_p] * 3 + [_c.c_uint64, _c.c_size_t, _c.c_size_t, _c.c_void_p]),
+    "sr_decompose_balanced_batch": (_c.c_int, [_c.c_void_p] * 3 + [_c.c_uint64, _c.c_size_t, _c.c_size_t]),
+    "sr_recompose_batch": (_c.c_int, [_c.c_void_p] * 3 + [_c.c_uint64, _c.c_size_t, _c.c_size_t]),
     "sr_ring_mul_batch_dev": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_size_t, _c.c_void_p]),
     "sr_reduce_batch_dev": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_size_t, _c.c_void_p, _c.c_size_t, _c.c_void_p]),
     "sr_fill_uniform_dev": (_c.c_int, [_c.c_void_p, _c.c_uint64, _c.c_uint64, _c.c_size_t, _c.c_void_p, _c.c_void_p]),

@@ -18,6 +18,7 @@
 #include "ntt_goldilocks.hpp"
 #include "ntt_regtile.hpp"
 #include "small_rings.hpp"
+#include "decompose.hpp"
 
 namespace {
 
@@ -509,6 +510,56 @@ bool is_pow2_ring(int ring) { return ring >= SR_RING_GOLDILOCKS_POW2 && ring <= 
         default: return fail(SR_E_INVALID, "not a power-of-two ring");              \
     }
 
+// dispatch over the coefficient field of any ring (the small rings' coefficients are Goldilocks / BabyBear elements)
+#define DISPATCH_FIELD(c, CALL)                                                                          \
+    switch ((c)->ring) {                                                                                 \
+        case SR_RING_GOLDILOCKS_POW2: case SR_RING_GOLDILOCKS_24: { using F = sr::Goldilocks; return CALL; } \
+        case SR_RING_BABYBEAR_POW2: case SR_RING_BABYBEAR_72: { using F = sr::BabyBear; return CALL; }   \
+        case SR_RING_STARK_POW2: { using F = sr::Stark; return CALL; }                                   \
+        default: return fail(SR_E_INVALID, "unknown ring");                                              \
+    }
+
+extern "C++" {
+template <class F>
+int decompose_dev(sr_ctx *c, uint64_t *out, const uint64_t *in, uint64_t b, size_t k, size_t batch, hipStream_t st) {
+    using S = typename F::storage;
+    const size_t n = batch * c->degree;
+    if (n == 0 || k == 0) return SR_OK;
+    size_t blocks = (n + 255) / 256;
+    if (blocks > 1u << 20) blocks = 1u << 20;
+    ProfScope ps(c, st, K_OTHER);
+    hipLaunchKernelGGL((sr::dec::decompose_kernel<F>), dim3((unsigned)blocks), dim3(256), 0, st, reinterpret_cast<S *>(out),
+                       reinterpret_cast<const S *>(in), c->degree, batch, b, sr::dec::exact_log2(b), k, c->d_counter + 2);
+    HIP_TRY(hipGetLastError());
+    return SR_OK;
+}
+template <class F>
+int recompose_dev(sr_ctx *c, uint64_t *out, const uint64_t *in, uint64_t b, size_t k, size_t batch_out, hipStream_t st) {
+    using S = typename F::storage;
+    const size_t n = batch_out * c->degree;
+    if (n == 0) return SR_OK;
+    size_t blocks = (n + 255) / 256;
+    if (blocks > 1u << 20) blocks = 1u << 20;
+    ProfScope ps(c, st, K_OTHER);
+    hipLaunchKernelGGL((sr::dec::recompose_kernel<F>), dim3((unsigned)blocks), dim3(256), 0, st, reinterpret_cast<S *>(out),
+                       reinterpret_cast<const S *>(in), c->degree, batch_out, b, k);
+    HIP_TRY(hipGetLastError());
+    return SR_OK;
+}
+}
+int check_basis(uint64_t b) {
+    if (b < 2) return fail(SR_E_INVALID, "cannot decompose in basis 0 or 1");              // mod.rs:63-66
+    if (b & 1) return fail(SR_E_INVALID, "decomposition basis must be even");              // mod.rs:69
+    if (b > (1ull << 32)) return fail(SR_E_INVALID, "decomposition basis above 2^32 is not supported");
+    return SR_OK;
+}
+int dev_decompose(sr_ctx *c, uint64_t *out, const uint64_t *in, uint64_t b, size_t k, size_t batch, hipStream_t st) {
+    DISPATCH_FIELD(c, (decompose_dev<F>(c, out, in, b, k, batch, st)));
+}
+int dev_recompose(sr_ctx *c, uint64_t *out, const uint64_t *in, uint64_t b, size_t k, size_t batch_out, hipStream_t st) {
+    DISPATCH_FIELD(c, (recompose_dev<F>(c, out, in, b, k, batch_out, st)));
+}
+
 int ensure_stage(sr_ctx *c, int which, size_t bytes) {
     if (c->stage_bytes[which] >= bytes) return SR_OK;
     if (c->stage[which]) HIP_TRY(hipFree(c->stage[which]));
@@ -625,9 +676,10 @@ int sr_ctx_create(int ring, int log2_degree, int device, sr_ctx **out) {
         return code;
     };
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) return bail(fail(SR_E_HIP, "hipStreamCreate failed"));
-    // two words: [0] scratch counter of count_noncanonical, [1] out-of-range column indices seen by spmv (sticky until read)
-    if (hipMalloc(&c->d_counter, 2 * sizeof(unsigned long long)) != hipSuccess) return bail(fail(SR_E_ALLOC, "hipMalloc counter failed"));
-    if (hipMemset(c->d_counter, 0, 2 * sizeof(unsigned long long)) != hipSuccess) return bail(fail(SR_E_HIP, "hipMemset counter failed"));
+    // three words: [0] scratch counter of count_noncanonical, [1] out-of-range column indices seen by spmv, [2] coefficients
+    // that needed more digits than padding_size in a decomposition (both sticky until read)
+    if (hipMalloc(&c->d_counter, 3 * sizeof(unsigned long long)) != hipSuccess) return bail(fail(SR_E_ALLOC, "hipMalloc counter failed"));
+    if (hipMemset(c->d_counter, 0, 3 * sizeof(unsigned long long)) != hipSuccess) return bail(fail(SR_E_HIP, "hipMemset counter failed"));
     if (is_pow2_ring(ring)) {
         c->k = log2_degree;
         c->degree = (size_t)1 << log2_degree;
@@ -774,6 +826,35 @@ int sr_matmul_ntt_dev(sr_ctx *c, uint64_t *y, const uint64_t *a, const uint64_t 
     return dev_matmul(c, y, a, b, n, m, p, (hipStream_t)stream);
 }
 
+int sr_decompose_balanced_batch_dev(sr_ctx *c, uint64_t *out, const uint64_t *in, uint64_t basis, size_t padding_size, size_t batch,
+                                    void *stream) {
+    if (int rc = check(c, out, in)) return rc;
+    if (int rc = check_basis(basis)) return rc;
+    if (out == in) return fail(SR_E_INVALID, "decompose: out must not alias in");
+    std::lock_guard<std::mutex> lk(c->mu);
+    DeviceGuard g(c->device);
+    return dev_decompose(c, out, in, basis, padding_size, batch, (hipStream_t)stream);
+}
+int sr_decompose_overflow_count(sr_ctx *c, unsigned long long *out, void *stream) {
+    if (int rc = check(c, out)) return rc;
+    std::lock_guard<std::mutex> lk(c->mu);
+    DeviceGuard g(c->device);
+    hipStream_t st = (hipStream_t)stream;
+    HIP_TRY(hipMemcpyAsync(out, c->d_counter + 2, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemsetAsync(c->d_counter + 2, 0, sizeof(unsigned long long), st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return SR_OK;
+}
+int sr_recompose_batch_dev(sr_ctx *c, uint64_t *out, const uint64_t *in, uint64_t basis, size_t padding_size, size_t batch_out,
+                           void *stream) {
+    if (int rc = check(c, out, in)) return rc;
+    if (basis > (1ull << 32)) return fail(SR_E_INVALID, "recomposition basis above 2^32 is not supported");
+    if (out == in) return fail(SR_E_INVALID, "recompose: out must not alias in");
+    std::lock_guard<std::mutex> lk(c->mu);
+    DeviceGuard g(c->device);
+    return dev_recompose(c, out, in, basis, padding_size, batch_out, (hipStream_t)stream);
+}
+
 // ---- host-pointer variants of the linear-algebra entry points: temporaries are allocated per call (these are
 // convenience entry points for callers that hold Vec<..> on the host; resident data uses the _dev forms)
 namespace {
@@ -848,6 +929,44 @@ int sr_spmv_ntt(sr_ctx *c, uint64_t *y, const uint64_t *vals, const uint32_t *co
                           (const uint64_t *)dv.p, nrows, ncols, c->stream))
         return rc;
     if (nrows) HIP_TRY(hipMemcpyAsync(y, dy.p, nrows * w, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return SR_OK;
+}
+int sr_decompose_balanced_batch(sr_ctx *c, uint64_t *out, const uint64_t *in, uint64_t basis, size_t padding_size, size_t batch) {
+    if (int rc = check(c, out, in)) return rc;
+    if (int rc = check_basis(basis)) return rc;
+    std::lock_guard<std::mutex> lk(c->mu);
+    DeviceGuard g(c->device);
+    const size_t w = c->degree * c->limbs * 8;
+    if (batch == 0 || padding_size == 0) return SR_OK;
+    DevBuf din, dout;
+    if (int rc = din.alloc(batch * w)) return rc;
+    if (int rc = dout.alloc(batch * padding_size * w)) return rc;
+    HIP_TRY(hipMemcpyAsync(din.p, in, batch * w, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemsetAsync(c->d_counter + 2, 0, sizeof(unsigned long long), c->stream));
+    if (int rc = dev_decompose(c, (uint64_t *)dout.p, (const uint64_t *)din.p, basis, padding_size, batch, c->stream)) return rc;
+    unsigned long long over = 0;
+    HIP_TRY(hipMemcpyAsync(&over, c->d_counter + 2, sizeof over, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(out, dout.p, batch * padding_size * w, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipMemsetAsync(c->d_counter + 2, 0, sizeof(unsigned long long), c->stream));
+    // the reference indexes out[padding_size] and panics (mod.rs:81-91)
+    if (over) return fail(SR_E_INVALID, "decompose: a coefficient needs more than padding_size digits");
+    return SR_OK;
+}
+int sr_recompose_batch(sr_ctx *c, uint64_t *out, const uint64_t *in, uint64_t basis, size_t padding_size, size_t batch_out) {
+    if (int rc = check(c, out, in)) return rc;
+    if (basis > (1ull << 32)) return fail(SR_E_INVALID, "recomposition basis above 2^32 is not supported");
+    std::lock_guard<std::mutex> lk(c->mu);
+    DeviceGuard g(c->device);
+    const size_t w = c->degree * c->limbs * 8;
+    if (batch_out == 0) return SR_OK;
+    DevBuf din, dout;
+    if (int rc = din.alloc(batch_out * padding_size * w)) return rc;
+    if (int rc = dout.alloc(batch_out * w)) return rc;
+    if (padding_size) HIP_TRY(hipMemcpyAsync(din.p, in, batch_out * padding_size * w, hipMemcpyHostToDevice, c->stream));
+    if (int rc = dev_recompose(c, (uint64_t *)dout.p, (const uint64_t *)din.p, basis, padding_size, batch_out, c->stream)) return rc;
+    HIP_TRY(hipMemcpyAsync(out, dout.p, batch_out * w, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return SR_OK;
 }

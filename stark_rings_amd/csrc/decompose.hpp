@@ -1,0 +1,202 @@
+// Balanced (gadget) decomposition and recomposition, coefficient-wise over a batch of ring elements -- SURVEY 8f #2.
+//
+//   decompose_balanced_in_place   crates/ring/src/balanced_decomposition/mod.rs:62-117
+//   signed representative         balanced_decomposition/fq_convertible.rs:21-35 (Fp64), stark_prime/decomposition.rs:41-53 (Fp256)
+//   rounded_div                   crates/linear_algebra/src/ops.rs:64-80
+//   ring elements coefficient-wise   cyclotomic_ring/coeff_form.rs:587-605
+//   gadget_decompose / recompose     balanced_decomposition/mod.rs:163-175, 119-131, 177-189
+//
+// One lane = one coefficient.  The value leaves Montgomery form (x * R^-1 = mul_boundary(x, 1)), becomes sign + magnitude
+// (the reference's i128 / BigInt), and k times: rem = |curr| mod b; |rem| <= b/2 keeps the digit and the truncated quotient,
+// otherwise the digit is -(sign)(b - rem) and the quotient moves one away from zero.  Digits go back to Montgomery form
+// (d * R = mul_boundary(d, R^2)) and are written digit-major: digit j of element e is ring element e * k + j of `out`, so the
+// stores of a wave are contiguous.  Memory-bound: D w bytes in, k D w bytes out per element.
+// Basis: even, 2 <= b <= 2^32 (the reference takes a u128; gadget bases in its tests are 2 .. 2^16).  A power of two is
+// a shift and a mask; any other even basis pays an integer division per digit (per 32-bit limb for Stark).
+#pragma once
+#include <type_traits>
+
+#include "fields.hpp"
+
+namespace sr {
+namespace dec {
+
+// ---- per-field constants: the integer 1 and R^2 mod p (R = 2^kBoundaryBits) as elements -----------------------------------
+template <class F>
+struct Consts;
+template <>
+struct Consts<Goldilocks> {
+    SR_HD static uint64_t one() { return 1; }
+    SR_HD static uint64_t r2() { return 0xFFFFFFFE00000001ull; }  // 2^128 mod p
+    SR_HD static uint64_t from_u64(uint64_t v) { return v; }       // v < p
+};
+template <>
+struct Consts<BabyBear> {
+    SR_HD static uint32_t one() { return 1; }
+    SR_HD static uint32_t r2() { return 663890614u; }  // 2^128 mod p
+    SR_HD static uint32_t from_u64(uint64_t v) { return (uint32_t)v; }
+};
+template <>
+struct Consts<Stark> {
+    SR_HD static U256 one() {
+        U256 e = Stark::zero();
+        e.l[0] = 1;
+        return e;
+    }
+    SR_HD static U256 r2() { return Stark::r2(); }  // 2^512 mod p
+    SR_HD static U256 from_u64(uint64_t v) {
+        U256 e = Stark::zero();
+        e.l[0] = (uint32_t)v;
+        e.l[1] = (uint32_t)(v >> 32);
+        return e;
+    }
+};
+
+// ---- sign + magnitude of the signed representative ------------------------------------------------------------------------
+// Fp64 fields: one u64.  [0, (p-1)/2] stays, ](p-1)/2, p[ -> p - x with the sign set.
+template <class F>
+struct Mag {
+    uint64_t m;
+    bool neg;
+    SR_HD static Mag from_image(typename F::elem img) {
+        const uint64_t x = (uint64_t)F::mul_boundary(img, Consts<F>::one());
+        const uint64_t p = (uint64_t)F::P;
+        Mag r;
+        r.neg = x > (p - 1) / 2;
+        r.m = r.neg ? p - x : x;
+        return r;
+    }
+    SR_HD bool is_zero() const { return m == 0; }
+    // m /= b, returns m mod b
+    SR_HD uint64_t divrem(uint64_t b, int log2b) {
+        uint64_t rem;
+        if (log2b >= 0) {
+            rem = m & (b - 1);
+            m = log2b >= 64 ? 0 : m >> log2b;
+        } else {
+            const uint64_t q = m / b;
+            rem = m - q * b;
+            m = q;
+        }
+        return rem;
+    }
+    SR_HD void inc() { m++; }
+};
+// Stark: eight 32-bit limbs
+template <>
+struct Mag<Stark> {
+    U256 m;
+    bool neg;
+    SR_HD static Mag from_image(const U256 &img) {
+        U256 x = Stark::mul_boundary(img, Consts<Stark>::one());
+        // x > (p-1)/2  <=>  2x > p - 1  <=>  2x >= p (p odd)
+        U256 dbl, t;
+        Stark::add_raw(dbl, x, x);  // < 2^253
+        Mag r;
+        r.neg = Stark::geq_p(dbl);
+        if (r.neg) {
+            Stark::sub_raw(t, Stark::modulus(), x);
+            x = t;
+        }
+        r.m = x;
+        return r;
+    }
+    SR_HD bool is_zero() const {
+        uint32_t o = 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) o |= m.l[i];
+        return o == 0;
+    }
+    SR_HD uint64_t divrem(uint64_t b, int log2b) {
+        uint64_t rem;
+        if (log2b >= 0 && log2b <= 32) {
+            rem = log2b == 32 ? (uint64_t)m.l[0] : (uint64_t)(m.l[0] & (uint32_t)(b - 1));
+            if (log2b == 32) {
+#pragma unroll
+                for (int i = 0; i < 7; i++) m.l[i] = m.l[i + 1];
+                m.l[7] = 0;
+            } else {
+#pragma unroll
+                for (int i = 0; i < 8; i++) {
+                    const uint32_t hi = i < 7 ? m.l[i + 1] : 0u;
+                    m.l[i] = (uint32_t)((((uint64_t)hi << 32) | m.l[i]) >> log2b);
+                }
+            }
+        } else {
+            uint64_t r = 0;  // < b <= 2^32: (r << 32 | limb) fits 64 bits
+#pragma unroll
+            for (int i = 7; i >= 0; i--) {
+                const uint64_t cur = (r << 32) | m.l[i];
+                const uint64_t q = cur / b;
+                m.l[i] = (uint32_t)q;
+                r = cur - q * b;
+            }
+            rem = r;
+        }
+        return rem;
+    }
+    SR_HD void inc() {
+        uint32_t c = 1;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const uint64_t s = (uint64_t)m.l[i] + c;
+            m.l[i] = (uint32_t)s;
+            c = (uint32_t)(s >> 32);
+        }
+    }
+};
+
+SR_HD int exact_log2(uint64_t b) { return (b & (b - 1)) == 0 ? 63 - __builtin_clzll(b) : -1; }
+
+// the Montgomery image of the signed digit (-1)^neg * dig, dig < p
+template <class F>
+SR_HD typename F::elem digit_image(uint64_t dig, bool neg) {
+    typename F::elem v = F::mul_boundary(Consts<F>::from_u64(dig), Consts<F>::r2());
+    return (neg && dig) ? F::sub(F::zero(), v) : v;
+}
+
+// in: batch ring elements of d coefficients; out: batch * k ring elements.  *overflow counts coefficients that needed more
+// than k digits (the reference indexes out[k] and panics).
+template <class F>
+__global__ __launch_bounds__(256) void decompose_kernel(typename F::storage *out, const typename F::storage *in, size_t d,
+                                                        size_t batch, uint64_t b, int log2b, size_t k,
+                                                        unsigned long long *overflow) {
+    const size_t n = batch * d;
+    for (size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x; t < n; t += (size_t)gridDim.x * blockDim.x) {
+        const size_t e = t / d, i = t - e * d;
+        Mag<F> cur = Mag<F>::from_image(F::load(in + t));
+        typename F::storage *o = out + e * k * d + i;
+        for (size_t j = 0; j < k; j++) {
+            const uint64_t rem = cur.divrem(b, log2b);
+            uint64_t dig = rem;
+            bool dneg = cur.neg;
+            if (rem > b / 2) {
+                dig = b - rem;
+                dneg = !cur.neg;
+                cur.inc();
+            }
+            F::store(o + j * d, digit_image<F>(dig, dneg));
+        }
+        if (!cur.is_zero()) atomicAdd(overflow, 1ull);
+    }
+}
+
+// out[e][i] = sum_j b^j in[e * k + j][i]: Horner from the top digit (mod.rs:119-131, 177-189)
+template <class F>
+__global__ __launch_bounds__(256) void recompose_kernel(typename F::storage *out, const typename F::storage *in, size_t d,
+                                                        size_t batch_out, uint64_t b, size_t k) {
+    const size_t n = batch_out * d;
+    // Montgomery image of R::from(b): b <= 2^32 is below p except for BabyBear
+    const uint64_t bred = std::is_same<F, BabyBear>::value ? b % (uint64_t)BabyBear::P : b;
+    const typename F::elem bimg = F::mul_boundary(Consts<F>::from_u64(bred), Consts<F>::r2());
+    for (size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x; t < n; t += (size_t)gridDim.x * blockDim.x) {
+        const size_t e = t / d, i = t - e * d;
+        const typename F::storage *src = in + e * k * d + i;
+        typename F::elem acc = F::zero();
+        for (size_t j = k; j-- > 0;) acc = F::add(F::mul_boundary(acc, bimg), F::load(src + j * d));
+        F::store(out + t, acc);
+    }
+}
+
+}  // namespace dec
+}  // namespace sr

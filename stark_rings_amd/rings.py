@@ -190,6 +190,27 @@ class CyclotomicRing:
                                             _np_ptr(b) if b.size else _np_ptr(z), n, m, p))
         return y[:n * p * w]
 
+    def gadget_decompose(self, a, basis, padding_size):
+        """GadgetDecompose for a Vec of ring elements in coefficient form (balanced_decomposition/mod.rs:163-175): returns
+        len * padding_size elements, digit j of element e at index e * padding_size + j.  RingError where the reference panics
+        (basis 0, 1 or odd; more than padding_size digits needed)."""
+        batch = self._batch_of(a.size)
+        out = np.empty(max(batch * padding_size * self.words_per_elem, 1), dtype=np.uint64)
+        src = a if a.size else np.zeros(1, dtype=np.uint64)
+        self._check(self._lib.sr_decompose_balanced_batch(self._ctx, _np_ptr(out), _np_ptr(src), basis, padding_size, batch))
+        return out[:batch * padding_size * self.words_per_elem]
+
+    def gadget_recompose(self, digits, basis, padding_size):
+        """GadgetRecompose (mod.rs:177-189): len / padding_size elements, each sum_j basis^j * digits[e * padding_size + j]."""
+        n = self._batch_of(digits.size)
+        if padding_size == 0 or n % padding_size:
+            raise RingError("recompose: length is not a multiple of padding_size")
+        batch_out = n // padding_size
+        out = np.empty(max(batch_out * self.words_per_elem, 1), dtype=np.uint64)
+        src = digits if digits.size else np.zeros(1, dtype=np.uint64)
+        self._check(self._lib.sr_recompose_batch(self._ctx, _np_ptr(out), _np_ptr(src), basis, padding_size, batch_out))
+        return out[:batch_out * self.words_per_elem]
+
     def reduce(self, coeffs, in_len_per_elem, batch):
         """CyclotomicConfig::reduce_in_place (ring_config.rs:23): (batch, in_len) -> (batch, D)."""
         if coeffs.size != batch * in_len_per_elem * self.limbs:
@@ -297,6 +318,28 @@ class CyclotomicRing:
             raise RingError("matmul: DifferentLengths")
         self._check(self._lib.sr_matmul_ntt_dev(self._ctx, py, pa, pb, n, m, p, self._stream(stream)))
         return y
+
+    def gadget_decompose_dev(self, out, a, basis, padding_size, stream=None):
+        po, n = self._dev(out)
+        pa, m = self._dev(a)
+        if n != m * padding_size:
+            raise RingError("decompose: out must hold len * padding_size elements")
+        self._check(self._lib.sr_decompose_balanced_batch_dev(self._ctx, po, pa, basis, padding_size, self._batch_of(m),
+                                                             self._stream(stream)))
+        return out
+
+    def decompose_overflow_count(self, stream=None):
+        n = ctypes.c_ulonglong(0)
+        self._check(self._lib.sr_decompose_overflow_count(self._ctx, ctypes.byref(n), self._stream(stream)))
+        return int(n.value)
+
+    def gadget_recompose_dev(self, out, digits, basis, padding_size, stream=None):
+        po, n = self._dev(out)
+        pd, m = self._dev(digits)
+        if m != n * padding_size:
+            raise RingError("recompose: digits must hold len(out) * padding_size elements")
+        self._check(self._lib.sr_recompose_batch_dev(self._ctx, po, pd, basis, padding_size, self._batch_of(n), self._stream(stream)))
+        return out
 
     def mul_dev(self, out, a, b, stream=None):
         """out = a * b; b is clobbered (holds crt(b)) when D exceeds one LDS tile; out may be a."""

@@ -118,6 +118,72 @@ static void small_suite(sr_ring ring, int field, int D, void (*crt)(uint64_t *),
     EXPECT(std::move(na).elementwise_icrt() == RqPolyVec(cfg, a));
 }
 
+// linear algebra over RqNTT: test_matrix_mul_vec / mul_mat (linear_algebra/src/matrix.rs:233-262), sparse mul_vec
+// (sparse_matrix.rs tests), against sums of the oracle's slot products via RqNTTVec arithmetic on single elements
+static void linalg_suite(sr_ring ring, int field, int log2d) {
+    CyclotomicConfig cfg(ring, log2d);
+    const size_t w = cfg.words_per_elem(), d = cfg.dimension();
+    const size_t n = 3, m = 4, p = 2;
+    auto A = uniform(field, 21, n * m * d), B = uniform(field, 22, m * p * d), v = uniform(field, 23, m * d);
+    auto elem = [&](const std::vector<uint64_t> &src, size_t i) { return std::vector<uint64_t>(src.begin() + i * w, src.begin() + (i + 1) * w); };
+    auto dot = [&](const std::vector<std::pair<std::vector<uint64_t>, std::vector<uint64_t>>> &terms) {
+        RqNTTVec acc(cfg, std::vector<uint64_t>(w, 0));
+        for (auto &t : terms) {
+            RqNTTVec x(cfg, t.first);
+            x *= RqNTTVec(cfg, t.second);
+            acc += x;
+        }
+        return acc.words();
+    };
+    MatrixNTT MA(cfg, n, m, A), MB(cfg, m, p, B);
+    RqNTTVec V(cfg, v);
+    auto y = MA.checked_mul_vec(V);
+    EXPECT(y.has_value());
+    for (size_t r = 0; r < n && y; r++) {
+        std::vector<std::pair<std::vector<uint64_t>, std::vector<uint64_t>>> terms;
+        for (size_t c = 0; c < m; c++) terms.push_back({elem(A, r * m + c), elem(v, c)});
+        EXPECT(elem(y->words(), r) == dot(terms));
+    }
+    EXPECT(!MA.checked_mul_vec(RqNTTVec(cfg, uniform(field, 24, (m + 1) * d))).has_value());   // DifferentLengths -> None
+    bool threw = false;
+    try {
+        MA.try_mul_vec(RqNTTVec(cfg, uniform(field, 24, (m - 1) * d)));
+    } catch (const std::length_error &) {
+        threw = true;
+    }
+    EXPECT(threw);
+    auto Y = MA.checked_mul_mat(MB);
+    EXPECT(Y.has_value() && Y->nrows() == n && Y->ncols() == p);
+    for (size_t i = 0; i < n && Y; i++)
+        for (size_t j = 0; j < p; j++) {
+            std::vector<std::pair<std::vector<uint64_t>, std::vector<uint64_t>>> terms;
+            for (size_t t = 0; t < m; t++) terms.push_back({elem(A, i * m + t), elem(B, t * p + j)});
+            EXPECT(elem(Y->words(), i * p + j) == dot(terms));
+        }
+    EXPECT(!MB.checked_mul_mat(MB).has_value());
+    // sparse: row 0 two entries (one column twice), row 1 empty, row 2 one entry
+    std::vector<std::vector<SparseMatrixNTT::Entry>> rows(3);
+    rows[0] = {{elem(A, 0), 1}, {elem(A, 1), 3}, {elem(A, 2), 1}};
+    rows[2] = {{elem(A, 5), 0}};
+    SparseMatrixNTT S(cfg, 3, m, rows);
+    auto sy = S.checked_mul_vec(V);
+    EXPECT(sy.has_value());
+    if (sy) {
+        EXPECT(elem(sy->words(), 0) == dot({{elem(A, 0), elem(v, 1)}, {elem(A, 1), elem(v, 3)}, {elem(A, 2), elem(v, 1)}}));
+        EXPECT(elem(sy->words(), 1) == std::vector<uint64_t>(w, 0));
+        EXPECT(elem(sy->words(), 2) == dot({{elem(A, 5), elem(v, 0)}}));
+    }
+    EXPECT(!S.checked_mul_vec(RqNTTVec(cfg, uniform(field, 25, (m + 2) * d))).has_value());
+    rows[1] = {{elem(A, 3), m}};  // column out of range: the reference panics on v[col]
+    threw = false;
+    try {
+        SparseMatrixNTT(cfg, 3, m, rows).checked_mul_vec(V);
+    } catch (const std::runtime_error &) {
+        threw = true;
+    }
+    EXPECT(threw);
+}
+
 int main() {
     try {
         pow2_suite(SR_RING_GOLDILOCKS_POW2, SRO_GOLDILOCKS, 10, 3);   // BASELINE configs[0]: D = 2^10 (batch 1 is element 0)
@@ -125,6 +191,9 @@ int main() {
         pow2_suite(SR_RING_BABYBEAR_POW2, SRO_BABYBEAR, 8, 5);
         pow2_suite(SR_RING_STARK_POW2, SRO_STARK, 4, 100);            // the reference's stark_prime ring
         pow2_suite(SR_RING_STARK_POW2, SRO_STARK, 8, 3);
+        linalg_suite(SR_RING_GOLDILOCKS_POW2, SRO_GOLDILOCKS, 6);
+        linalg_suite(SR_RING_BABYBEAR_POW2, SRO_BABYBEAR, 5);
+        linalg_suite(SR_RING_STARK_POW2, SRO_STARK, 4);
         small_suite(SR_RING_GOLDILOCKS_24, SRO_GOLDILOCKS, 24, sro_g24_crt, sro_g24_ntt_mul, sro_g24_icrt);
         small_suite(SR_RING_BABYBEAR_72, SRO_BABYBEAR, 72, sro_bb72_crt, sro_bb72_ntt_mul, sro_bb72_icrt);
     } catch (const std::exception &e) {

@@ -11,6 +11,9 @@ Sources:
   goldilocks/ntt.rs  test_crt / test_crt2 / test_icrt / test_icrt_2, ROOTS_OF_UNITY_24, KAPPA, EIGHT_INV, FOUR_INV
   stark_prime/ntt.rs test_crt / test_crt2 / test_icrt / test_icrt_2, ROOTS_OF_UNITY_32, SIXTEEN_INV*
   babybear/ntt.rs    test_babybear_icrt_hardcoded, ROOTS_OF_UNITY_24, KAPPA, EIGHT_INV, FOUR_INV
+  stark_prime/decomposition.rs  test_stark_prime_decomposition (balanced digits of one Fq, basis 2^16)
+  balanced_decomposition/mod.rs test_gadget_decompose / test_gadget_recompose / test_sparse_matrix_gadget_decompose and the
+                                parameters of the property tests (Q, D, BASIS_TEST_RANGE)
 """
 import json
 import os
@@ -185,6 +188,55 @@ def main():
         fr["kats"].append({"name": name, "kind": kind, "lines": [a, b],
                            "coeffs": S(pad(blocks[0], 16)), "residues": S(blocks[1])})
     out["rings"]["frog16"] = fr
+
+    # ---------------- balanced decomposition ("next" row 2) ----------------
+    SIGNED = re.compile(r"(-?)\s*Fq::(?:from\((-?\d+)\)|(zero)\(\))")
+
+    def signed_values(text):
+        vals = []
+        for m in SIGNED.finditer(text):
+            neg, num, zero = m.groups()
+            v = 0 if zero else int(num)
+            vals.append(-v if neg else v)
+        return vals
+
+    dec = {}
+    rel = "stark_prime/decomposition.rs"
+    L = read(os.path.join(MODELS, rel))
+    a, b = fn_span(L, "test_stark_prime_decomposition")
+    text = "\n".join(L[a - 1:b])
+    x = re.search(r'MontFp!\("(\d+)"\)', text).group(1)
+    call = re.search(r"decompose\((.+?),\s*(\d+)\)", text)
+    basis = eval(call.group(1), {"__builtins__": {}})  # "1 << 16"
+    digits = signed_values(text[text.index("vec!["):])
+    dec["stark_prime_fq"] = {"source": rel, "lines": [a, b], "x": x, "basis": basis, "padding": int(call.group(2)),
+                             "digits": [str(v) for v in digits]}
+    rel = "balanced_decomposition/mod.rs"
+    L = read(os.path.join(REF, "crates/ring/src", rel))
+    a, b = fn_span(L, "test_gadget_decompose")
+    text = "\n".join(L[a - 1:b])
+    call = re.search(r"gadget_decompose\((\d+),\s*(\d+)\)", text)
+    halves = text.split("let decomposed")
+    ring_deg = int(re.search(r"\(0\.\.(\d+)\)", text).group(1))
+    dec["goldilocks24_gadget"] = {"source": rel, "lines": [a, b], "degree": ring_deg, "basis": int(call.group(1)),
+                                  "padding": int(call.group(2)),
+                                  "input_coefficient_values": signed_values(halves[0]),       # every coefficient of element e
+                                  "expected_coefficient_values": signed_values(halves[1])}    # ... of output element e * k + j
+    a, b = fn_span(L, "test_sparse_matrix_gadget_decompose")
+    text = "\n".join(L[a - 1:b])
+    halves = text.split("let decomposed")
+    call = re.search(r"gadget_decompose\((\d+),\s*(\d+)\)", text)
+    pair = re.compile(r"Fq::from\((-?\d+)\)\)\.collect::<Vec<Fq>>\(\)\),\s*(\d+),", re.S)
+    dec["goldilocks24_sparse_gadget"] = {"source": rel, "lines": [a, b], "basis": int(call.group(1)), "padding": int(call.group(2)),
+                                         "input_entries": [[int(v), int(c)] for v, c in pair.findall(halves[0])],
+                                         "expected_entries": [[int(v), int(c)] for v, c in pair.findall(halves[1])]}
+    consts = "\n".join(L)
+    dec["property_test_parameters"] = {
+        "source": rel, "D": int(re.search(r"const D: usize = (\d+);", consts).group(1)),
+        "Q": int(re.search(r"const Q: u64 = (\d+);", consts).group(1)),
+        "bases": [int(v) for v in re.search(r"BASIS_TEST_RANGE: \[u128; \d+\] = \[([^\]]+)\]", consts).group(1).split(",")],
+        "scalar_padding": 32, "vector_padding": 16}
+    out["decomposition"] = dec
 
     with open(OUT, "w") as f:
         json.dump(out, f, indent=1)

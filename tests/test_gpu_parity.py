@@ -555,3 +555,89 @@ def test_matmul_ntt_matches_oracle(torch_cuda, name, k, n, m, p_):
     assert np.array_equal(ring.matvec_ntt(a, tv.cpu().numpy().view(np.uint64), n, m), y2.cpu().numpy().view(np.uint64))
     with pytest.raises(RingError, match="DifferentLengths"):
         ring.matmul_ntt(a, b, n, m + 1, p_)
+
+
+# ----------------------------------------------------------------------------- second "next" row: balanced gadget decomposition
+def _signed_std(F, arr, p):
+    return [v - p if v > (p - 1) // 2 else v for v in O.from_mont(F, arr)]
+
+
+def test_decomposition_reference_kats_on_gpu(torch_cuda, kats):
+    """stark_prime/decomposition.rs:72-99 and balanced_decomposition/mod.rs:469-514 through the C ABI."""
+    kat = kats["decomposition"]["stark_prime_fq"]
+    p = P.PRIMES["stark"][0]
+    ring = ring_for("stark", 4)
+    x = [int(kat["x"])] + [0] * 15
+    digits = ring.gadget_decompose(O.to_mont(O.STARK, x), kat["basis"], kat["padding"])
+    got = _signed_std(O.STARK, digits, p)
+    assert [got[j * 16] for j in range(kat["padding"])] == [int(v) for v in kat["digits"]]
+    assert all(got[j * 16 + i] == 0 for j in range(kat["padding"]) for i in range(1, 16))
+    assert O.from_mont(O.STARK, ring.gadget_recompose(digits, kat["basis"], kat["padding"])) == x
+    kat = kats["decomposition"]["goldilocks24_gadget"]
+    p = P.PRIMES["goldilocks"][0]
+    ring = ring_for("goldilocks24", 0)
+    vals = kat["input_coefficient_values"]
+    a = O.to_mont(O.GOLDILOCKS, [v % p for v in vals for _ in range(24)])
+    digits = ring.gadget_decompose(a, kat["basis"], kat["padding"])
+    assert _signed_std(O.GOLDILOCKS, digits, p) == [v for v in kat["expected_coefficient_values"] for _ in range(24)]
+    assert np.array_equal(ring.gadget_recompose(digits, kat["basis"], kat["padding"]), a)   # test_gadget_recompose
+
+
+@pytest.mark.parametrize("name,k", [("goldilocks", 7), ("babybear", 7), ("stark", 4), ("goldilocks24", 0), ("babybear72", 0)])
+@pytest.mark.parametrize("basis", [2, 4, 16, 1 << 16, 10, 1 << 32])
+def test_decomposition_matches_oracle(torch_cuda, name, k, basis):
+    """test_decompose_balanced / _vec / _polyring (mod.rs:409-467) shapes on every ring: digits equal the oracle's,
+    |digit| <= b/2, recompose(decompose(v)) == v; edge coefficients 0, 1, p-1, (p-1)/2, (p-1)/2 + 1."""
+    torch = torch_cuda
+    base = {"goldilocks24": "goldilocks", "babybear72": "babybear"}.get(name, name)
+    F = O.FIELD_ID[base]
+    p = P.PRIMES[base][0]
+    ring = ring_for(name, k)
+    d, w, batch = ring.degree, ring.words_per_elem, 5
+    a = O.fill_uniform(F, 0x77 + basis % 97, 0, batch * d)
+    edge = O.to_mont(F, [0, 1, p - 1, (p - 1) // 2, (p - 1) // 2 + 1, 2, p - 2, basis % p, (basis // 2) % p, (basis // 2 + 1) % p])
+    a[:edge.size] = edge
+    pad = 1
+    while (basis // 2) * (basis ** pad - 1) // (basis - 1) < (p - 1) // 2:
+        pad += 1
+    pad += 1
+    want, over = O.decompose_balanced(F, a, d, batch, basis, pad)
+    assert not over
+    got = ring.gadget_decompose(a, basis, pad)
+    assert np.array_equal(got, want)
+    assert all(abs(v) <= basis // 2 for v in _signed_std(F, got[:2 * pad * w], p))
+    assert np.array_equal(ring.gadget_recompose(got, basis, pad), a)
+    assert np.array_equal(O.recompose(F, got, d, batch, basis, pad), a)
+    # device-resident forms
+    ta = torch.from_numpy(a.view(np.int64)).cuda()
+    tout = torch.empty(batch * pad * w, dtype=torch.int64, device="cuda")
+    ring.gadget_decompose_dev(tout, ta, basis, pad)
+    assert np.array_equal(tout.cpu().numpy().view(np.uint64), want)
+    assert ring.decompose_overflow_count() == 0
+    tback = torch.empty_like(ta)
+    ring.gadget_recompose_dev(tback, tout, basis, pad)
+    assert torch.equal(tback, ta)
+
+
+def test_decomposition_errors(torch_cuda):
+    """panics of the reference as errors: basis 0 / 1 ("cannot decompose in basis 0 or 1"), odd basis ("must be even"),
+    out[i] out of bounds when padding_size digits do not suffice."""
+    torch = torch_cuda
+    from stark_rings_amd import RingError
+
+    ring = ring_for("goldilocks", 7)
+    F, p = O.GOLDILOCKS, P.PRIMES["goldilocks"][0]
+    a = O.fill_uniform(F, 9, 0, 2 * ring.degree)
+    for bad, msg in ((0, "basis 0 or 1"), (1, "basis 0 or 1"), (7, "must be even"), ((1 << 32) + 2, "not supported")):
+        with pytest.raises(RingError, match=msg):
+            ring.gadget_decompose(a, bad, 8)
+    with pytest.raises(RingError, match="more than padding_size"):
+        ring.gadget_decompose(a, 2, 8)
+    ta = torch.from_numpy(a.view(np.int64)).cuda()
+    tout = torch.empty(a.size * 8, dtype=torch.int64, device="cuda")
+    ring.gadget_decompose_dev(tout, ta, 2, 8)
+    n_over = ring.decompose_overflow_count()
+    want_over = sum(1 for v in O.from_mont(F, a) if abs(v - p if v > (p - 1) // 2 else v) >= 2 ** 8)
+    assert n_over == want_over and ring.decompose_overflow_count() == 0
+    with pytest.raises(RingError, match="multiple of padding_size"):
+        ring.gadget_recompose(a, 2, 3)

@@ -190,3 +190,77 @@ def test_fill_uniform_is_in_range_and_reproducible():
         assert len(set(vals)) > 4000
         y = O.fill_uniform(F, 42, 1000 + 17, 100)
         assert np.array_equal(y, x[17 * O.LIMBS[F]:117 * O.LIMBS[F]])
+
+
+# ----------------------------------------------------------------------------- balanced decomposition ("next" row 2)
+def _signed(F, arr, p):
+    return [v - p if v > (p - 1) // 2 else v for v in O.from_mont(F, arr)]
+
+
+def test_decomposition_stark_kat(kats):
+    """stark_prime/decomposition.rs:72-99: the one literal decomposition KAT of the reference."""
+    kat = kats["decomposition"]["stark_prime_fq"]
+    p = P.PRIMES["stark"][0]
+    x, b, k = int(kat["x"]), kat["basis"], kat["padding"]
+    want = [int(v) for v in kat["digits"]]
+    assert P.decompose_balanced(x, p, b, k) == want
+    digits, overflow = O.decompose_balanced(O.STARK, O.to_mont(O.STARK, [x]), 1, 1, b, k)
+    assert not overflow and _signed(O.STARK, digits, p) == want
+    assert O.from_mont(O.STARK, O.recompose(O.STARK, digits, 1, 1, b, k)) == [x]
+
+
+def test_decomposition_gadget_kats(kats):
+    """balanced_decomposition/mod.rs:469-514 (gadget_decompose / recompose of constant-coefficient RqPoly) and :582-625 (the
+    sparse form keeps the non-zero digits of 13 at columns 4, 6, 7)."""
+    kat = kats["decomposition"]["goldilocks24_gadget"]
+    p = P.PRIMES["goldilocks"][0]
+    d, b, k = kat["degree"], kat["basis"], kat["padding"]
+    vals = kat["input_coefficient_values"]
+    a = O.to_mont(O.GOLDILOCKS, [v % p for v in vals for _ in range(d)])
+    digits, overflow = O.decompose_balanced(O.GOLDILOCKS, a, d, len(vals), b, k)
+    assert not overflow
+    got = _signed(O.GOLDILOCKS, digits, p)
+    want = [v for v in kat["expected_coefficient_values"] for _ in range(d)]
+    assert got == want
+    assert np.array_equal(O.recompose(O.GOLDILOCKS, digits, d, len(vals), b, k), a)
+    sp = kats["decomposition"]["goldilocks24_sparse_gadget"]
+    (val, col), = sp["input_entries"]
+    dg = P.decompose_balanced(val, p, sp["basis"], sp["padding"])
+    assert [[v, col * sp["padding"] + i] for i, v in enumerate(dg) if v] == sp["expected_entries"]
+
+
+@pytest.mark.parametrize("name", ["goldilocks", "babybear", "stark"])
+def test_decomposition_properties_as_reference_tests(kats, name):
+    """test_decompose_balanced / _vec (mod.rs:409-448): |digit| <= b/2 and recompose(decompose(v)) == v, for the reference's
+    bases and value range, plus values near +-(p-1)/2 and random ones; C oracle == Python restatement."""
+    prm = kats["decomposition"]["property_test_parameters"]
+    F = O.FIELD_ID[name]
+    p = P.PRIMES[name][0]
+    rng = np.random.default_rng(5)
+    vals = list(range(0, prm["Q"], 257)) + [prm["Q"] - 1, (p - 1) // 2, (p - 1) // 2 + 1, p - 1, p - 2, 1, 0]
+    vals += [int(v) % p for v in rng.integers(0, 2**62, 40)] + [(int(v) ** 4) % p for v in rng.integers(2**40, 2**62, 20)]
+    a = O.to_mont(F, vals)
+    for b in prm["bases"] + [1 << 16, 10, 1 << 32]:
+        k = 1
+        while (b // 2) * (b ** k - 1) // (b - 1) < (p - 1) // 2:     # enough digits for every residue
+            k += 1
+        k += 1
+        digits, overflow = O.decompose_balanced(F, a, len(vals), 1, b, k)
+        assert not overflow
+        got = _signed(F, digits, p)
+        for i, v in enumerate(vals):
+            mine = [got[j * len(vals) + i] for j in range(k)]
+            assert mine == P.decompose_balanced(v, p, b, k), (name, b, v)
+            assert all(abs(dg) <= b // 2 for dg in mine)
+            assert P.recompose(mine, b, p) == v
+        assert np.array_equal(O.recompose(F, digits, len(vals), 1, b, k), a)
+    # too few digits: the reference panics (index out of bounds); the oracle reports overflow
+    _, overflow = O.decompose_balanced(F, O.to_mont(F, [(p - 1) // 2]), 1, 1, 2, 8)
+    assert overflow
+    with pytest.raises(IndexError):
+        P.decompose_balanced((p - 1) // 2, p, 2, 8)
+    for bad in (0, 1, 3):
+        with pytest.raises(ValueError):
+            O.decompose_balanced(F, a, len(vals), 1, bad, 4)
+        with pytest.raises(ValueError):
+            P.decompose_balanced(1, p, bad, 4)
