@@ -345,10 +345,10 @@ int matvec_dev(sr_ctx *c, uint64_t *y, const uint64_t *m, const uint64_t *v, siz
     using S = typename F::storage;
     if (nrows == 0) return SR_OK;
     constexpr int RB = 4;
-    const size_t bx = (c->degree + 255) / 256, by = (nrows + RB - 1) / RB;
-    if (by > 65535) return fail(SR_E_INVALID, "matvec: too many rows for one launch");
+    const size_t blocks = ((c->degree + 255) / 256) * ((nrows + RB - 1) / RB);
+    if (blocks > 0x7FFFFFFFull) return fail(SR_E_INVALID, "matvec: too many rows for one launch");
     ProfScope ps(c, st, K_OTHER);
-    hipLaunchKernelGGL((sr::matvec_kernel<F, RB>), dim3((unsigned)bx, (unsigned)by), dim3(256), 0, st, reinterpret_cast<S *>(y),
+    hipLaunchKernelGGL((sr::matvec_kernel<F, RB>), dim3((unsigned)blocks), dim3(256), 0, st, reinterpret_cast<S *>(y),
                        reinterpret_cast<const S *>(m), reinterpret_cast<const S *>(v), nrows, ncols, c->k);
     HIP_TRY(hipGetLastError());
     return SR_OK;
@@ -358,9 +358,10 @@ int spmv_dev(sr_ctx *c, uint64_t *y, const uint64_t *vals, const uint32_t *cols,
              size_t nrows, size_t ncols, hipStream_t st) {
     using S = typename F::storage;
     if (nrows == 0) return SR_OK;
-    if (nrows > 65535) return fail(SR_E_INVALID, "spmv: too many rows for one launch");
+    const size_t blocks = ((c->degree + 255) / 256) * nrows;
+    if (blocks > 0x7FFFFFFFull) return fail(SR_E_INVALID, "spmv: too many rows for one launch");
     ProfScope ps(c, st, K_OTHER);
-    hipLaunchKernelGGL((sr::spmv_kernel<F>), dim3((unsigned)((c->degree + 255) / 256), (unsigned)nrows), dim3(256), 0, st,
+    hipLaunchKernelGGL((sr::spmv_kernel<F>), dim3((unsigned)blocks), dim3(256), 0, st,
                        reinterpret_cast<S *>(y), reinterpret_cast<const S *>(vals), cols, row_ptr, reinterpret_cast<const S *>(v),
                        ncols, c->k, c->d_counter + 1);
     HIP_TRY(hipGetLastError());
@@ -371,10 +372,10 @@ int matmul_dev(sr_ctx *c, uint64_t *y, const uint64_t *a, const uint64_t *b, siz
     using S = typename F::storage;
     if (n == 0 || p == 0) return SR_OK;
     constexpr int RB = 4, CB = 2;
-    const size_t by = (n + RB - 1) / RB, bz = (p + CB - 1) / CB;
-    if (by > 65535 || bz > 65535) return fail(SR_E_INVALID, "matmul: too many rows or columns for one launch");
+    const size_t blocks = ((c->degree + 255) / 256) * ((n + RB - 1) / RB) * ((p + CB - 1) / CB);
+    if (blocks > 0x7FFFFFFFull) return fail(SR_E_INVALID, "matmul: too many rows or columns for one launch");
     ProfScope ps(c, st, K_OTHER);
-    hipLaunchKernelGGL((sr::matmul_kernel<F, RB, CB>), dim3((unsigned)((c->degree + 255) / 256), (unsigned)by, (unsigned)bz),
+    hipLaunchKernelGGL((sr::matmul_kernel<F, RB, CB>), dim3((unsigned)blocks),
                        dim3(256), 0, st, reinterpret_cast<S *>(y), reinterpret_cast<const S *>(a), reinterpret_cast<const S *>(b),
                        n, m, p, c->k);
     HIP_TRY(hipGetLastError());

@@ -212,8 +212,9 @@ template <class F, int RB>
 __global__ __launch_bounds__(256) void matvec_kernel(typename F::storage *y, const typename F::storage *m,
                                                      const typename F::storage *v, size_t nrows, size_t ncols, int k) {
     const size_t d = (size_t)1 << k;
-    const size_t slot = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
-    const size_t r0 = (size_t)blockIdx.y * RB;
+    const size_t chunks = (d + 255) >> 8;  // flat grid: row-block major, slot chunk minor (no 65535 limit on the rows)
+    const size_t slot = (blockIdx.x % chunks) * (size_t)blockDim.x + threadIdx.x;
+    const size_t r0 = (blockIdx.x / chunks) * RB;
     if (slot >= d) return;
     typename F::elem acc[RB];
 #pragma unroll
@@ -238,8 +239,9 @@ __global__ __launch_bounds__(256) void spmv_kernel(typename F::storage *y, const
                                                    const uint64_t *row_ptr, const typename F::storage *v, size_t ncols, int k,
                                                    unsigned long long *bad) {
     const size_t d = (size_t)1 << k;
-    const size_t slot = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
-    const size_t r = blockIdx.y;
+    const size_t chunks = (d + 255) >> 8;  // flat grid: row major, slot chunk minor
+    const size_t slot = (blockIdx.x % chunks) * (size_t)blockDim.x + threadIdx.x;
+    const size_t r = blockIdx.x / chunks;
     if (slot >= d) return;
     typename F::elem acc = F::zero();
     const uint64_t j1 = row_ptr[r + 1];
@@ -261,8 +263,11 @@ template <class F, int RB, int CB>
 __global__ __launch_bounds__(256) void matmul_kernel(typename F::storage *y, const typename F::storage *a,
                                                      const typename F::storage *b, size_t n, size_t m, size_t p, int k) {
     const size_t d = (size_t)1 << k;
-    const size_t slot = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
-    const size_t r0 = (size_t)blockIdx.y * RB, c0 = (size_t)blockIdx.z * CB;
+    const size_t chunks = (d + 255) >> 8;  // flat grid: (row-block, column-block) major, slot chunk minor
+    const size_t cblocks = (p + CB - 1) / CB;
+    const size_t slot = (blockIdx.x % chunks) * (size_t)blockDim.x + threadIdx.x;
+    const size_t tile = blockIdx.x / chunks;
+    const size_t r0 = (tile / cblocks) * RB, c0 = (tile % cblocks) * CB;
     if (slot >= d) return;
     typename F::elem acc[RB][CB];
 #pragma unroll

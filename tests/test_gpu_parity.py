@@ -641,3 +641,35 @@ def test_decomposition_errors(torch_cuda):
     assert n_over == want_over and ring.decompose_overflow_count() == 0
     with pytest.raises(RingError, match="multiple of padding_size"):
         ring.gadget_recompose(a, 2, 3)
+
+
+def test_linear_algebra_many_rows(torch_cuda):
+    """more rows than a 16-bit grid dimension holds: the launches are flat over (row, slot chunk)"""
+    torch = torch_cuda
+    F, p = O.GOLDILOCKS, P.PRIMES["goldilocks"][0]
+    k, nrows, ncols = 3, 70001, 3
+    ring = ring_for("goldilocks", k)
+    w = ring.words_per_elem
+    m = O.fill_uniform(F, 81, 0, nrows * ncols << k)
+    v = O.fill_uniform(F, 82, 0, ncols << k)
+    tm, tv = torch.from_numpy(m.view(np.int64)).cuda(), torch.from_numpy(v.view(np.int64)).cuda()
+    ty = torch.empty(nrows * w, dtype=torch.int64, device="cuda")
+    ring.matvec_ntt_dev(ty, tm, tv, nrows, ncols)
+    y = ty.cpu().numpy().view(np.uint64)
+    for r in (0, 1, 65535, 65536, nrows - 1):
+        want = _slot_products(F, p, k, w, [(m[(r * ncols + c) * w:(r * ncols + c + 1) * w], v[c * w:(c + 1) * w]) for c in range(ncols)])
+        assert O.from_mont(F, y[r * w:(r + 1) * w]) == want
+    # sparse: one stored entry per row, column r mod ncols, values = the first column of m
+    cols = torch.arange(nrows, dtype=torch.int32, device="cuda") % ncols
+    ptr = torch.arange(nrows + 1, dtype=torch.int64, device="cuda")
+    vals = tm.view(nrows, ncols * w)[:, :w].contiguous().view(-1)
+    ring.spmv_ntt_dev(ty, vals, cols, ptr, tv, nrows, ncols)
+    y = ty.cpu().numpy().view(np.uint64)
+    for r in (0, 65535, 65536, nrows - 1):
+        c = r % ncols
+        assert O.from_mont(F, y[r * w:(r + 1) * w]) == _slot_products(F, p, k, w, [(m[r * ncols * w:(r * ncols + 1) * w], v[c * w:(c + 1) * w])])
+    # mat-mat with 70001 x 3 times 3 x 1 equals the mat-vec
+    y2 = torch.empty(nrows * w, dtype=torch.int64, device="cuda")
+    ring.matmul_ntt_dev(y2, tm, tv, nrows, ncols, 1)
+    ring.matvec_ntt_dev(ty, tm, tv, nrows, ncols)
+    assert torch.equal(y2, ty)
