@@ -14,6 +14,8 @@
 //   BabyBear limb is an 8-byte Fp64 with an always-zero upper half), so the caller's a and b are only read
 //   and a ring product moves 48 instead of 72 bytes per coefficient through HBM.
 #pragma once
+#include <cstdlib>
+
 #include "fields.hpp"
 
 namespace sr {
@@ -248,6 +250,157 @@ __global__ __launch_bounds__(256) void strided_kernel(const typename View<F, VI>
     for (int j = 0; j < R; j++) View<F, VO>::st(dst + off + ((size_t)j << ls), x[j]);
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// D = 2^16 and 2^20: stages 0..7 in ONE column pass (cols256_kernel) instead of two 4-stage passes / instead of leaving
+// twelve stages to the VALU-bound rows kernel.  A workgroup owns 256 legs (stride N2 = D / 256) x 16 consecutive columns:
+// pass A (stages 0..3, twiddles uniform over the grid) on legs rg + 16 jj, one exchange through the padded LDS tile,
+// pass B (stages 4..7, the lane's block is rg') on legs 16 rg' + j.  The pass streams one operand once and has VALU to
+// spare, so the four stages it takes over from the rows kernel are free.  grid.x = npoly * N2 / 16.
+// ------------------------------------------------------------------------------------------------------------------
+template <class F, int DIR, class VI, class VO, int COLS>
+__global__ __launch_bounds__(16 * COLS) void cols256_kernel(const typename View<F, VI>::T *src, typename View<F, VO>::T *dst,
+                                                            Params<F> p) {
+    using E = typename F::elem;
+    // [leg][column] words; COLS = 32 for 4-byte elements so that a leg's segment is a whole 128-byte line on the packed side
+    __shared__ E lds[256 * COLS + 16 * COLS];
+    constexpr int LC = COLS == 32 ? 5 : 4;
+    const int t = threadIdx.x;
+    const int ls = p.k - 8;  // log2 N2
+    const unsigned ci = blockIdx.x & ((1u << (ls - LC)) - 1u);
+    const size_t poly = blockIdx.x >> (ls - LC);
+    const int col = t & (COLS - 1), rg = t >> LC;
+    const size_t off = (poly << p.k) + ci * (unsigned)COLS + (unsigned)col;
+    auto at = [](int leg, int c) { const int pos = leg * COLS + c; return pos + (pos >> 8) * (COLS == 32 ? 0 : 16); };
+    E x[16], w[15];
+    if (DIR == 0) {
+#pragma unroll
+        for (int jj = 0; jj < 16; jj++) x[jj] = View<F, VI>::ld(src + off + ((size_t)(rg + 16 * jj) << ls));
+        load_tw16<F>(w, p.tw, 0, 0u);
+        fwd16<F>(x, w);
+        load_tw16<F>(w, p.tw, 4, (unsigned)rg);  // pass-B twiddles in flight across the exchange
+#pragma unroll
+        for (int h = 0; h < 16; h++) lds[at(16 * h + rg, col)] = x[h];
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 16; j++) x[j] = lds[at(16 * rg + j, col)];  // block rg, leg j
+        fwd16<F>(x, w);
+#pragma unroll
+        for (int j = 0; j < 16; j++) View<F, VO>::st(dst + off + ((size_t)(16 * rg + j) << ls), x[j]);
+    } else {
+#pragma unroll
+        for (int j = 0; j < 16; j++) x[j] = View<F, VI>::ld(src + off + ((size_t)(16 * rg + j) << ls));
+        load_tw16<F>(w, p.itw, 4, (unsigned)rg);
+        inv16<F, false>(x, w, p);
+        load_tw16<F>(w, p.itw, 0, 0u);
+#pragma unroll
+        for (int j = 0; j < 16; j++) lds[at(16 * rg + j, col)] = x[j];
+        __syncthreads();
+#pragma unroll
+        for (int h = 0; h < 16; h++) x[h] = lds[at(16 * h + rg, col)];
+        inv16<F, true>(x, w, p);  // contains global stage 0: the D^-1 constants
+#pragma unroll
+        for (int jj = 0; jj < 16; jj++) View<F, VO>::st(dst + off + ((size_t)(rg + 16 * jj) << ls), x[jj]);
+    }
+}
+
+// D = 2^16 behind cols256: a 4096-coefficient tile is 16 blocks of 256 coefficients that only need stages 8..15:
+// the last two register passes of rows_kernel (Params::c = k - 12 as usual, so the twiddle indices are the same),
+// one LDS exchange per transform.  Lane (rho, i0) starts in block rho of the tile.
+template <class F, int MODE, class VI, class VO>
+__global__ __launch_bounds__(256, 4) void rows256_kernel(const typename View<F, VI>::T *a, const typename View<F, VI>::T *b,
+                                                         typename View<F, VO>::T *out, Params<F> p) {
+    using E = typename F::elem;
+    using In = View<F, VI>;
+    using Out = View<F, VO>;
+    __shared__ E lds[(MODE == 2 ? 2 : 1) * kLds];
+    E *la = lds, *lb = lds + kLds;
+    const int t = threadIdx.x;
+    const size_t base = (size_t)blockIdx.x * kTile;
+    const unsigned tile_blk = blockIdx.x & ((1u << p.c) - 1u);
+    const int i0 = t & 15, base2 = (t >> 4) * 256 + i0;
+    E x[16], y[16], w[15], wn[15];
+    const unsigned blk2 = (tile_blk << 4) + (unsigned)(t >> 4), blk3 = (tile_blk << 8) + (unsigned)t;
+
+    // STAGED = send the tile through LDS so that global accesses are lane-contiguous instead of 64-byte segments (4-byte
+    // elements).  Measured on BabyBear D = 2^16: 11.1 ms against 4.8 ms for the direct form (the extra exchanges and the
+    // registers they hold cost more than the half-line accesses), so it stays off.
+    constexpr bool STAGED = false;
+    if (MODE != 1) {
+        load_tw16<F>(wn, p.tw, p.c + 4, blk2);
+        load_tw16<F>(w, p.tw, p.c + 8, blk3);
+        if (STAGED) {
+#pragma unroll
+            for (int j = 0; j < 16; j++) {
+                la[pad(j * 256 + t)] = In::ld(a + base + j * 256 + t);
+                if (MODE == 2) lb[pad(j * 256 + t)] = In::ld(b + base + j * 256 + t);
+            }
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < 16; j++) {
+                x[j] = la[pad(base2 + j * 16)];
+                if (MODE == 2) y[j] = lb[pad(base2 + j * 16)];
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 16; j++) {
+                x[j] = In::ld(a + base + base2 + j * 16);
+                if (MODE == 2) y[j] = In::ld(b + base + base2 + j * 16);
+            }
+        }
+        fwd16<F>(x, wn);
+        if (MODE == 2) fwd16<F>(y, wn);
+#pragma unroll
+        for (int s = 0; s < 16; s++) {
+            la[pad(base2 + s * 16)] = x[s];
+            if (MODE == 2) lb[pad(base2 + s * 16)] = y[s];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            x[j] = la[17 * t + j];
+            if (MODE == 2) y[j] = lb[17 * t + j];
+        }
+        if (MODE == 2) load_tw16<F>(wn, p.itw, p.c + 8, blk3);
+        fwd16<F>(x, w);
+        if (MODE == 0) {
+#pragma unroll
+            for (int j = 0; j < 16; j++) la[17 * t + j] = x[j];  // own slots
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < 16; j++) Out::st(out + base + j * 256 + t, la[pad(j * 256 + t)]);
+            return;
+        }
+        fwd16<F>(y, w);
+#pragma unroll
+        for (int j = 0; j < 16; j++) x[j] = F::mul_tw(x[j], y[j]);
+    } else {
+#pragma unroll
+        for (int j = 0; j < 16; j++) la[pad(j * 256 + t)] = In::ld(a + base + j * 256 + t);
+        load_tw16<F>(wn, p.itw, p.c + 8, blk3);
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 16; j++) x[j] = la[17 * t + j];
+    }
+    load_tw16<F>(w, p.itw, p.c + 4, blk2);
+    inv16<F, false>(x, wn, p);
+#pragma unroll
+    for (int j = 0; j < 16; j++) la[17 * t + j] = x[j];  // own slots
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < 16; s++) x[s] = la[pad(base2 + s * 16)];
+    inv16<F, false>(x, w, p);
+    if (STAGED) {
+#pragma unroll
+        for (int j = 0; j < 16; j++) la[pad(base2 + j * 16)] = x[j];  // the very slots this lane just read
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 16; j++) Out::st(out + base + j * 256 + t, la[pad(j * 256 + t)]);
+    } else {
+#pragma unroll
+        for (int j = 0; j < 16; j++) Out::st(out + base + base2 + j * 16, x[j]);
+    }
+}
+
 // ---- host-side launchers ---------------------------------------------------------------------------
 inline int plan(int c, int *ms) {  // split c strided stages into register passes of at most 4
     int n = 0;
@@ -292,10 +445,27 @@ inline int launch_strided(const Hooks &hk, int M, const typename View<F, VI>::T 
 #undef SR_RT_STRIDED
     return hipGetLastError() != hipSuccess;
 }
+// 2^16 and 2^20 run stages 0..7 as one cols256 launch (SR_RT_COLS256=0: the 4-stage register passes, kept for A/B tests)
+template <class F>
+inline bool use_cols256(const Params<F> &p) {
+    const char *e = getenv("SR_RT_COLS256");  // read per call: tests flip it between contexts
+    return !(e && atoi(e) == 0) && (p.k == 16 || p.k == 20);
+}
+template <class F, int DIR, class VI, class VO>
+inline int launch_cols256(const Hooks &hk, const typename View<F, VI>::T *src, typename View<F, VO>::T *dst, size_t npoly,
+                          const Params<F> &p, hipStream_t st) {
+    constexpr int COLS = sizeof(typename F::elem) == 4 ? 32 : 16;
+    const size_t blocks = (npoly << (p.k - 8)) / COLS;
+    if (blocks == 0 || blocks > 0x7FFFFFFFull) return 1;
+    Scope sc(hk, DIR == 0 ? 0 : 2, st);
+    hipLaunchKernelGGL((cols256_kernel<F, DIR, VI, VO, COLS>), dim3((unsigned)blocks), dim3(16 * COLS), 0, st, src, dst, p);
+    return hipGetLastError() != hipSuccess;
+}
 // forward strided stages: boundary words at `src` -> packed words at `dst` (c >= 1)
 template <class F>
 inline int strided_fwd(const Hooks &hk, const typename F::storage *src, typename F::elem *dst, size_t npoly,
                        const Params<F> &p, hipStream_t st) {
+    if (use_cols256(p)) return launch_cols256<F, 0, Boundary, Packed>(hk, src, dst, npoly, p, st);
     int ms[8], s_lo = 0;
     const int n = plan(p.c, ms);
     for (int i = 0; i < n; i++) {
@@ -310,6 +480,7 @@ inline int strided_fwd(const Hooks &hk, const typename F::storage *src, typename
 template <class F>
 inline int strided_inv(const Hooks &hk, typename F::elem *src, typename F::storage *dst, size_t npoly, const Params<F> &p,
                        hipStream_t st) {
+    if (use_cols256(p)) return launch_cols256<F, 1, Packed, Boundary>(hk, src, dst, npoly, p, st);
     int ms[8], s_lo = p.c;
     const int n = plan(p.c, ms);
     for (int i = n - 1; i >= 0; i--) {
@@ -326,7 +497,9 @@ inline int launch_rows(const Hooks &hk, const typename View<F, VI>::T *a, const 
     const size_t tiles = npoly << p.c;
     if (tiles == 0 || tiles > 0x7FFFFFFFull) return 1;
     Scope sc(hk, 1, st);
-    if (p.c == 0)
+    if (p.k == 16 && use_cols256(p))  // stages 0..7 are done (or come last) in cols256: only 8..15 here
+        hipLaunchKernelGGL((rows256_kernel<F, MODE, VI, VO>), dim3((unsigned)tiles), dim3(256), 0, st, a, b, out, p);
+    else if (p.c == 0)
         hipLaunchKernelGGL((rows_kernel<F, MODE, VI, VO, true>), dim3((unsigned)tiles), dim3(256), 0, st, a, b, out, p);
     else
         hipLaunchKernelGGL((rows_kernel<F, MODE, VI, VO, false>), dim3((unsigned)tiles), dim3(256), 0, st, a, b, out, p);

@@ -344,6 +344,32 @@ def test_register_tiled_path_matches_oracle_and_generic(torch_cuda, name, k, bat
     generic.close()
 
 
+@pytest.mark.parametrize("k,batch", [(16, 3), (20, 1)])
+def test_babybear_older_plan_equals_cols256_plan(torch_cuda, k, batch):
+    """SR_RT_COLS256=0 selects the 4-stage register column passes + twelve-stage rows these sizes ran before the 8-stage
+    column pass existed: same bytes out."""
+    import os
+
+    from stark_rings_amd import CyclotomicRing
+
+    F = O.BABYBEAR
+    a = edge_and_random(F, k, batch, 0x1E0 + k)
+    b = O.fill_uniform(F, 0x1F0 + k, 0, batch << k)
+    ring = ring_for("babybear", k)
+    fa = ring.elementwise_crt(a.copy())
+    want = O.pow2_ring_mul(F, a, b, k, batch, 4)
+    assert np.array_equal(ring.mul(a, b), want)
+    os.environ["SR_RT_COLS256"] = "0"
+    try:
+        older = CyclotomicRing("babybear", k, device=0)
+        assert np.array_equal(older.elementwise_crt(a.copy()), fa)
+        assert np.array_equal(older.elementwise_icrt(fa.copy()), a)
+        assert np.array_equal(older.mul(a, b), want)
+        older.close()
+    finally:
+        del os.environ["SR_RT_COLS256"]
+
+
 # ----------------------------------------------------------------------------- maximum sizes and BASELINE full sizes
 @pytest.mark.parametrize("name,k", [("goldilocks", 22), ("goldilocks", 24), ("babybear", 24), ("stark", 18)])
 def test_maximum_degrees_single_element(torch_cuda, name, k):
