@@ -12,8 +12,9 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 GOLDILOCKS, BABYBEAR, STARK = 0, 1, 2
-FIELD_ID = {"goldilocks": GOLDILOCKS, "babybear": BABYBEAR, "stark": STARK}
-LIMBS = {GOLDILOCKS: 1, BABYBEAR: 1, STARK: 4}
+FROG = 3
+FIELD_ID = {"goldilocks": GOLDILOCKS, "babybear": BABYBEAR, "stark": STARK, "frog": FROG}
+LIMBS = {GOLDILOCKS: 1, BABYBEAR: 1, STARK: 4, FROG: 1}
 
 _lib = None
 _u64p = ctypes.POINTER(ctypes.c_uint64)
@@ -61,6 +62,12 @@ def lib():
             "sro_bb72_dehomogenize": (None, [_u64p]),
             "sro_bb72_ntt_mul": (None, [_u64p, _u64p]),
             "sro_bb72_reduce": (None, [_u64p, sz, _u64p]),
+            "sro_frog16_crt": (None, [_u64p]),
+            "sro_frog16_icrt": (None, [_u64p]),
+            "sro_frog16_homogenize": (None, [_u64p]),
+            "sro_frog16_dehomogenize": (None, [_u64p]),
+            "sro_frog16_ntt_mul": (None, [_u64p, _u64p]),
+            "sro_frog16_reduce": (None, [_u64p, sz, _u64p]),
             "sro_fill_uniform": (None, [i, u64, u64, sz, _u64p]),
         }
         for name, (res, args) in sigs.items():
@@ -177,7 +184,7 @@ def small(fn_name, a, b=None):
     """Call a small-ring in-place function on a copy (batched over leading dim)."""
     a = np.array(a, dtype=np.uint64, copy=True)
     fn = getattr(lib(), fn_name)
-    width = 24 if "g24" in fn_name else 72
+    width = 24 if "g24" in fn_name else (16 if "frog16" in fn_name else 72)
     flat = a.reshape(-1, width)
     if b is not None:
         bf = np.ascontiguousarray(b, dtype=np.uint64).reshape(-1, width)

@@ -20,7 +20,10 @@ GOLDILOCKS_P = 2**64 - 2**32 + 1            # models/goldilocks/mod.rs:20-24, ge
 BABYBEAR_P = 2013265921                      # models/babybear/mod.rs:21-25, generator 31
 STARK_P = 2**251 + 17 * 2**192 + 1           # models/stark_prime/mod.rs:20-24, generator 3
 
+FROG_P = 15912092521325583641                # models/frog_ring/mod.rs:19-25, generator 3 ("next" row 4)
+
 PRIMES = {
+    "frog": (FROG_P, 3, 1),
     "goldilocks": (GOLDILOCKS_P, 7, 1),      # (p, generator, u64 limbs N)
     "babybear": (BABYBEAR_P, 31, 1),         # stored as Fp64 (N=1, R=2^64): babybear/mod.rs:25
     "stark": (STARK_P, 3, 4),
@@ -441,3 +444,109 @@ def recompose(digits, b, p):
     for d in reversed(digits):
         acc = (acc * b + d) % p
     return acc
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# frog ring Fq[X]/(X^16 + 1) -> 4 x Fq4 -- SURVEY 8f #4; restatement of models/frog_ring/ntt.rs:108-267 and mod.rs:36-60
+def roots8():
+    """ROOTS_OF_UNITY_8[k] = w^k, w = 3^((p-1)/8) (frog_ring/ntt.rs:15-24; checked against the literals in the tests)"""
+    w = pow(3, (FROG_P - 1) // 8, FROG_P)
+    return [pow(w, k, FROG_P) for k in range(8)]
+
+
+# (source index, root index) per output index; root -1 = copy, -2 = negate.  frog_ring/ntt.rs:215-291
+_FROG_HOMO = [
+    [(0, -1), (2, -1), (1, -1), (3, -1)],          # nonresidue_to_nonresidue: swap(2, 1)
+    [(0, -1), (2, 2), (1, 1), (3, 3)],             # nonresidue_to_5_to_nonresidue
+    [(0, -1), (2, 1), (3, 6), (1, -2)],            # nonresidue_to_3_to_nonresidue
+    [(0, -1), (2, 3), (3, 5), (1, 1)],             # nonresidue_to_7_to_nonresidue
+]
+_FROG_DEHOMO = [
+    [(0, -1), (2, -1), (1, -1), (3, -1)],
+    [(0, -1), (2, 7), (1, 6), (3, 5)],             # nonresidue_to_nonresidue_to_5
+    [(0, -1), (3, -2), (1, 7), (2, 2)],            # nonresidue_to_nonresidue_to_3
+    [(0, -1), (3, 7), (1, 5), (2, 3)],             # nonresidue_to_nonresidue_to_7
+]
+
+
+def _frog_maps(c, maps):
+    p, R = FROG_P, roots8()
+    out = list(c)
+    for blk in range(4):
+        seg = c[4 * blk:4 * blk + 4]
+        for i, (src, r) in enumerate(maps[blk]):
+            v = seg[src]
+            out[4 * blk + i] = v if r == -1 else ((-v) % p if r == -2 else v * R[r] % p)
+    return out
+
+
+def frog16_homogenize(c):
+    return _frog_maps(c, _FROG_HOMO)
+
+
+def frog16_dehomogenize(c):
+    return _frog_maps(c, _FROG_DEHOMO)
+
+
+def frog16_crt(a):
+    """serial_frog_crt_in_place (ntt.rs:114-151): two radix-2 stages with ROOTS[2], then ROOTS[1] / ROOTS[3]; homogenize."""
+    p, R = FROG_P, roots8()
+    a = list(a)
+    assert len(a) == 16
+    for i in range(8):
+        x, z = a[i], R[2] * a[8 + i] % p
+        a[i], a[8 + i] = (x + z) % p, (x - z) % p
+    for i in range(4):
+        x, z = a[i], R[1] * a[4 + i] % p
+        a[i], a[4 + i] = (x + z) % p, (x - z) % p
+        x, z = a[8 + i], R[3] * a[12 + i] % p
+        a[8 + i], a[12 + i] = (x + z) % p, (x - z) % p
+    return frog16_homogenize(a)
+
+
+def frog16_icrt(a):
+    """serial_frog_icrt_in_place (ntt.rs:163-200)"""
+    p, R = FROG_P, roots8()
+    inv4 = pow(4, -1, p)
+    a = frog16_dehomogenize(list(a))
+    for i in range(4):
+        x, y = a[i], a[4 + i]
+        a[i], a[4 + i] = (x + y) % p, R[7] * (x - y) % p
+        x, y = a[8 + i], a[12 + i]
+        a[8 + i], a[12 + i] = (x + y) % p, R[5] * (x - y) % p
+    for i in range(8):
+        x, y = a[i], a[8 + i]
+        a[i], a[8 + i] = inv4 * (x + y) % p, inv4 * (R[6] * (x - y) % p) % p
+    return a
+
+
+def frog16_reduce(c):
+    """reduce_in_place (frog_ring/mod.rs:72-79): lo -= hi, missing coefficients are zero"""
+    p = FROG_P
+    get = lambda i: c[i] if i < len(c) else 0
+    return [(get(i) - get(16 + i)) % p for i in range(16)]
+
+
+def fq4_mul(x, y):
+    """Fq4 = Fq2[v]/(v^2 - u), Fq2 = Fq[u]/(u^2 - NONRESIDUE), NONRESIDUE = ROOTS[1] (frog_ring/mod.rs:36-60);
+    memory (c0.c0, c0.c1, c1.c0, c1.c1)"""
+    p, nr = FROG_P, roots8()[1]
+
+    def m2(a, b):
+        return [(a[0] * b[0] + nr * a[1] * b[1]) % p, (a[0] * b[1] + a[1] * b[0]) % p]
+
+    def mul_u(a):
+        return [nr * a[1] % p, a[0]]
+
+    a0, a1, b0, b1 = x[0:2], x[2:4], y[0:2], y[2:4]
+    t = mul_u(m2(a1, b1))
+    c0 = [(u + v) % p for u, v in zip(m2(a0, b0), t)]
+    c1 = [(u + v) % p for u, v in zip(m2(a0, b1), m2(a1, b0))]
+    return c0 + c1
+
+
+def frog16_ntt_mul(x, y):
+    out = []
+    for s_ in range(4):
+        out += fq4_mul(x[4 * s_:4 * s_ + 4], y[4 * s_:4 * s_ + 4])
+    return out

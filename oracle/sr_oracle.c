@@ -63,7 +63,7 @@ static uint64_t fp64_pow(const fp64_cfg *c, uint64_t base, uint64_t e) {
 }
 static uint64_t fp64_inv(const fp64_cfg *c, uint64_t a) { return fp64_pow(c, a, c->p - 2); }
 
-static fp64_cfg g_cfg64[2];
+static fp64_cfg g_cfg64[4]; /* indexed by field id; [SRO_STARK] unused */
 static int g_cfg64_ready;
 
 static void fp64_init_one(fp64_cfg *c, uint64_t p, uint64_t gen) {
@@ -78,6 +78,7 @@ static void stark_init(void);
 static void init_all(void) {
     fp64_init_one(&g_cfg64[SRO_GOLDILOCKS], 0xFFFFFFFF00000001ULL, 7);
     fp64_init_one(&g_cfg64[SRO_BABYBEAR], 2013265921ULL, 31);
+    fp64_init_one(&g_cfg64[SRO_FROG], 15912092521325583641ULL, 3); /* frog_ring/mod.rs:19-25 */
     stark_init();
     g_cfg64_ready = 1;
 }
@@ -893,6 +894,109 @@ void sro_bb72_ntt_mul(uint64_t *lhs, const uint64_t *rhs) {
 }
 
 /* ======================================================================================
+ * frog ring Fq[X]/(X^16 + 1) -> 4 x Fq4: frog_ring/ntt.rs:108-267, mod.rs:36-60, 72-79
+ * ==================================================================================== */
+static uint64_t FROG_R[8], FROG_INV4; /* ROOTS_OF_UNITY_8, FOUR_INV in Montgomery form (ntt.rs:15-27) */
+static pthread_once_t g_frog_once = PTHREAD_ONCE_INIT;
+static void frog_init(void) {
+    const fp64_cfg *c = cfg64(SRO_FROG);
+    uint64_t w = fp64_pow(c, fp64_from_std(c, 3), (c->p - 1) / 8);
+    FROG_R[0] = c->r1;
+    for (int k = 1; k < 8; k++) FROG_R[k] = fp64_mul(c, FROG_R[k - 1], w);
+    FROG_INV4 = fp64_inv(c, fp64_from_std(c, 4));
+}
+typedef struct { signed char src[4], root[4]; } frog_map; /* root -1 copy, -2 negate */
+static const frog_map FROG_HOMO[4] = {   /* ntt.rs:206-211, 227-291 */
+    {{0, 2, 1, 3}, {-1, -1, -1, -1}}, {{0, 2, 1, 3}, {-1, 2, 1, 3}}, {{0, 2, 3, 1}, {-1, 1, 6, -2}}, {{0, 2, 3, 1}, {-1, 3, 5, 1}}};
+static const frog_map FROG_DEHOMO[4] = { /* ntt.rs:215-220 */
+    {{0, 2, 1, 3}, {-1, -1, -1, -1}}, {{0, 2, 1, 3}, {-1, 7, 6, 5}}, {{0, 3, 1, 2}, {-1, -2, 7, 2}}, {{0, 3, 1, 2}, {-1, 7, 5, 3}}};
+static void frog_maps(uint64_t *a, const frog_map *maps) {
+    const fp64_cfg *c = cfg64(SRO_FROG);
+    pthread_once(&g_frog_once, frog_init);
+    for (int b = 0; b < 4; b++) {
+        uint64_t seg[4];
+        memcpy(seg, a + 4 * b, 32);
+        for (int i = 0; i < 4; i++) {
+            uint64_t v = seg[maps[b].src[i]];
+            int r = maps[b].root[i];
+            a[4 * b + i] = r == -1 ? v : (r == -2 ? fp64_neg(c, v) : fp64_mul(c, v, FROG_R[r]));
+        }
+    }
+}
+void sro_frog16_homogenize(uint64_t *a) { frog_maps(a, FROG_HOMO); }
+void sro_frog16_dehomogenize(uint64_t *a) { frog_maps(a, FROG_DEHOMO); }
+void sro_frog16_crt(uint64_t *a) { /* ntt.rs:114-151 */
+    const fp64_cfg *c = cfg64(SRO_FROG);
+    pthread_once(&g_frog_once, frog_init);
+    for (int i = 0; i < 8; i++) {
+        uint64_t x = a[i], z = fp64_mul(c, FROG_R[2], a[8 + i]);
+        a[i] = fp64_add(c, x, z);
+        a[8 + i] = fp64_sub(c, x, z);
+    }
+    for (int i = 0; i < 4; i++) {
+        uint64_t x = a[i], z = fp64_mul(c, FROG_R[1], a[4 + i]);
+        a[i] = fp64_add(c, x, z);
+        a[4 + i] = fp64_sub(c, x, z);
+        x = a[8 + i];
+        z = fp64_mul(c, FROG_R[3], a[12 + i]);
+        a[8 + i] = fp64_add(c, x, z);
+        a[12 + i] = fp64_sub(c, x, z);
+    }
+    sro_frog16_homogenize(a);
+}
+void sro_frog16_icrt(uint64_t *a) { /* ntt.rs:163-200 */
+    const fp64_cfg *c = cfg64(SRO_FROG);
+    pthread_once(&g_frog_once, frog_init);
+    sro_frog16_dehomogenize(a);
+    for (int i = 0; i < 4; i++) {
+        uint64_t x = a[i], y = a[4 + i];
+        a[i] = fp64_add(c, x, y);
+        a[4 + i] = fp64_mul(c, FROG_R[7], fp64_sub(c, x, y));
+        x = a[8 + i];
+        y = a[12 + i];
+        a[8 + i] = fp64_add(c, x, y);
+        a[12 + i] = fp64_mul(c, FROG_R[5], fp64_sub(c, x, y));
+    }
+    for (int i = 0; i < 8; i++) {
+        uint64_t x = a[i], y = a[8 + i];
+        a[i] = fp64_mul(c, FROG_INV4, fp64_add(c, x, y));
+        a[8 + i] = fp64_mul(c, FROG_INV4, fp64_mul(c, FROG_R[6], fp64_sub(c, x, y)));
+    }
+}
+void sro_frog16_reduce(const uint64_t *in, size_t n, uint64_t *out) { /* mod.rs:72-79 */
+    const fp64_cfg *c = cfg64(SRO_FROG);
+    for (size_t i = 0; i < 16; i++) {
+        uint64_t lo = i < n ? in[i] : 0, hi = 16 + i < n ? in[16 + i] : 0;
+        out[i] = fp64_sub(c, lo, hi);
+    }
+}
+/* Fq4 = Fq2[v]/(v^2 - u), Fq2 = Fq[u]/(u^2 - NONRESIDUE), NONRESIDUE = ROOTS[1]; memory (c0.c0, c0.c1, c1.c0, c1.c1) */
+static void frog_fq2_mul(const fp64_cfg *c, uint64_t *r, const uint64_t *a, const uint64_t *b) {
+    uint64_t r0 = fp64_add(c, fp64_mul(c, a[0], b[0]), fp64_mul(c, FROG_R[1], fp64_mul(c, a[1], b[1])));
+    uint64_t r1 = fp64_add(c, fp64_mul(c, a[0], b[1]), fp64_mul(c, a[1], b[0]));
+    r[0] = r0;
+    r[1] = r1;
+}
+void sro_frog16_ntt_mul(uint64_t *lhs, const uint64_t *rhs) {
+    const fp64_cfg *c = cfg64(SRO_FROG);
+    pthread_once(&g_frog_once, frog_init);
+    for (int s = 0; s < 4; s++) {
+        uint64_t *x = lhs + 4 * s;
+        const uint64_t *y = rhs + 4 * s;
+        uint64_t p00[2], p11[2], p01[2], p10[2];
+        frog_fq2_mul(c, p00, x, y);
+        frog_fq2_mul(c, p11, x + 2, y + 2);
+        frog_fq2_mul(c, p01, x, y + 2);
+        frog_fq2_mul(c, p10, x + 2, y);
+        /* c0 = a0 b0 + u a1 b1 with u (t0 + t1 u) = NR t1 + t0 u;  c1 = a0 b1 + a1 b0 */
+        x[0] = fp64_add(c, p00[0], fp64_mul(c, FROG_R[1], p11[1]));
+        x[1] = fp64_add(c, p00[1], p11[0]);
+        x[2] = fp64_add(c, p01[0], p10[0]);
+        x[3] = fp64_add(c, p01[1], p10[1]);
+    }
+}
+
+/* ======================================================================================
  * Synthetic inputs (shared definition with the HIP library's generator; see sr_oracle.h)
  * ==================================================================================== */
 static inline uint64_t mix64(uint64_t z) {
@@ -917,7 +1021,7 @@ void sro_fill_uniform(int field, uint64_t seed, uint64_t first, size_t n, uint64
             }
             memcpy(out + 4 * i, &v, 32);
         } else {
-            uint64_t p = field == SRO_GOLDILOCKS ? 0xFFFFFFFF00000001ULL : 2013265921ULL;
+            uint64_t p = field == SRO_GOLDILOCKS ? 0xFFFFFFFF00000001ULL : (field == SRO_FROG ? 15912092521325583641ULL : 2013265921ULL);
             uint64_t v = 0;
             for (unsigned r = 0; r < 64; r++) {
                 v = prng_word(seed, idx, 0, r);

@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-enum { SRO_GOLDILOCKS = 0, SRO_BABYBEAR = 1, SRO_STARK = 2 };
+enum { SRO_GOLDILOCKS = 0, SRO_BABYBEAR = 1, SRO_STARK = 2, SRO_FROG = 3 /* frog_ring/mod.rs:19-25, only the frog16 and element-wise entry points */ };
 
 /* limbs per field element (1, 1, 4) */
 int sro_limbs(int field);
@@ -65,6 +65,14 @@ void sro_bb72_homogenize(uint64_t *a);    /* babybear/ntt.rs:324-333 */
 void sro_bb72_dehomogenize(uint64_t *a);  /* babybear/ntt.rs:337-346 */
 void sro_bb72_ntt_mul(uint64_t *lhs, const uint64_t *rhs);  /* 8 Fq9 products */
 void sro_bb72_reduce(const uint64_t *in, size_t in_len, uint64_t *out72); /* babybear/mod.rs:87-110 */
+
+/* frog ring Fq[X]/(X^16+1) -> 4 x Fq4 ("next" row 4): frog_ring/ntt.rs, in place on 16 Montgomery-form words */
+void sro_frog16_crt(uint64_t *a);            /* ntt.rs:114-151 */
+void sro_frog16_icrt(uint64_t *a);           /* ntt.rs:163-200 */
+void sro_frog16_homogenize(uint64_t *a);     /* ntt.rs:206-211 */
+void sro_frog16_dehomogenize(uint64_t *a);   /* ntt.rs:215-220 */
+void sro_frog16_ntt_mul(uint64_t *lhs, const uint64_t *rhs);  /* 4 Fq4 products, mod.rs:36-60 */
+void sro_frog16_reduce(const uint64_t *in, size_t in_len, uint64_t *out16); /* mod.rs:72-79 */
 
 /* ---- synthetic inputs: counter-based PRNG shared by tests, bench and the HIP library
  *      (SplitMix64 keyed by (seed, flat coefficient index, limb, retry); rejection >= p).

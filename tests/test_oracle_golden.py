@@ -264,3 +264,59 @@ def test_decomposition_properties_as_reference_tests(kats, name):
             O.decompose_balanced(F, a, len(vals), 1, bad, 4)
         with pytest.raises(ValueError):
             P.decompose_balanced(1, p, bad, 4)
+
+
+# ----------------------------------------------------------------------------- frog ring ("next" row 4)
+def test_frog16_reference_kats(kats):
+    """frog_ring/ntt.rs:387-563: test_crt / test_crt2 (crt then dehomogenize) and test_icrt / test_icrt_2 (homogenize then
+    icrt), ROOTS_OF_UNITY_8; Python restatement and C oracle."""
+    fr = kats["frog16"]
+    p = P.FROG_P
+    assert int(fr["modulus"]) == p
+    assert [str(v) for v in P.roots8()] == fr["roots_of_unity_8"]["values"]
+    for k in fr["kats"]:
+        c, r = I(k["coeffs"]), I(k["residues"])
+        if k["kind"] == "crt_then_dehomogenize":
+            assert P.frog16_dehomogenize(P.frog16_crt(c)) == r
+            got = O.small("sro_frog16_dehomogenize", O.small("sro_frog16_crt", O.to_mont(O.FROG, c)))
+            assert O.from_mont(O.FROG, got) == r
+        else:
+            assert P.frog16_icrt(P.frog16_homogenize(r)) == c
+            got = O.small("sro_frog16_icrt", O.small("sro_frog16_homogenize", O.to_mont(O.FROG, r)))
+            assert O.from_mont(O.FROG, got) == c
+
+
+def test_frog16_identities_c_vs_python():
+    """test_mul_crt, test_crt_one, test_reduce (frog_ring/mod.rs:143-219) as identities; C oracle == Python restatement on
+    random elements (Fq4 slot products included)."""
+    import random
+
+    rng = random.Random(11)
+    p = P.FROG_P
+    assert P.frog16_crt([1] + [0] * 15) == [1, 0, 0, 0] * 4
+    for _ in range(5):
+        a = [rng.randrange(p) for _ in range(16)]
+        b = [rng.randrange(p) for _ in range(16)]
+        ma, mb = O.to_mont(O.FROG, a), O.to_mont(O.FROG, b)
+        fa, fb = O.small("sro_frog16_crt", ma), O.small("sro_frog16_crt", mb)
+        assert O.from_mont(O.FROG, fa) == P.frog16_crt(a)
+        assert np.array_equal(O.small("sro_frog16_icrt", fa), ma)
+        prod = O.small("sro_frog16_ntt_mul", fa, fb)
+        assert O.from_mont(O.FROG, prod) == P.frog16_ntt_mul(P.frog16_crt(a), P.frog16_crt(b))
+        sb = [0] * 31
+        for i in range(16):
+            for j in range(16):
+                sb[i + j] = (sb[i + j] + a[i] * b[j]) % p
+        want = P.frog16_reduce(sb)
+        assert O.from_mont(O.FROG, O.small("sro_frog16_icrt", prod)) == want
+        out = np.zeros(16, dtype=np.uint64)
+        msb = O.to_mont(O.FROG, sb)
+        O.lib().sro_frog16_reduce(O.ptr(msb), 31, O.ptr(out))
+        assert O.from_mont(O.FROG, out) == want
+    # balanced decomposition works over the frog prime too (test_implements_decompose, mod.rs:146-153)
+    vals = [0, 1, p - 1, (p - 1) // 2, (p - 1) // 2 + 1] + [rng.randrange(p) for _ in range(20)]
+    digits, over = O.decompose_balanced(O.FROG, O.to_mont(O.FROG, vals), len(vals), 1, 16, 18)
+    assert not over
+    sg = [v - p if v > (p - 1) // 2 else v for v in O.from_mont(O.FROG, digits)]
+    for i, v in enumerate(vals):
+        assert [sg[j * len(vals) + i] for j in range(18)] == P.decompose_balanced(v, p, 16, 18)
