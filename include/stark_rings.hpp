@@ -57,7 +57,7 @@ public:
     int limbs() const { return limbs_; }                    // N
     size_t words_per_elem() const { return degree_ * (size_t)limbs_; }
     int crt_field_extension_degree() const {
-        return ring_ == SR_RING_GOLDILOCKS_24 ? 3 : (ring_ == SR_RING_BABYBEAR_72 ? 9 : 1);
+        return ring_ == SR_RING_GOLDILOCKS_24 ? 3 : (ring_ == SR_RING_BABYBEAR_72 ? 9 : (ring_ == SR_RING_FROG_16 ? 4 : 1));
     }
     sr_ctx *raw() const { return ctx_.get(); }
 

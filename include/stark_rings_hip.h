@@ -48,7 +48,9 @@ enum sr_ring {
     SR_RING_STARK_POW2 = 2,
     /* reference-native partially-splitting rings (log2_degree ignored) */
     SR_RING_GOLDILOCKS_24 = 3, /* X^24-X^12+1, 8 x Fq3: GoldilocksRingConfig, goldilocks/mod.rs:69-119 */
-    SR_RING_BABYBEAR_72 = 4    /* X^72-X^36+1, 8 x Fq9: BabyBearRingConfig,  babybear/mod.rs:81-131 */
+    SR_RING_BABYBEAR_72 = 4,   /* X^72-X^36+1, 8 x Fq9: BabyBearRingConfig,  babybear/mod.rs:81-131 */
+    SR_RING_FROG_16 = 5        /* X^16+1 over p = 15912092521325583641, 4 x Fq4: FrogRingConfig, frog_ring/mod.rs:62-107
+                                  ("next" row 4; crt/icrt frog_ring/ntt.rs:114-200, one u64 Montgomery limb per coefficient) */
 };
 
 enum sr_status {

@@ -19,6 +19,7 @@
 #include "ntt_regtile.hpp"
 #include "small_rings.hpp"
 #include "decompose.hpp"
+#include "frog_ring.hpp"
 
 namespace {
 
@@ -74,6 +75,7 @@ struct sr_ctx {
     std::mutex mu;
     Prof prof;
     sr::SmallRingConsts small{};
+    sr::FrogConsts frog{};
     sr::GoldilocksFastTables gl_fast{};
 };
 
@@ -517,6 +519,7 @@ bool is_pow2_ring(int ring) { return ring >= SR_RING_GOLDILOCKS_POW2 && ring <= 
         case SR_RING_GOLDILOCKS_POW2: case SR_RING_GOLDILOCKS_24: { using F = sr::Goldilocks; return CALL; } \
         case SR_RING_BABYBEAR_POW2: case SR_RING_BABYBEAR_72: { using F = sr::BabyBear; return CALL; }   \
         case SR_RING_STARK_POW2: { using F = sr::Stark; return CALL; }                                   \
+        case SR_RING_FROG_16: { using F = sr::Frog; return CALL; }                                       \
         default: return fail(SR_E_INVALID, "unknown ring");                                              \
     }
 
@@ -580,6 +583,7 @@ int check(sr_ctx *c, const void *p0, const void *p1 = (const void *)1, const voi
 
 // ---- per-ring device dispatch (pow2 rings and the reference-native small rings) --------------
 int dev_fwd(sr_ctx *c, uint64_t *d, size_t batch, hipStream_t st) {
+    if (c->ring == SR_RING_FROG_16) return sr::frog_launch(c->frog, sr::FROG_CRT, d, nullptr, 0, d, batch, st) ? fail(SR_E_HIP, "frog-ring launch failed") : SR_OK;
     if (c->ring == SR_RING_GOLDILOCKS_24) return sr::small_launch(c->small, sr::SMALL_G24_CRT, d, nullptr, 0, d, batch, st) ? fail(SR_E_HIP, "small-ring launch failed") : SR_OK;
     if (c->ring == SR_RING_BABYBEAR_72) return sr::small_launch(c->small, sr::SMALL_B72_CRT, d, nullptr, 0, d, batch, st) ? fail(SR_E_HIP, "small-ring launch failed") : SR_OK;
     if (c->regtile) {
@@ -592,6 +596,7 @@ int dev_fwd(sr_ctx *c, uint64_t *d, size_t batch, hipStream_t st) {
     DISPATCH_POW2(c, (fwd_dev<F>(c, d, batch, st)));
 }
 int dev_inv(sr_ctx *c, uint64_t *d, size_t batch, hipStream_t st) {
+    if (c->ring == SR_RING_FROG_16) return sr::frog_launch(c->frog, sr::FROG_ICRT, d, nullptr, 0, d, batch, st) ? fail(SR_E_HIP, "frog-ring launch failed") : SR_OK;
     if (c->ring == SR_RING_GOLDILOCKS_24) return sr::small_launch(c->small, sr::SMALL_G24_ICRT, d, nullptr, 0, d, batch, st) ? fail(SR_E_HIP, "small-ring launch failed") : SR_OK;
     if (c->ring == SR_RING_BABYBEAR_72) return sr::small_launch(c->small, sr::SMALL_B72_ICRT, d, nullptr, 0, d, batch, st) ? fail(SR_E_HIP, "small-ring launch failed") : SR_OK;
     if (c->regtile) {
@@ -604,6 +609,7 @@ int dev_inv(sr_ctx *c, uint64_t *d, size_t batch, hipStream_t st) {
     DISPATCH_POW2(c, (inv_dev<F>(c, d, batch, st)));
 }
 int dev_pointwise(sr_ctx *c, uint64_t *l, const uint64_t *r, size_t batch, hipStream_t st) {
+    if (c->ring == SR_RING_FROG_16) return sr::frog_launch(c->frog, sr::FROG_MUL, l, r, 0, l, batch, st) ? fail(SR_E_HIP, "frog-ring launch failed") : SR_OK;
     if (c->ring == SR_RING_GOLDILOCKS_24) return sr::small_launch(c->small, sr::SMALL_G24_MUL, l, r, 0, l, batch, st) ? fail(SR_E_HIP, "small-ring launch failed") : SR_OK;
     if (c->ring == SR_RING_BABYBEAR_72) return sr::small_launch(c->small, sr::SMALL_B72_MUL, l, r, 0, l, batch, st) ? fail(SR_E_HIP, "small-ring launch failed") : SR_OK;
     DISPATCH_POW2(c, (pointwise_dev<F>(c, l, r, batch << c->k, st)));
@@ -615,6 +621,7 @@ int dev_addsub(sr_ctx *c, uint64_t *l, const uint64_t *r, size_t batch, bool sub
         case SR_RING_GOLDILOCKS_24: return addsub_dev<sr::Goldilocks>(c, l, r, n, sub, st);
         case SR_RING_BABYBEAR_POW2:
         case SR_RING_BABYBEAR_72: return addsub_dev<sr::BabyBear>(c, l, r, n, sub, st);
+        case SR_RING_FROG_16: return addsub_dev<sr::Frog>(c, l, r, n, sub, st);
         default: return addsub_dev<sr::Stark>(c, l, r, n, sub, st);
     }
 }
@@ -629,6 +636,7 @@ int dev_matvec(sr_ctx *c, uint64_t *y, const uint64_t *m, const uint64_t *v, siz
     DISPATCH_POW2(c, (matvec_dev<F>(c, y, m, v, nrows, ncols, st)));
 }
 int dev_ring_mul(sr_ctx *c, uint64_t *out, const uint64_t *a, uint64_t *b, size_t batch, hipStream_t st) {
+    if (c->ring == SR_RING_FROG_16) return sr::frog_launch(c->frog, sr::FROG_RINGMUL, a, b, 0, out, batch, st) ? fail(SR_E_HIP, "frog-ring launch failed") : SR_OK;
     if (c->ring == SR_RING_GOLDILOCKS_24) return sr::small_launch(c->small, sr::SMALL_G24_RINGMUL, a, b, 0, out, batch, st) ? fail(SR_E_HIP, "small-ring launch failed") : SR_OK;
     if (c->ring == SR_RING_BABYBEAR_72) return sr::small_launch(c->small, sr::SMALL_B72_RINGMUL, a, b, 0, out, batch, st) ? fail(SR_E_HIP, "small-ring launch failed") : SR_OK;
     if (c->regtile) {
@@ -641,6 +649,10 @@ int dev_ring_mul(sr_ctx *c, uint64_t *out, const uint64_t *a, uint64_t *b, size_
     DISPATCH_POW2(c, (ring_mul_dev<F>(c, out, a, b, batch, st)));
 }
 int dev_reduce(sr_ctx *c, const uint64_t *in, size_t in_len, uint64_t *out, size_t batch, hipStream_t st) {
+    if (c->ring == SR_RING_FROG_16) {
+        if (in_len > 2 * c->degree) return fail(SR_E_INVALID, "reduce: in_len_per_elem > 2D");
+        return sr::frog_launch(c->frog, sr::FROG_REDUCE, in, nullptr, in_len, out, batch, st) ? fail(SR_E_HIP, "frog-ring launch failed") : SR_OK;
+    }
     if (c->ring == SR_RING_GOLDILOCKS_24 || c->ring == SR_RING_BABYBEAR_72) {
         if (in_len > 2 * c->degree) return fail(SR_E_INVALID, "reduce: in_len_per_elem > 2D");
         int op = c->ring == SR_RING_GOLDILOCKS_24 ? sr::SMALL_G24_REDUCE : sr::SMALL_B72_REDUCE;
@@ -660,7 +672,7 @@ const char *sr_version(void) { return "stark-rings-amd 0.1 (gfx950)"; }
 int sr_ctx_create(int ring, int log2_degree, int device, sr_ctx **out) {
     if (!out) return fail(SR_E_INVALID, "null out pointer");
     *out = nullptr;
-    if (ring < SR_RING_GOLDILOCKS_POW2 || ring > SR_RING_BABYBEAR_72) return fail(SR_E_INVALID, "unknown ring id");
+    if (ring < SR_RING_GOLDILOCKS_POW2 || ring > SR_RING_FROG_16) return fail(SR_E_INVALID, "unknown ring id");
     if (is_pow2_ring(ring) && (log2_degree < 0 || log2_degree > 24)) return fail(SR_E_INVALID, "log2_degree out of range");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
@@ -707,6 +719,11 @@ int sr_ctx_create(int ring, int log2_degree, int device, sr_ctx **out) {
         c->rt_hooks.user = c;
         c->rt_hooks.begin = gl_prof_begin;
         c->rt_hooks.end = gl_prof_end;
+    } else if (ring == SR_RING_FROG_16) {
+        c->k = 0;
+        c->degree = 16;
+        c->limbs = 1;
+        sr::frog_init(c->frog);
     } else {
         c->k = 0;
         c->degree = ring == SR_RING_GOLDILOCKS_24 ? 24 : 72;
@@ -994,6 +1011,7 @@ int sr_fill_uniform_dev(sr_ctx *c, uint64_t seed, uint64_t first, size_t n, uint
         case SR_RING_GOLDILOCKS_24: return fill_dev<sr::Goldilocks>(c, seed, first, n, out, st);
         case SR_RING_BABYBEAR_POW2:
         case SR_RING_BABYBEAR_72: return fill_dev<sr::BabyBear>(c, seed, first, n, out, st);
+        case SR_RING_FROG_16: return fill_dev<sr::Frog>(c, seed, first, n, out, st);
         default: return fill_dev<sr::Stark>(c, seed, first, n, out, st);
     }
 }
@@ -1007,6 +1025,7 @@ int sr_count_noncanonical_dev(sr_ctx *c, const uint64_t *d, size_t n, uint64_t *
         case SR_RING_GOLDILOCKS_24: return count_dev<sr::Goldilocks>(c, d, n, host_count, st);
         case SR_RING_BABYBEAR_POW2:
         case SR_RING_BABYBEAR_72: return count_dev<sr::BabyBear>(c, d, n, host_count, st);
+        case SR_RING_FROG_16: return count_dev<sr::Frog>(c, d, n, host_count, st);
         default: return count_dev<sr::Stark>(c, d, n, host_count, st);
     }
 }
@@ -1105,6 +1124,7 @@ int sr_selftest_field_op(int field, int op, const uint64_t *a, const uint64_t *b
         case 0: rc = selftest_op<sr::Goldilocks>(op, ta, tb, to); break;
         case 1: rc = selftest_op<sr::BabyBear>(op, ta, tb, to); break;
         case 2: rc = selftest_op<sr::Stark>(op, ta, tb, to); break;
+        case 3: rc = selftest_op<sr::Frog>(op, ta, tb, to); break;
         default: return fail(SR_E_INVALID, "selftest: unknown field");
     }
     memcpy(out, to, words * 8);

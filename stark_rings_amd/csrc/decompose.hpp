@@ -31,6 +31,12 @@ struct Consts<Goldilocks> {
     SR_HD static uint64_t from_u64(uint64_t v) { return v; }       // v < p
 };
 template <>
+struct Consts<Frog> {
+    SR_HD static uint64_t one() { return 1; }
+    SR_HD static uint64_t r2() { return Frog::R2; }  // 2^128 mod p
+    SR_HD static uint64_t from_u64(uint64_t v) { return v; }  // v < p
+};
+template <>
 struct Consts<BabyBear> {
     SR_HD static uint32_t one() { return 1; }
     SR_HD static uint32_t r2() { return 663890614u; }  // 2^128 mod p

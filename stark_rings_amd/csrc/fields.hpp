@@ -485,6 +485,46 @@ struct Stark {
 // ------------------------------------------------------------------------------------------
 // helpers shared by host set-up code and device table builders
 // ------------------------------------------------------------------------------------------
+// ------------------------------------------------------------------------------------------
+// Frog prime p = 15912092521325583641 (frog_ring/mod.rs:19-25, "next" row 4): a generic 64-bit Montgomery field,
+// R = 2^64; p > 2^63, so sums carry out of 64 bits.  Data and table constants are both Montgomery images.
+// ------------------------------------------------------------------------------------------
+struct Frog {
+    using elem = uint64_t;
+    using storage = uint64_t;
+    static constexpr int kStorageWords64 = 1;
+    static constexpr int kLdsWords = 2;
+    static constexpr uint64_t P = 0xDCD31BD79EC2DD19ull;
+    static constexpr uint64_t PINV = 0xA3AE2AD7EED4D0D7ull;  // -p^-1 mod 2^64
+    static constexpr uint64_t R1 = 0x232CE428613D22E7ull;    // 2^64 mod p
+    static constexpr uint64_t R2 = 0x39662481D8836F74ull;    // 2^128 mod p
+    static constexpr uint32_t kGenerator = 3;
+    static constexpr int kBoundaryBits = 64;
+    static constexpr int kTwoAdicity = 3;
+
+    SR_HD static elem zero() { return 0; }
+    SR_HD static elem load(const storage *p) { return *p; }
+    SR_HD static void store(storage *p, elem v) { *p = v; }
+    SR_HD static bool valid(elem v) { return v < P; }
+    SR_HD static elem add(elem a, elem b) {
+        uint64_t s = a + b;
+        return (s < a || s >= P) ? s - P : s;
+    }
+    SR_HD static elem sub(elem a, elem b) { return a >= b ? a - b : a + (P - b); }
+    SR_HD static elem neg(elem a) { return a ? P - a : 0; }
+    SR_HD static elem mont_mul(elem a, elem b) {  // a * b * 2^-64 mod p
+        unsigned __int128 t = (unsigned __int128)a * b;
+        uint64_t m = (uint64_t)t * PINV;
+        unsigned __int128 u = t + (unsigned __int128)m * P;  // low 64 bits vanish; may carry out of 128 bits
+        uint64_t hi = (uint64_t)(u >> 64);
+        return (u < t || hi >= P) ? hi - P : hi;
+    }
+    SR_HD static elem mul_tw(elem a, elem w) { return mont_mul(a, w); }
+    SR_HD static elem mul_boundary(elem a, elem b) { return mont_mul(a, b); }
+    SR_HD static elem tw_from_u64(uint64_t x) { return mont_mul(x % P, R2); }
+    SR_HD static elem tw_one() { return R1; }
+};
+
 template <class F>
 SR_HD typename F::elem pow_tw(typename F::elem base, const uint64_t *e, int e_words) {
     typename F::elem acc = F::tw_one();

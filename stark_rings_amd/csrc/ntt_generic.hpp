@@ -348,6 +348,16 @@ SR_HD void uniform_words<Goldilocks>(uint64_t seed, uint64_t idx, uint64_t *out)
     out[0] = v;
 }
 template <>
+SR_HD void uniform_words<Frog>(uint64_t seed, uint64_t idx, uint64_t *out) {
+    uint64_t v = 0;
+    for (unsigned r = 0; r < 64; r++) {
+        v = prng_word(seed, idx, 0, r);
+        if (v < Frog::P) break;
+        v = 0;
+    }
+    out[0] = v;
+}
+template <>
 SR_HD void uniform_words<BabyBear>(uint64_t seed, uint64_t idx, uint64_t *out) {
     uint64_t v = 0;
     for (unsigned r = 0; r < 64; r++) {

@@ -22,7 +22,7 @@ import numpy as np
 
 from . import _lib
 
-GOLDILOCKS_POW2, BABYBEAR_POW2, STARK_POW2, GOLDILOCKS_24, BABYBEAR_72 = 0, 1, 2, 3, 4
+GOLDILOCKS_POW2, BABYBEAR_POW2, STARK_POW2, GOLDILOCKS_24, BABYBEAR_72, FROG_16 = 0, 1, 2, 3, 4, 5
 PROF_TAGS = ("fwd_cols", "rows", "inv_cols", "pointwise", "other")
 
 _RING_NAMES = {
@@ -31,6 +31,7 @@ _RING_NAMES = {
     "stark": STARK_POW2,
     "goldilocks24": GOLDILOCKS_24,
     "babybear72": BABYBEAR_72,
+    "frog16": FROG_16,          # X^16 + 1 over the frog prime, 4 x Fq4 (frog_ring/mod.rs:62-107)
 }
 
 

@@ -93,11 +93,11 @@ static void pow2_suite(sr_ring ring, int field, int log2d, size_t batch) {
     EXPECT(threw);
 }
 
-static void small_suite(sr_ring ring, int field, int D, void (*crt)(uint64_t *), void (*mul)(uint64_t *, const uint64_t *),
+static void small_suite(sr_ring ring, int field, int D, int ext, void (*crt)(uint64_t *), void (*mul)(uint64_t *, const uint64_t *),
                         void (*icrt)(uint64_t *)) {
     CyclotomicConfig cfg(ring);
     EXPECT(cfg.dimension() == (size_t)D);
-    EXPECT(cfg.crt_field_extension_degree() == D / 8);
+    EXPECT(cfg.crt_field_extension_degree() == ext);
     const size_t batch = 100;  // crt.rs:106-121 uses 100 x 100
     auto a = uniform(field, 21, batch * D), b = uniform(field, 22, batch * D);
     RqNTTVec na = RqPolyVec(cfg, a).elementwise_crt();
@@ -194,8 +194,9 @@ int main() {
         linalg_suite(SR_RING_GOLDILOCKS_POW2, SRO_GOLDILOCKS, 6);
         linalg_suite(SR_RING_BABYBEAR_POW2, SRO_BABYBEAR, 5);
         linalg_suite(SR_RING_STARK_POW2, SRO_STARK, 4);
-        small_suite(SR_RING_GOLDILOCKS_24, SRO_GOLDILOCKS, 24, sro_g24_crt, sro_g24_ntt_mul, sro_g24_icrt);
-        small_suite(SR_RING_BABYBEAR_72, SRO_BABYBEAR, 72, sro_bb72_crt, sro_bb72_ntt_mul, sro_bb72_icrt);
+        small_suite(SR_RING_GOLDILOCKS_24, SRO_GOLDILOCKS, 24, 3, sro_g24_crt, sro_g24_ntt_mul, sro_g24_icrt);
+        small_suite(SR_RING_BABYBEAR_72, SRO_BABYBEAR, 72, 9, sro_bb72_crt, sro_bb72_ntt_mul, sro_bb72_icrt);
+        small_suite(SR_RING_FROG_16, SRO_FROG, 16, 4, sro_frog16_crt, sro_frog16_ntt_mul, sro_frog16_icrt);   // frog_ring/mod.rs tests
     } catch (const std::exception &e) {
         std::printf("EXCEPTION %s\n", e.what());
         return 2;

@@ -699,3 +699,59 @@ def test_linear_algebra_many_rows(torch_cuda):
     ring.matmul_ntt_dev(y2, tm, tv, nrows, ncols, 1)
     ring.matvec_ntt_dev(ty, tm, tv, nrows, ncols)
     assert torch.equal(y2, ty)
+
+
+# ----------------------------------------------------------------------------- "next" row 4: the frog ring X^16 + 1 -> 4 x Fq4
+def test_frog16_reference_kats_on_gpu(torch_cuda, kats):
+    """frog_ring/ntt.rs:387-563 through the C ABI: crt then (oracle) dehomogenize == expected residues; (oracle) homogenize then
+    icrt == expected coefficients."""
+    ring = ring_for("frog16", 0)
+    F = O.FROG
+    for k in kats["frog16"]["kats"]:
+        c, r = [int(v) for v in k["coeffs"]], [int(v) for v in k["residues"]]
+        if k["kind"] == "crt_then_dehomogenize":
+            got = ring.elementwise_crt(O.to_mont(F, c))
+            assert O.from_mont(F, O.small("sro_frog16_dehomogenize", got)) == r
+        else:
+            got = ring.elementwise_icrt(O.small("sro_frog16_homogenize", O.to_mont(F, r)))
+            assert O.from_mont(F, got) == c
+
+
+def test_frog16_matches_oracle(torch_cuda):
+    """test_crt_one / test_icrt_one / test_mul_crt / test_reduce of frog_ring/mod.rs:143-219 as batch parity against the oracle:
+    crt, icrt, Fq4 slot products, the fused ring product (== schoolbook reduced), reduce with ragged lengths, add / sub, and the
+    balanced decomposition over the frog prime."""
+    ring = ring_for("frog16", 0)
+    F, p, D = O.FROG, P.FROG_P, 16
+    batch = 301
+    a = O.fill_uniform(F, 0xF1, 0, batch * D)
+    b = O.fill_uniform(F, 0xF2, 0, batch * D)
+    a[:D] = O.to_mont(F, [1] + [0] * 15)
+    a[D:2 * D] = O.to_mont(F, [p - 1] * 16)
+    fa = ring.elementwise_crt(a.copy())
+    assert np.array_equal(fa, O.small("sro_frog16_crt", a))
+    assert O.from_mont(F, fa[:D]) == [1, 0, 0, 0] * 4                      # crt(ONE) == ONE
+    assert np.array_equal(ring.elementwise_icrt(fa.copy()), a)
+    fb = ring.elementwise_crt(b.copy())
+    prod = ring.ntt_mul(fa.copy(), fb)
+    assert np.array_equal(prod, O.small("sro_frog16_ntt_mul", fa, fb))
+    c = ring.mul(a, b)
+    assert np.array_equal(c, ring.elementwise_icrt(prod.copy()))
+    for e in (0, 1, 7, batch - 1):
+        sb = O.schoolbook(F, a[e * D:(e + 1) * D], b[e * D:(e + 1) * D], D)
+        assert O.from_mont(F, c[e * D:(e + 1) * D]) == P.frog16_reduce(O.from_mont(F, sb))
+    for in_len in (0, 5, 16, 19, 31, 32):
+        src = O.fill_uniform(F, 0xF3 + in_len, 0, 2 * in_len) if in_len else np.zeros(0, dtype=np.uint64)
+        got = ring.reduce(src, in_len, 2)
+        for e in range(2):
+            std = O.from_mont(F, src[e * in_len:(e + 1) * in_len]) if in_len else []
+            assert O.from_mont(F, got[e * D:(e + 1) * D]) == P.frog16_reduce(std)
+    sa, sb_ = O.from_mont(F, a), O.from_mont(F, b)
+    assert O.from_mont(F, ring.add(a.copy(), b)) == [(x + y) % p for x, y in zip(sa, sb_)]
+    assert O.from_mont(F, ring.sub(a.copy(), b)) == [(x - y) % p for x, y in zip(sa, sb_)]
+    for basis, pad in ((2, 65), (1 << 16, 5), (10, 21)):
+        want, over = O.decompose_balanced(F, a, D, batch, basis, pad)
+        assert not over
+        got = ring.gadget_decompose(a, basis, pad)
+        assert np.array_equal(got, want)
+        assert np.array_equal(ring.gadget_recompose(got, basis, pad), a)

@@ -16,8 +16,8 @@ import pyref as P
 from stark_rings_amd import _lib
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-NAMES = ["goldilocks", "babybear", "stark"]
-KAPPA_BITS = {"goldilocks": 0, "babybear": 32, "stark": 256}
+NAMES = ["goldilocks", "babybear", "stark", "frog"]
+KAPPA_BITS = {"goldilocks": 0, "babybear": 32, "stark": 256, "frog": 64}
 
 
 def test_library_exports_every_declared_symbol():

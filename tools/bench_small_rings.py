@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Throughput of the reference-native small rings (Goldilocks-24, BabyBear-72) on one GPU: CRT, ICRT, slot product,
+"""Throughput of the reference-native small rings (Goldilocks-24, BabyBear-72, Frog-16) on one GPU: CRT, ICRT, slot product,
 fused ring product over a large batch resident in HBM.  Prints elements/s and effective HBM GB/s (algorithmic bytes)."""
 import os
 import sys
@@ -11,7 +11,7 @@ import torch
 
 from stark_rings_amd import CyclotomicRing
 
-for name, D in (("goldilocks24", 24), ("babybear72", 72)):
+for name, D in (("goldilocks24", 24), ("babybear72", 72), ("frog16", 16)):
     ring = CyclotomicRing(name)
     batch = 1 << 22
     n = batch * D
