@@ -13,6 +13,15 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+@pytest.fixture(scope="session", autouse=True)
+def _native_artefacts_built():
+    """The in-tree .so files are build products (git-ignored): compile them when a fresh checkout runs the suite.
+    build() is a no-op when they are newer than their sources (hipcc cross-compiles gfx950 without a GPU, about a minute)."""
+    import __graft_entry__ as g
+
+    g.build()
+
+
 @pytest.fixture(scope="session")
 def kats():
     import json
