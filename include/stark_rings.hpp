@@ -24,6 +24,8 @@
 //   Matrix<RqNTT> (linear_algebra)       matrix.rs:14-20             class MatrixNTT        (dense, row-major, flat)
 //     checked_mul_vec / try_mul_vec      matrix.rs:168-183             checked_mul_vec -> std::optional (nullopt: DifferentLengths), try_mul_vec throws
 //     checked_mul_mat                    matrix.rs:148-166             checked_mul_mat -> std::optional
+//   GadgetDecompose / GadgetRecompose    balanced_decomposition/     gadget_decompose(const RqPolyVec&, b, k) / gadget_recompose(...)
+//     for &[R] / Vec<R>                  mod.rs:163-206                (digit j of element e = element e * k + j; throws where it panics)
 //   SparseMatrix<RqNTT>                  sparse_matrix.rs:17-22      class SparseMatrixNTT  (coeffs: rows of (element, column))
 //     checked_mul_vec / try_mul_vec      sparse_matrix.rs:201-216      same contract; an out-of-range column throws (the reference panics)
 //
@@ -182,6 +184,31 @@ private:
 inline RqNTTVec RqPolyVec::elementwise_crt() && {
     CyclotomicConfig::check(sr_ntt_fwd_batch(cfg_.raw(), w_.data(), len()), "elementwise_crt");
     return RqNTTVec(cfg_, std::move(w_));
+}
+
+// GadgetDecompose for &[R] / Vec<R> (balanced_decomposition/mod.rs:163-175, 192-198): len * padding_size elements, digit j of
+// element e at index e * padding_size + j.  The reference panics on basis 0, 1 or odd and when padding_size digits do not
+// suffice; std::runtime_error here.
+inline RqPolyVec gadget_decompose(const RqPolyVec &v, uint64_t b, size_t padding_size) {
+    const CyclotomicConfig &cfg = v.config();
+    std::vector<uint64_t> out(v.len() * padding_size * cfg.words_per_elem());
+    std::vector<uint64_t> dummy(1);
+    CyclotomicConfig::check(sr_decompose_balanced_batch(cfg.raw(), out.empty() ? dummy.data() : out.data(),
+                                                        v.words().empty() ? dummy.data() : v.words().data(), b, padding_size, v.len()),
+                            "gadget_decompose");
+    return RqPolyVec(cfg, std::move(out));
+}
+// GadgetRecompose (mod.rs:177-189, 200-206): len / padding_size elements
+inline RqPolyVec gadget_recompose(const RqPolyVec &digits, uint64_t b, size_t padding_size) {
+    const CyclotomicConfig &cfg = digits.config();
+    if (padding_size == 0 || digits.len() % padding_size) throw std::length_error("length is not a multiple of padding_size");
+    const size_t n = digits.len() / padding_size;
+    std::vector<uint64_t> out(n * cfg.words_per_elem());
+    std::vector<uint64_t> dummy(1);
+    CyclotomicConfig::check(sr_recompose_batch(cfg.raw(), out.empty() ? dummy.data() : out.data(),
+                                               digits.words().empty() ? dummy.data() : digits.words().data(), b, padding_size, n),
+                            "gadget_recompose");
+    return RqPolyVec(cfg, std::move(out));
 }
 
 // Matrix<RqNTT> (crates/linear_algebra/src/matrix.rs): nrows x ncols ring elements in CRT/NTT form, row-major, flat

@@ -184,6 +184,33 @@ static void linalg_suite(sr_ring ring, int field, int log2d) {
     EXPECT(threw);
 }
 
+// test_gadget_decompose / test_gadget_recompose (balanced_decomposition/mod.rs:469-514) and parity with the oracle
+static void gadget_suite(sr_ring ring, int field, int log2d) {
+    CyclotomicConfig cfg(ring, log2d);
+    const size_t d = cfg.dimension(), L = cfg.limbs(), batch = 7, k = field == SRO_STARK ? 64 : 17;
+    auto a = uniform(field, 31, batch * d);
+    RqPolyVec v(cfg, a);
+    RqPolyVec dig = gadget_decompose(v, 16, k);
+    std::vector<uint64_t> want(batch * k * d * L);
+    EXPECT(sro_decompose_balanced(field, a.data(), d, batch, 16, k, want.data()) == 0);
+    EXPECT(dig.words() == want);
+    EXPECT(gadget_recompose(dig, 16, k) == v);
+    bool threw = false;
+    try {
+        gadget_decompose(v, 7, k);  // "decomposition basis must be even"
+    } catch (const std::runtime_error &) {
+        threw = true;
+    }
+    EXPECT(threw);
+    threw = false;
+    try {
+        gadget_decompose(v, 2, 8);  // out[i] out of bounds in the reference
+    } catch (const std::runtime_error &) {
+        threw = true;
+    }
+    EXPECT(threw);
+}
+
 int main() {
     try {
         pow2_suite(SR_RING_GOLDILOCKS_POW2, SRO_GOLDILOCKS, 10, 3);   // BASELINE configs[0]: D = 2^10 (batch 1 is element 0)
@@ -191,6 +218,9 @@ int main() {
         pow2_suite(SR_RING_BABYBEAR_POW2, SRO_BABYBEAR, 8, 5);
         pow2_suite(SR_RING_STARK_POW2, SRO_STARK, 4, 100);            // the reference's stark_prime ring
         pow2_suite(SR_RING_STARK_POW2, SRO_STARK, 8, 3);
+        gadget_suite(SR_RING_GOLDILOCKS_POW2, SRO_GOLDILOCKS, 6);
+        gadget_suite(SR_RING_BABYBEAR_POW2, SRO_BABYBEAR, 5);
+        gadget_suite(SR_RING_STARK_POW2, SRO_STARK, 4);
         linalg_suite(SR_RING_GOLDILOCKS_POW2, SRO_GOLDILOCKS, 6);
         linalg_suite(SR_RING_BABYBEAR_POW2, SRO_BABYBEAR, 5);
         linalg_suite(SR_RING_STARK_POW2, SRO_STARK, 4);
