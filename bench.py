@@ -188,7 +188,9 @@ def main():
     value = total_muls / elapsed
     bytes_per_mul = 3 * d * coeff_bytes  # read a, read b, write c
     kern = {t: v for t, v in prof.items() if v["launches"]}
-    dom_tag = max(kern, key=lambda t: kern[t]["ms"])
+    # dominant kernel = the longest single launch of the step (the two forward column launches together take about as long as
+    # the rows launch at D = 2^16, so "largest total" would flip between runs; the per-launch figure is stable)
+    dom_tag = max(kern, key=lambda t: kern[t]["ms"] / kern[t]["launches"])
     dom = kern[dom_tag]
     launches_per_step = dom["launches"] / args.steps
     dom_avg_ms = dom["ms"] / dom["launches"]
