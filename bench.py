@@ -203,11 +203,14 @@ def main():
     # HBM traffic of the dominant kernel per launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE /
     # WRITE_SIZE in their own runs, FETCH_SIZE doubled per MI355X_MICROARCH.md): profiles/<round>/traffic.json
     traffic = None
+    step_traffic = None  # measured HBM bytes of one whole step (every launch), for the achieved-bandwidth figure
     try:
         rounds = sorted(r for r in os.listdir(os.path.join(ROOT, "profiles")) if r.startswith("r"))
         tj = json.load(open(os.path.join(ROOT, "profiles", rounds[-1], "traffic.json")))
         if tj.get("workload") == args.workload and batch == tj.get("batch"):
             traffic = tj["bytes_per_launch"].get(dom_tag)
+            if all(t in tj["bytes_per_launch"] for t in kern):
+                step_traffic = sum(tj["bytes_per_launch"][t] * kern[t]["launches"] / args.steps for t in kern)
     except (OSError, ValueError, KeyError, IndexError):
         pass
 
@@ -250,6 +253,11 @@ def main():
                      "kernel": dom_tag, "kernel_avg_ms": dom_avg_ms, "launches_per_step": launches_per_step,
                      "algorithmic_bytes_per_ring_mul": bytes_per_mul,
                      "whole_step_achieved_per_gpu": step_gbs, "whole_step_frac": step_gbs / HBM_PEAK_GBS,
+                     # measured HBM traffic of the whole step (PMC passes under profiles/) over the step time: the bandwidth the
+                     # step actually draws, as opposed to the algorithmic 3*D*w figure above
+                     "whole_step_hbm_traffic_bytes": step_traffic,
+                     "whole_step_hbm_traffic_gbs": (step_traffic / (elapsed / args.steps) / 1e9) if step_traffic else None,
+                     "whole_step_hbm_traffic_frac": (step_traffic / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS) if step_traffic else None,
                      "per_kernel_ms_per_step": {t: v["ms"] / args.steps for t, v in kern.items()}},
     }
 
