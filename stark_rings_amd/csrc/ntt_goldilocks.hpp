@@ -1,26 +1,26 @@
-// Tuned Goldilocks path for Fp[X]/(X^D+1), D = 2^k >= 4096 (BASELINE configs 2 and 4).
+// Tuned Goldilocks path for Fp[X]/(X^D+1), 2^8 <= D <= 2^22 (BASELINE configs 1, 2 and 4).
 //
 // Same function as the generic kernels -- the reference's stark_prime-style negacyclic NTT
 // (crates/ring/src/cyclotomic_ring/models/stark_prime/ntt.rs:121-346 generalised),
-// outputs bit-identical -- but decomposed for the gfx950 integer pipe, where a 64x64 product is four
-// quarter-rate v_mad_u64_u32 and dominates everything else:
+// outputs bit-identical -- but decomposed for the gfx950 integer pipe.  In Goldilocks 2 has order 192 (2^96 = -1) and
+// omega_64 = 7^((p-1)/64) = 8^13 = 2^39: every root of unity of order <= 64 is a power of two, and multiplying by one
+// is a shift plus one fold instead of a general product.  The decomposition keeps every butterfly twiddle a
+// compile-time shift and leaves ONE general (table) product per coefficient between two register passes.
 //
-//   D = 2^c * 4096 (for 256 <= D <= 4096 there are no strided passes: a tile holds 4096 / D whole ring elements, the rows
-//   kernel applies the twist itself and skips the radix-16 stages that would mix them -- one fused launch).
-//   (1) strided passes: the first c merged negacyclic radix-2 stages, 2^M legs per lane in registers,
-//       twiddles tw[2^s + b] wave-uniform (scalar loads); the last pass multiplies block b, position i
-//       by gamma_b^i (gamma_b = psi^(2 brv_c(b) + 1)), which turns every 4096-block into a plain
-//       CYCLIC DFT problem.  Memory-bound streaming kernels.
-//   (2) rows kernel: cyclic DFT_4096 = 16 x 16 x 16 (decimation in frequency), 16 coefficients per
-//       lane in registers, two trips through a padded 34 KiB LDS tile.  In Goldilocks 2 has order 192
-//       and omega_64 = 7^((p-1)/64) = 8^13, so omega_16 = 2^156 = -2^60: every butterfly twiddle inside
-//       a radix-16 is a compile-time SHIFT (2^96 = -1 gives the sign for free), and only one table
-//       multiply per coefficient separates two passes.  General modmuls per coefficient and transform:
-//       2 in the rows kernel (+ c/2 + 1 in the memory-bound strided passes) instead of k/2 = 8.
+//   column stages + twist: the first c merged negacyclic radix-2 stages split X^D + 1 into 2^c factors
+//       X^N2 - gamma_b^N2 (N2 = D >> c, gamma_b = psi^(2 brv_c(b) + 1)); multiplying block b, position i by gamma_b^i
+//       turns each block into a plain CYCLIC DFT_N2 problem.
+//         2^16 <= D <= 2^20: cols256_kernel, c = 8 in one launch, shift-only (see the comment at the kernel);
+//         2^13 .. 2^15 and 2^21, 2^22: strided_kernel<M> / strided256_kernel with table twiddles.
+//   rows: cyclic DFT_N2 out of shift-only radix-16 register passes (omega_16 = 2^156 = -2^60), 16 coefficients per lane,
+//       exchanges through a padded 34 KiB LDS tile: rows256_kernel (N2 = 256: 16 x 16), rows_kernel (N2 = 4096:
+//       16 x 16 x 16; 512..2048: leading stages skipped, several blocks per tile).
+//   D <= 4096: no column launch at all -- a tile holds 4096 / D whole ring elements and rows_kernel<.., TW = true>
+//       applies the twist itself (a compile-time shift per register slot and a column factor merged into its table).
 //   The fused ring product keeps fwd(a) in registers while fwd(b) runs, multiplies slot-wise
 //   (ntt_form.rs:177-189), and runs the inverse from registers: a, b read once, c written once.
 //   Inverse = mirror image; D^-1 (and, for the fused product, R^-1 = 2^-64, see fields.hpp) is folded
-//   into the inverse twist table.
+//   into the inverse twist table (D <= 4096: into the inverse W1 table).
 //
 // tools/model_fast_goldilocks.py is the index-level model of this file, checked against the oracle.
 #pragma once
