@@ -121,6 +121,11 @@ int sr_matvec_ntt(sr_ctx *ctx, uint64_t *y, const uint64_t *m, const uint64_t *v
 int sr_spmv_ntt(sr_ctx *ctx, uint64_t *y, const uint64_t *vals, const uint32_t *cols, const uint64_t *row_ptr, const uint64_t *v,
                 size_t nrows, size_t ncols);
 int sr_matmul_ntt(sr_ctx *ctx, uint64_t *y, const uint64_t *a, const uint64_t *b, size_t n, size_t m, size_t p);
+/* Cyclotomic::rot (crates/ring/src/traits.rs:54-66): every ring element of the batch (COEFFICIENT form) times X, modulo X^D + 1
+ * (stark_prime/mod.rs:87-95, frog_ring/mod.rs:126-134 and the power-of-two rings) or X^D - X^(D/2) + 1 (goldilocks/mod.rs:138-149,
+ * babybear/mod.rs:150-161).  The device form is out of place (d_out must not alias d_in); the host form works in place. */
+int sr_rot_batch_dev(sr_ctx *ctx, uint64_t *d_out, const uint64_t *d_in, size_t batch, void *stream);
+int sr_rot_batch(sr_ctx *ctx, uint64_t *data, size_t batch);
 /* Second "next" row: balanced gadget decomposition, coefficient-wise, of `batch` ring elements in COEFFICIENT
  * form: digit j of element e is ring element e * padding_size + j of d_out (batch * padding_size elements) --
  * GadgetDecompose for &[R] (crates/ring/src/balanced_decomposition/mod.rs:163-175) over Decompose for the ring

@@ -44,6 +44,7 @@ def lib():
             "sro_pow2_pointwise": (i, [i, _u64p, _u64p, sz]),
             "sro_pow2_reduce": (i, [i, _u64p, sz, _u64p, i]),
             "sro_schoolbook": (i, [i, _u64p, _u64p, sz, _u64p]),
+            "sro_rot": (None, [i, _u64p, sz, i, _u64p]),
             "sro_decompose_balanced": (i, [i, _u64p, sz, sz, ctypes.c_uint64, sz, _u64p]),
             "sro_recompose": (i, [i, _u64p, sz, sz, ctypes.c_uint64, sz, _u64p]),
             "sro_pow2_ring_mul": (i, [i, _u64p, _u64p, _u64p, i]),
@@ -160,6 +161,19 @@ def schoolbook(field, a, b, d):
     b = np.ascontiguousarray(b, dtype=np.uint64)
     out = np.empty((2 * d - 1) * LIMBS[field], dtype=np.uint64)
     assert lib().sro_schoolbook(field, ptr(a), ptr(b), d, ptr(out)) == 0
+    return out
+
+
+def rot(field, a, d, trinomial=False):
+    """Cyclotomic::rot of every ring element of the batch"""
+    a = np.ascontiguousarray(a, dtype=np.uint64)
+    out = np.empty_like(a)
+    w = d * LIMBS[field]
+    for e in range(a.size // w):
+        src = np.ascontiguousarray(a[e * w:(e + 1) * w])
+        dst = np.empty(w, dtype=np.uint64)
+        lib().sro_rot(field, ptr(src), d, 1 if trinomial else 0, ptr(dst))
+        out[e * w:(e + 1) * w] = dst
     return out
 
 

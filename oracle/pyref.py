@@ -550,3 +550,15 @@ def frog16_ntt_mul(x, y):
     for s_ in range(4):
         out += fq4_mul(x[4 * s_:4 * s_ + 4], y[4 * s_:4 * s_ + 4])
     return out
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Cyclotomic::rot (crates/ring/src/traits.rs:54-66): multiply by X modulo the ring's polynomial
+def rot(c, p, trinomial=False):
+    """X^D + 1 (stark_prime/mod.rs:87-95, frog_ring/mod.rs:126-134): new[0] = -old[D-1], new[i] = old[i-1];
+    X^D - X^(D/2) + 1 (goldilocks/mod.rs:138-149, babybear/mod.rs:150-161): additionally new[D/2] += old[D-1]"""
+    last = c[-1]
+    out = [(-last) % p] + list(c[:-1])
+    if trinomial:
+        out[len(c) // 2] = (out[len(c) // 2] + last) % p
+    return out

@@ -996,6 +996,25 @@ void sro_frog16_ntt_mul(uint64_t *lhs, const uint64_t *rhs) {
     }
 }
 
+/* Cyclotomic::rot (traits.rs:54-66; stark_prime/mod.rs:87-95, goldilocks/mod.rs:138-149, babybear/mod.rs:150-161,
+ * frog_ring/mod.rs:126-134): out = X * in modulo X^d + 1 (trinomial == 0) or X^d - X^(d/2) + 1 (trinomial != 0) */
+void sro_rot(int field, const uint64_t *in, size_t d, int trinomial, uint64_t *out) {
+    pthread_once(&g_once, init_all);
+    if (field == SRO_STARK) {
+        fe4 last, z = {{0, 0, 0, 0}}, t;
+        memcpy(&last, in + 4 * (d - 1), 32);
+        fe4_sub(&t, &z, &last);
+        memcpy(out, &t, 32);
+        memmove(out + 4, in, 32 * (d - 1));
+    } else {
+        const fp64_cfg *c = cfg64(field);
+        uint64_t last = in[d - 1];
+        memmove(out + 1, in, 8 * (d - 1));
+        out[0] = fp64_neg(c, last);
+        if (trinomial) out[d / 2] = fp64_add(c, out[d / 2], last);
+    }
+}
+
 /* ======================================================================================
  * Synthetic inputs (shared definition with the HIP library's generator; see sr_oracle.h)
  * ==================================================================================== */

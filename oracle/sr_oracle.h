@@ -43,6 +43,8 @@ int sro_pow2_reduce(int field, const uint64_t *in, size_t in_len, uint64_t *out,
 int sro_decompose_balanced(int field, const uint64_t *in, size_t d, size_t batch, uint64_t b, size_t k, uint64_t *out);
 /* gadget_recompose (mod.rs:119-131, 177-189): out[e] = sum_j b^j in[e * k + j] */
 int sro_recompose(int field, const uint64_t *in, size_t d, size_t batch_out, uint64_t b, size_t k, uint64_t *out);
+/* Cyclotomic::rot (traits.rs:54-66): out = X * in; in and out must not overlap */
+void sro_rot(int field, const uint64_t *in, size_t d, int trinomial, uint64_t *out);
 int sro_schoolbook(int field, const uint64_t *a, const uint64_t *b, size_t d, uint64_t *out_2d_minus_1); /* coeff_form.rs:54-67 */
 int sro_pow2_ring_mul(int field, uint64_t *out, const uint64_t *a, const uint64_t *b, int log2d);
 /* batch of independent elements; nthreads >= 1 pthreads over the batch (mirrors cfg_iter!) */

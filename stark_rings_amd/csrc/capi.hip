@@ -551,6 +551,25 @@ int recompose_dev(sr_ctx *c, uint64_t *out, const uint64_t *in, uint64_t b, size
     return SR_OK;
 }
 }
+extern "C++" {
+template <class F>
+int rot_dev(sr_ctx *c, uint64_t *out, const uint64_t *in, size_t batch, hipStream_t st) {
+    using S = typename F::storage;
+    const size_t n = batch * c->degree;
+    if (n == 0) return SR_OK;
+    size_t blocks = (n + 255) / 256;
+    if (blocks > 1u << 20) blocks = 1u << 20;
+    const size_t half = (c->ring == SR_RING_GOLDILOCKS_24 || c->ring == SR_RING_BABYBEAR_72) ? c->degree / 2 : 0;
+    ProfScope ps(c, st, K_OTHER);
+    hipLaunchKernelGGL((sr::rot_kernel<F>), dim3((unsigned)blocks), dim3(256), 0, st, reinterpret_cast<S *>(out),
+                       reinterpret_cast<const S *>(in), c->degree, half, batch);
+    HIP_TRY(hipGetLastError());
+    return SR_OK;
+}
+}
+int dev_rot(sr_ctx *c, uint64_t *out, const uint64_t *in, size_t batch, hipStream_t st) {
+    DISPATCH_FIELD(c, (rot_dev<F>(c, out, in, batch, st)));
+}
 int check_basis(uint64_t b) {
     if (b < 2) return fail(SR_E_INVALID, "cannot decompose in basis 0 or 1");              // mod.rs:63-66
     if (b & 1) return fail(SR_E_INVALID, "decomposition basis must be even");              // mod.rs:69
@@ -844,6 +863,27 @@ int sr_matmul_ntt_dev(sr_ctx *c, uint64_t *y, const uint64_t *a, const uint64_t 
     return dev_matmul(c, y, a, b, n, m, p, (hipStream_t)stream);
 }
 
+int sr_rot_batch_dev(sr_ctx *c, uint64_t *out, const uint64_t *in, size_t batch, void *stream) {
+    if (int rc = check(c, out, in)) return rc;
+    if (out == in) return fail(SR_E_INVALID, "rot: out must not alias in");
+    std::lock_guard<std::mutex> lk(c->mu);
+    DeviceGuard g(c->device);
+    return dev_rot(c, out, in, batch, (hipStream_t)stream);
+}
+int sr_rot_batch(sr_ctx *c, uint64_t *data, size_t batch) {
+    if (int rc = check(c, data)) return rc;
+    std::lock_guard<std::mutex> lk(c->mu);
+    DeviceGuard g(c->device);
+    const size_t bytes = batch * c->degree * c->limbs * 8;
+    if (bytes == 0) return SR_OK;
+    if (int rc = ensure_stage(c, 0, bytes)) return rc;
+    if (int rc = ensure_stage(c, 1, bytes)) return rc;
+    HIP_TRY(hipMemcpyAsync(c->stage[0], data, bytes, hipMemcpyHostToDevice, c->stream));
+    if (int rc = dev_rot(c, (uint64_t *)c->stage[1], (const uint64_t *)c->stage[0], batch, c->stream)) return rc;
+    HIP_TRY(hipMemcpyAsync(data, c->stage[1], bytes, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return SR_OK;
+}
 int sr_decompose_balanced_batch_dev(sr_ctx *c, uint64_t *out, const uint64_t *in, uint64_t basis, size_t padding_size, size_t batch,
                                     void *stream) {
     if (int rc = check(c, out, in)) return rc;

@@ -292,6 +292,21 @@ __global__ __launch_bounds__(256) void matmul_kernel(typename F::storage *y, con
             if (r0 + r < n && c0 + c < p) F::store(y + (((r0 + r) * p + c0 + c) << k) + slot, acc[r][c]);
 }
 
+// Cyclotomic::rot (crates/ring/src/traits.rs:54-66): out = X * in for every ring element of the batch.
+// X^D + 1 (half = 0; stark_prime/mod.rs:87-95, frog_ring/mod.rs:126-134): out[0] = -in[D-1], out[i] = in[i-1];
+// X^D - X^(D/2) + 1 (half = D/2; goldilocks/mod.rs:138-149, babybear/mod.rs:150-161): additionally out[D/2] += in[D-1].
+template <class F>
+__global__ void rot_kernel(typename F::storage *out, const typename F::storage *in, size_t d, size_t half, size_t batch) {
+    const size_t n = batch * d;
+    for (size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x; t < n; t += (size_t)gridDim.x * blockDim.x) {
+        const size_t e = t / d, i = t - e * d;
+        const typename F::storage *src = in + e * d;
+        typename F::elem v = i == 0 ? F::sub(F::zero(), F::load(src + d - 1)) : F::load(src + i - 1);
+        if (half && i == half) v = F::add(v, F::load(src + d - 1));
+        F::store(out + t, v);
+    }
+}
+
 // out[e][i] = in[e][i] - in[e][D + i]   (stark_prime/mod.rs:40-47); in_len <= 2D per element
 template <class F>
 __global__ void reduce_pow2_kernel(const typename F::storage *in, size_t in_len, typename F::storage *out, int k,

@@ -191,6 +191,11 @@ class CyclotomicRing:
                                             _np_ptr(b) if b.size else _np_ptr(z), n, m, p))
         return y[:n * p * w]
 
+    def rot(self, data):
+        """Cyclotomic::rot (traits.rs:54-66) of every element of the batch, in place: coefficients times X modulo the ring."""
+        self._check(self._lib.sr_rot_batch(self._ctx, _np_ptr(data), self._batch_of(data.size)))
+        return data
+
     def gadget_decompose(self, a, basis, padding_size):
         """GadgetDecompose for a Vec of ring elements in coefficient form (balanced_decomposition/mod.rs:163-175): returns
         len * padding_size elements, digit j of element e at index e * padding_size + j.  RingError where the reference panics
@@ -319,6 +324,14 @@ class CyclotomicRing:
             raise RingError("matmul: DifferentLengths")
         self._check(self._lib.sr_matmul_ntt_dev(self._ctx, py, pa, pb, n, m, p, self._stream(stream)))
         return y
+
+    def rot_dev(self, out, a, stream=None):
+        po, n = self._dev(out)
+        pa, m = self._dev(a)
+        if n != m:
+            raise RingError("operand lengths differ")
+        self._check(self._lib.sr_rot_batch_dev(self._ctx, po, pa, self._batch_of(n), self._stream(stream)))
+        return out
 
     def gadget_decompose_dev(self, out, a, basis, padding_size, stream=None):
         po, n = self._dev(out)

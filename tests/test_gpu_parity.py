@@ -755,3 +755,27 @@ def test_frog16_matches_oracle(torch_cuda):
         got = ring.gadget_decompose(a, basis, pad)
         assert np.array_equal(got, want)
         assert np.array_equal(ring.gadget_recompose(got, basis, pad), a)
+
+
+# ----------------------------------------------------------------------------- Cyclotomic::rot
+@pytest.mark.parametrize("name,k", [("goldilocks", 6), ("babybear", 5), ("stark", 4), ("goldilocks24", 0), ("babybear72", 0), ("frog16", 0)])
+def test_rot_matches_oracle_and_monomial_products(torch_cuda, name, k):
+    """test_cyclotomic (goldilocks/mod.rs:249-262, babybear/mod.rs:259-272, stark_prime/mod.rs:179-192, frog_ring/mod.rs:221-234):
+    rot^i(a) == a * X^i with the product taken by the ring's own multiplication; rot == the oracle's on a batch."""
+    torch = torch_cuda
+    base = {"goldilocks24": "goldilocks", "babybear72": "babybear", "frog16": "frog"}.get(name, name)
+    F = O.FIELD_ID[base]
+    ring = ring_for(name, k)
+    d, w, batch = ring.degree, ring.words_per_elem, 6
+    tri = name in ("goldilocks24", "babybear72")
+    a = O.fill_uniform(F, 0x90, 0, batch * d)
+    assert np.array_equal(ring.rot(a.copy()), O.rot(F, a, d, tri))
+    ta = torch.from_numpy(a.view(np.int64)).cuda()
+    tout = torch.empty_like(ta)
+    ring.rot_dev(tout, ta)
+    assert np.array_equal(tout.cpu().numpy().view(np.uint64), O.rot(F, a, d, tri))
+    cur = a[:w].copy()
+    for i in range(1, min(d, 20)):
+        cur = ring.rot(cur)
+        xi = O.to_mont(F, [1 if j == i else 0 for j in range(d)])
+        assert np.array_equal(cur, ring.mul(a[:w].copy(), xi))

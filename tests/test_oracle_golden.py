@@ -320,3 +320,33 @@ def test_frog16_identities_c_vs_python():
     sg = [v - p if v > (p - 1) // 2 else v for v in O.from_mont(O.FROG, digits)]
     for i, v in enumerate(vals):
         assert [sg[j * len(vals) + i] for j in range(18)] == P.decompose_balanced(v, p, 16, 18)
+
+
+# ----------------------------------------------------------------------------- Cyclotomic::rot
+@pytest.mark.parametrize("name,d,tri", [("goldilocks", 24, True), ("babybear", 72, True), ("stark", 16, False), ("frog", 16, False),
+                                        ("goldilocks", 32, False)])
+def test_rot_is_multiplication_by_x(name, d, tri):
+    """test_cyclotomic (goldilocks/mod.rs:249-262, stark_prime/mod.rs:179-192, frog_ring/mod.rs:221-234): rot^i(a) == a * X^i,
+    here via schoolbook + reduce in plain integers; C oracle == Python restatement."""
+    import random
+
+    rng = random.Random(5)
+    F, p = O.FIELD_ID[name], P.PRIMES[name][0]
+    a = [rng.randrange(p) for _ in range(d)]
+
+    def times_x(c):
+        sb = [0] + list(c)                           # X * c, degree d
+        if tri:
+            hi = sb[d]
+            r = sb[:d]
+            r[0] = (r[0] - hi) % p                   # X^d = X^(d/2) - 1
+            r[d // 2] = (r[d // 2] + hi) % p
+            return r
+        return [(sb[0] - sb[d]) % p] + sb[1:d]       # X^d = -1
+
+    cur, m = list(a), O.to_mont(F, a)
+    for _ in range(d + 3):
+        cur = times_x(cur)
+        m = O.rot(F, m, d, tri)
+        assert O.from_mont(F, m) == cur
+    assert P.rot(a, p, tri) == times_x(a)
