@@ -198,15 +198,67 @@ __device__ __forceinline__ void small_slot_mul(typename F::elem *x, const typena
     for (int m = 0; m < W; m++) x[m] = F::boundary_post(t[T::PERM[m]]);
 }
 
+// A workgroup is ONE wave and owns 64 consecutive ring elements.  A lane works on its own element, whose D words are
+// D * 8 bytes apart from its neighbour's: reading them lane by lane would touch 64 cache lines per load instruction.  The
+// block of 64 * D words is therefore moved between HBM and LDS with lane-contiguous accesses (512 B per instruction) and
+// each lane picks its element out of LDS (element stride D + 1 words: conflict-free).  A ragged last block clamps its reads.
+template <class F, int D>
+__device__ __forceinline__ void small_block_load(typename F::elem *lds, const uint64_t *src, size_t first, size_t batch,
+                                                 typename F::elem *x) {
+    const int t = threadIdx.x;
+    const size_t n_valid = (batch - first < 64 ? batch - first : 64) * D;
+#pragma unroll 4
+    for (int idx = t; idx < 64 * D; idx += 64) {
+        const int el = idx / D, i = idx - el * D;
+        lds[el * (D + 1) + i] = F::load(src + first * D + ((size_t)idx < n_valid ? idx : 0));
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < D; i++) x[i] = lds[t * (D + 1) + i];
+    __syncthreads();
+}
+template <class F, int D>
+__device__ __forceinline__ void small_block_store(typename F::elem *lds, uint64_t *dst, size_t first, size_t batch,
+                                                  const typename F::elem *x) {
+    const int t = threadIdx.x;
+    const size_t n_valid = (batch - first < 64 ? batch - first : 64) * D;
+#pragma unroll
+    for (int i = 0; i < D; i++) lds[t * (D + 1) + i] = x[i];
+    __syncthreads();
+#pragma unroll 4
+    for (int idx = t; idx < 64 * D; idx += 64) {
+        const int el = idx / D, i = idx - el * D;
+        if ((size_t)idx < n_valid) F::store(dst + first * D + idx, lds[el * (D + 1) + i]);
+    }
+}
+
+// STAGED: through LDS as above; otherwise each lane reads and writes its own element directly.  Which one wins was
+// measured per ring and operation over 2^22 elements (tools/bench_small_rings.py): staging gains 25-70 % everywhere
+// except Goldilocks-24 ICRT (-4 %) and its fused ring product (-14 %, 96 data VGPRs plus the exchanges), which stay direct.
+template <class F, int D, int W, int OP>
+constexpr bool small_staged() {
+    return !(D == 24 && (OP == SOP_ICRT || OP == SOP_RINGMUL));
+}
+template <class F, int D, bool STAGED>
+__device__ __forceinline__ void small_get(typename F::elem *lds, const uint64_t *src, size_t first, size_t batch,
+                                          typename F::elem *x) {
+    if (STAGED) {
+        small_block_load<F, D>(lds, src, first, batch, x);
+    } else {
+        const size_t e = first + threadIdx.x < batch ? first + threadIdx.x : batch - 1;
+#pragma unroll
+        for (int i = 0; i < D; i++) x[i] = F::load(src + e * D + i);
+    }
+}
 template <class F, int D, int W, int OP>
 __global__ __launch_bounds__(64) void small_ring_kernel(SmallRingConsts k, const uint64_t *a, const uint64_t *b,
                                                         uint64_t *out, size_t batch) {
     using E = typename F::elem;
-    size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
-    if (e >= batch) return;
+    constexpr bool STAGED = small_staged<F, D, W, OP>();
+    __shared__ E lds[STAGED ? 64 * (D + 1) : 1];
+    const size_t first = blockIdx.x * (size_t)64;
     E x[D];
-#pragma unroll
-    for (int i = 0; i < D; i++) x[i] = F::load(a + e * D + i);
+    small_get<F, D, STAGED>(lds, a, first, batch, x);
     if (OP == SOP_CRT) {
         small_fwd3<F, D>(x, k);
         small_homogenize<F, W>(x, k);
@@ -215,8 +267,7 @@ __global__ __launch_bounds__(64) void small_ring_kernel(SmallRingConsts k, const
         small_inv3<F, D>(x, k);
     } else {
         E y[D];
-#pragma unroll
-        for (int i = 0; i < D; i++) y[i] = F::load(b + e * D + i);
+        small_get<F, D, STAGED>(lds, b, first, batch, y);
         if (OP == SOP_RINGMUL) {
             small_fwd3<F, D>(x, k);
             small_homogenize<F, W>(x, k);
@@ -230,8 +281,13 @@ __global__ __launch_bounds__(64) void small_ring_kernel(SmallRingConsts k, const
             small_inv3<F, D>(x, k);
         }
     }
+    if (STAGED) {
+        small_block_store<F, D>(lds, out, first, batch, x);
+    } else if (first + threadIdx.x < batch) {
+        const size_t e = first + threadIdx.x;
 #pragma unroll
-    for (int i = 0; i < D; i++) F::store(out + e * D + i, x[i]);
+        for (int i = 0; i < D; i++) F::store(out + e * D + i, x[i]);
+    }
 }
 
 // goldilocks/mod.rs:75-98, babybear/mod.rs:87-110
