@@ -175,7 +175,9 @@ constexpr int kappa_bits() {  // mul_tw(x, y) = x * y * 2^-kappa_bits
 }
 template <class F>
 constexpr int default_log_tile() {
-    return std::is_same<F, sr::Stark>::value ? 10 : 12;
+    // Stark: 512 coefficients x 32 B = 16 KiB per tile (two tiles in the fused product): five workgroups per CU.  With 1024
+    // coefficients (two per CU) the rows kernel took 3.23 ms at D = 2^12, batch 2^12; with 512 it takes 2.39 ms.
+    return std::is_same<F, sr::Stark>::value ? 9 : 12;
 }
 
 template <class F>
@@ -196,6 +198,10 @@ int init_pow2(sr_ctx *c) {
     const int k = c->k;
     if (k > F::kTwoAdicity - 1) return fail(SR_E_INVALID, "log2_degree exceeds the field's 2-adicity");
     c->log_tile = default_log_tile<F>();
+    if (const char *lt = getenv("SR_LOG_TILE")) {  // tuning knob: LDS tile of the generic kernels (8..12)
+        const int v = atoi(lt);
+        if (v >= 8 && v <= 12) c->log_tile = v;
+    }
     if (k > 2 * c->log_tile) return fail(SR_E_INVALID, "log2_degree too large for the two-level kernels");
     const size_t d = c->degree;
     size_t extra = 0;
