@@ -779,3 +779,43 @@ def test_rot_matches_oracle_and_monomial_products(torch_cuda, name, k):
         cur = ring.rot(cur)
         xi = O.to_mont(F, [1 if j == i else 0 for j in range(d)])
         assert np.array_equal(cur, ring.mul(a[:w].copy(), xi))
+
+
+# ----------------------------------------------------------------------------- threading (Send + Sync, rayon callers)
+def test_concurrent_calls_on_shared_and_private_contexts(torch_cuda):
+    """The reference's ring types are Send + Sync and rayon workers multiply concurrently (matrix.rs:174): several host threads
+    call the host-pointer entry points at once, four on ONE shared context (serialised by the context's mutex) and four on
+    contexts of their own; every result must equal the oracle's."""
+    import threading
+
+    from stark_rings_amd import CyclotomicRing
+
+    F, k, batch = O.GOLDILOCKS, 13, 5
+    shared = CyclotomicRing("goldilocks", k, device=0)
+    jobs, errors = [], []
+    for i in range(8):
+        a = O.fill_uniform(F, 0x300 + i, 0, batch << k)
+        b = O.fill_uniform(F, 0x400 + i, 0, batch << k)
+        jobs.append((a, b, O.pow2_ring_mul(F, a, b, k, batch, 4)))
+
+    def work(i):
+        try:
+            ring = shared if i < 4 else CyclotomicRing("goldilocks", k, device=0)
+            a, b, want = jobs[i]
+            for _ in range(3):
+                if not np.array_equal(ring.mul(a, b), want):
+                    errors.append("thread %d: product differs" % i)
+                if not np.array_equal(ring.elementwise_icrt(ring.elementwise_crt(a.copy())), a):
+                    errors.append("thread %d: round trip differs" % i)
+            if ring is not shared:
+                ring.close()
+        except Exception as exc:  # noqa: BLE001 - reported below
+            errors.append("thread %d: %r" % (i, exc))
+
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(8)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    shared.close()
+    assert not errors, errors
