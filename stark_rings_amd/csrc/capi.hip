@@ -8,8 +8,11 @@
 
 #include <cstdio>
 #include <cstring>
+#include <condition_variable>
+#include <functional>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <type_traits>
 #include <vector>
 
@@ -68,9 +71,10 @@ struct sr_ctx {
     // inverse stage-0 constants (table form): plain inverse, and fused ring-mul (with boundary correction)
     unsigned char inv_scale0[32], inv_scale1[32], mul_scale0[32], mul_scale1[32];
     // staging for host-pointer entry points
-    void *stage[2] = {nullptr, nullptr};
-    size_t stage_bytes[2] = {0, 0};
+    void *stage[4] = {nullptr, nullptr, nullptr, nullptr};  // [2], [3]: second lane of the chunked host pipeline
+    size_t stage_bytes[4] = {0, 0, 0, 0};
     hipStream_t stream = nullptr;
+    hipStream_t out_stream = nullptr;  // device-to-host copies of the chunked host pipeline
     unsigned long long *d_counter = nullptr;
     std::mutex mu;
     Prof prof;
@@ -714,6 +718,7 @@ int sr_ctx_create(int ring, int log2_degree, int device, sr_ctx **out) {
         return code;
     };
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) return bail(fail(SR_E_HIP, "hipStreamCreate failed"));
+    if (hipStreamCreateWithFlags(&c->out_stream, hipStreamNonBlocking) != hipSuccess) return bail(fail(SR_E_HIP, "hipStreamCreate failed"));
     // three words: [0] scratch counter of count_noncanonical, [1] out-of-range column indices seen by spmv, [2] coefficients
     // that needed more digits than padding_size in a decomposition (both sticky until read)
     if (hipMalloc(&c->d_counter, 3 * sizeof(unsigned long long)) != hipSuccess) return bail(fail(SR_E_ALLOC, "hipMalloc counter failed"));
@@ -770,10 +775,11 @@ int sr_ctx_destroy(sr_ctx *c) {
     sr::gl_fast_destroy(c->gl_fast);
     sr::small_destroy(c->small);
     if (c->tables) (void)hipFree(c->tables);
-    for (int i = 0; i < 2; i++) {
+    for (int i = 0; i < 4; i++)
         if (c->stage[i]) (void)hipFree(c->stage[i]);
+    for (int i = 0; i < 2; i++)
         if (c->rt_scratch[i]) (void)hipFree(c->rt_scratch[i]);
-    }
+    if (c->out_stream) (void)hipStreamDestroy(c->out_stream);
     if (c->d_counter) (void)hipFree(c->d_counter);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -1077,19 +1083,124 @@ int sr_count_noncanonical_dev(sr_ctx *c, const uint64_t *d, size_t n, uint64_t *
 }
 
 // ---- host-buffer entry points: stage, run, copy back ----
+// Host-pointer batches: results = compute(a[, b]) element-wise over the batch, through device staging buffers.
+// Small batches: copy in, compute, copy out on the context's stream.  Large batches are cut into chunks (default 128 MiB per
+// operand, SR_HOST_CHUNK_MB) that alternate between two sets of staging buffers: the calling thread copies chunk i in and
+// launches it while a helper thread copies chunk i-1 out on a second stream, so the two PCIe directions overlap and the device
+// memory needed no longer grows with the batch.  compute(s0, s1, n, stream) works in place on s0 (n elements).
+extern "C++" {
+static int host_pipeline(sr_ctx *c, uint64_t *out, const uint64_t *a, const uint64_t *b, size_t batch,
+                         const std::function<int(uint64_t *, uint64_t *, size_t, hipStream_t)> &compute) {
+    const size_t elem_bytes = c->degree * c->limbs * 8;
+    const size_t bytes = batch * elem_bytes;
+    if (bytes == 0) return SR_OK;
+    size_t chunk_mb = 128;
+    if (const char *e = getenv("SR_HOST_CHUNK_MB")) {
+        const long v = atol(e);
+        if (v > 0) chunk_mb = (size_t)v;
+    }
+    size_t chunk = (chunk_mb << 20) / elem_bytes;
+    if (chunk == 0) chunk = 1;
+    if (batch <= 2 * chunk) {  // one shot
+        if (int rc = ensure_stage(c, 0, bytes)) return rc;
+        if (b)
+            if (int rc = ensure_stage(c, 1, bytes)) return rc;
+        HIP_TRY(hipMemcpyAsync(c->stage[0], a, bytes, hipMemcpyHostToDevice, c->stream));
+        if (b) HIP_TRY(hipMemcpyAsync(c->stage[1], b, bytes, hipMemcpyHostToDevice, c->stream));
+        if (int rc = compute((uint64_t *)c->stage[0], (uint64_t *)c->stage[1], batch, c->stream)) return rc;
+        HIP_TRY(hipMemcpyAsync(out, c->stage[0], bytes, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        return SR_OK;
+    }
+    const size_t chunk_bytes = chunk * elem_bytes;
+    for (int i = 0; i < 4; i++)
+        if (b || (i & 1) == 0)
+            if (int rc = ensure_stage(c, i, chunk_bytes)) return rc;
+    hipEvent_t ready[2];
+    for (auto &e : ready) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    struct Job {
+        const void *src;
+        uint64_t *dst;
+        size_t bytes;
+    } jobs[2];
+    std::mutex m;
+    std::condition_variable cv;
+    size_t submitted = 0, done = 0;
+    bool stop = false;
+    hipError_t worker_err = hipSuccess;
+    const int device = c->device;
+    hipStream_t out_stream = c->out_stream;
+    std::thread worker([&] {
+        (void)hipSetDevice(device);
+        for (;;) {
+            Job j;
+            int lane;
+            {
+                std::unique_lock<std::mutex> lk(m);
+                cv.wait(lk, [&] { return done < submitted || stop; });
+                if (done == submitted) return;
+                lane = (int)(done & 1);
+                j = jobs[lane];
+            }
+            hipError_t e = hipStreamWaitEvent(out_stream, ready[lane], 0);
+            if (e == hipSuccess) e = hipMemcpyAsync(j.dst, j.src, j.bytes, hipMemcpyDeviceToHost, out_stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(out_stream);
+            {
+                std::lock_guard<std::mutex> lk(m);
+                if (e != hipSuccess && worker_err == hipSuccess) worker_err = e;
+                done++;
+            }
+            cv.notify_all();
+        }
+    });
+    int rc = SR_OK;
+    hipError_t main_err = hipSuccess;
+    const size_t nchunks = (batch + chunk - 1) / chunk;
+    for (size_t i = 0; i < nchunks && rc == SR_OK && main_err == hipSuccess; i++) {
+        const int lane = (int)(i & 1);
+        const size_t first = i * chunk, n = batch - first < chunk ? batch - first : chunk;
+        {
+            std::unique_lock<std::mutex> lk(m);  // the lane's buffers are free once chunk i - 2 has been copied out
+            cv.wait(lk, [&] { return i < 2 || done + 1 >= i; });
+        }
+        uint64_t *s0 = (uint64_t *)c->stage[2 * lane], *s1 = (uint64_t *)c->stage[2 * lane + 1];
+        main_err = hipMemcpyAsync(s0, a + first * (elem_bytes / 8), n * elem_bytes, hipMemcpyHostToDevice, c->stream);
+        if (main_err == hipSuccess && b)
+            main_err = hipMemcpyAsync(s1, b + first * (elem_bytes / 8), n * elem_bytes, hipMemcpyHostToDevice, c->stream);
+        if (main_err != hipSuccess) break;
+        rc = compute(s0, s1, n, c->stream);
+        if (rc != SR_OK) break;
+        main_err = hipEventRecord(ready[lane], c->stream);
+        if (main_err != hipSuccess) break;
+        {
+            std::lock_guard<std::mutex> lk(m);
+            jobs[lane] = Job{s0, out + first * (elem_bytes / 8), n * elem_bytes};
+            submitted++;
+        }
+        cv.notify_all();
+    }
+    {
+        std::unique_lock<std::mutex> lk(m);
+        cv.wait(lk, [&] { return done == submitted; });
+        stop = true;
+    }
+    cv.notify_all();
+    worker.join();
+    (void)hipStreamSynchronize(c->stream);
+    for (auto &e : ready) (void)hipEventDestroy(e);
+    if (rc != SR_OK) return rc;
+    if (main_err != hipSuccess) return fail(SR_E_HIP, std::string("host pipeline: ") + hipGetErrorString(main_err));
+    if (worker_err != hipSuccess) return fail(SR_E_HIP, std::string("host pipeline (copy out): ") + hipGetErrorString(worker_err));
+    return SR_OK;
+}
+}  // extern "C++"
 static int host_inplace(sr_ctx *c, uint64_t *data, size_t batch, bool fwd) {
     if (int rc = check(c, data)) return rc;
     std::lock_guard<std::mutex> lk(c->mu);
     DeviceGuard g(c->device);
-    size_t bytes = batch * c->degree * c->limbs * 8;
-    if (bytes == 0) return SR_OK;
-    if (int rc = ensure_stage(c, 0, bytes)) return rc;
-    HIP_TRY(hipMemcpyAsync(c->stage[0], data, bytes, hipMemcpyHostToDevice, c->stream));
-    int rc = fwd ? dev_fwd(c, (uint64_t *)c->stage[0], batch, c->stream) : dev_inv(c, (uint64_t *)c->stage[0], batch, c->stream);
-    if (rc) return rc;
-    HIP_TRY(hipMemcpyAsync(data, c->stage[0], bytes, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    return SR_OK;
+    return host_pipeline(c, data, data, nullptr, batch, [&](uint64_t *s0, uint64_t *, size_t n, hipStream_t st) {
+        return fwd ? dev_fwd(c, s0, n, st) : dev_inv(c, s0, n, st);
+    });
 }
 int sr_ntt_fwd_batch(sr_ctx *c, uint64_t *data, size_t batch) { return host_inplace(c, data, batch, true); }
 int sr_ntt_inv_batch(sr_ctx *c, uint64_t *data, size_t batch) { return host_inplace(c, data, batch, false); }
@@ -1099,20 +1210,11 @@ static int host_binary(sr_ctx *c, uint64_t *out, const uint64_t *a, const uint64
     if (int rc = check(c, out, a, b)) return rc;
     std::lock_guard<std::mutex> lk(c->mu);
     DeviceGuard g(c->device);
-    size_t bytes = batch * c->degree * c->limbs * 8;
-    if (bytes == 0) return SR_OK;
-    if (int rc = ensure_stage(c, 0, bytes)) return rc;
-    if (int rc = ensure_stage(c, 1, bytes)) return rc;
-    HIP_TRY(hipMemcpyAsync(c->stage[0], a, bytes, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(hipMemcpyAsync(c->stage[1], b, bytes, hipMemcpyHostToDevice, c->stream));
-    uint64_t *s0 = (uint64_t *)c->stage[0], *s1 = (uint64_t *)c->stage[1];
-    int rc = op == HB_RING_MUL ? dev_ring_mul(c, s0, s0, s1, batch, c->stream)
-             : op == HB_POINTWISE ? dev_pointwise(c, s0, s1, batch, c->stream)
-                                  : dev_addsub(c, s0, s1, batch, op == HB_SUB, c->stream);
-    if (rc) return rc;
-    HIP_TRY(hipMemcpyAsync(out, c->stage[0], bytes, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    return SR_OK;
+    return host_pipeline(c, out, a, b, batch, [&](uint64_t *s0, uint64_t *s1, size_t n, hipStream_t st) {
+        return op == HB_RING_MUL ? dev_ring_mul(c, s0, s0, s1, n, st)
+               : op == HB_POINTWISE ? dev_pointwise(c, s0, s1, n, st)
+                                    : dev_addsub(c, s0, s1, n, op == HB_SUB, st);
+    });
 }
 int sr_pointwise_mul_batch(sr_ctx *c, uint64_t *lhs, const uint64_t *rhs, size_t batch) {
     return host_binary(c, lhs, lhs, rhs, batch, HB_POINTWISE);

@@ -819,3 +819,34 @@ def test_concurrent_calls_on_shared_and_private_contexts(torch_cuda):
         t.join()
     shared.close()
     assert not errors, errors
+
+
+@pytest.mark.parametrize("name,k,batch", [("goldilocks", 13, 83), ("babybear", 13, 83), ("stark", 8, 301), ("goldilocks24", 0, 30000)])
+def test_host_pointer_pipeline_chunks_equal_one_shot(torch_cuda, name, k, batch):
+    """SR_HOST_CHUNK_MB=1 cuts the host batches of the transform / product entry points into many chunks (ragged last one) that
+    alternate between two staging lanes while a helper thread copies results out: same bytes as the oracle and as one shot."""
+    import os
+
+    base = {"goldilocks24": "goldilocks"}.get(name, name)
+    F = O.FIELD_ID[base]
+    ring = ring_for(name, k)
+    n = batch * ring.degree
+    a = O.fill_uniform(F, 0x501, 0, n)
+    b = O.fill_uniform(F, 0x502, 0, n)
+    one_fwd = ring.elementwise_crt(a.copy())
+    one_mul = ring.mul(a, b)
+    one_add = ring.add(a.copy(), b)
+    os.environ["SR_HOST_CHUNK_MB"] = "1"
+    try:
+        fa = ring.elementwise_crt(a.copy())
+        assert np.array_equal(fa, one_fwd)
+        assert np.array_equal(ring.elementwise_icrt(fa.copy()), a)
+        assert np.array_equal(ring.mul(a, b), one_mul)
+        inplace = a.copy()
+        assert np.array_equal(ring.mul(inplace, b, inplace), one_mul)       # out aliases a
+        assert np.array_equal(ring.add(a.copy(), b), one_add)
+        assert np.array_equal(ring.ntt_mul(fa.copy(), ring.elementwise_crt(b.copy())), ring.elementwise_crt(one_mul.copy()))
+    finally:
+        del os.environ["SR_HOST_CHUNK_MB"]
+    if k:
+        assert np.array_equal(one_mul, O.pow2_ring_mul(F, a, b, k, batch, 4))

@@ -13,7 +13,7 @@ import numpy as np
 import oracle_lib as O
 from stark_rings_amd import CyclotomicRing
 
-for name, k, batch in (("goldilocks", 16, 2048), ("goldilocks", 10, 131072), ("babybear", 16, 2048), ("stark", 12, 4096)):
+for name, k, batch in (("goldilocks", 16, 2048), ("goldilocks", 16, 8192), ("goldilocks", 10, 524288), ("babybear", 16, 8192), ("stark", 12, 32768)):
     F = O.FIELD_ID[name]
     ring = CyclotomicRing(name, k)
     a = O.fill_uniform(F, 1, 0, batch << k)
