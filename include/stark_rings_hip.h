@@ -64,7 +64,11 @@ enum sr_status {
 typedef struct sr_ctx sr_ctx;
 
 /* ---- context -------------------------------------------------------------------------- */
-/* Creates a context on HIP device `device` and builds its twiddle tables there. */
+/* Creates a context on HIP device `device` and builds its twiddle tables there.
+ * Threading (the reference's types are Send + Sync): every entry point may be called from any thread; calls on one
+ * context are serialised by the context (host-pointer calls run to completion, device-pointer calls enqueue and return).
+ * Device-pointer calls on different streams of one context may overlap on the GPU; the context orders its own shared scratch
+ * between streams with an event.  Contexts are independent of each other. */
 int sr_ctx_create(int ring, int log2_degree, int device, sr_ctx **out);
 int sr_ctx_destroy(sr_ctx *ctx);
 /* D, u64 limbs per coefficient, u64 words per ring element */

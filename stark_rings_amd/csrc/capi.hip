@@ -66,6 +66,10 @@ struct sr_ctx {
     sr::rt::Hooks rt_hooks{};
     void *rt_scratch[2] = {nullptr, nullptr};   // packed intermediates of the register-tiled path
     size_t rt_scratch_bytes[2] = {0, 0};
+    // the scratch is shared by every call on this context: a call on another stream first waits for the previous user
+    hipEvent_t rt_scratch_free = nullptr;
+    hipStream_t rt_scratch_stream = nullptr;
+    bool rt_scratch_used = false;
     void *tables = nullptr;  // [tw (D elems) | itw (D elems)] in table form
     size_t table_bytes = 0;
     // inverse stage-0 constants (table form): plain inverse, and fused ring-mul (with boundary correction)
@@ -485,31 +489,51 @@ int rt_ensure_scratch(sr_ctx *c, int n_buffers, size_t bytes) {
     }
     return SR_OK;
 }
+// stream ordering of the shared scratch (callers hold the context's mutex, so the bookkeeping itself is serialised)
+int rt_scratch_acquire(sr_ctx *c, hipStream_t st) {
+    if (c->k <= 12) return SR_OK;
+    if (!c->rt_scratch_free) HIP_TRY(hipEventCreateWithFlags(&c->rt_scratch_free, hipEventDisableTiming));
+    if (c->rt_scratch_used && c->rt_scratch_stream != st) HIP_TRY(hipStreamWaitEvent(st, c->rt_scratch_free, 0));
+    return SR_OK;
+}
+int rt_scratch_release(sr_ctx *c, hipStream_t st) {
+    if (c->k <= 12) return SR_OK;
+    HIP_TRY(hipEventRecord(c->rt_scratch_free, st));
+    c->rt_scratch_stream = st;
+    c->rt_scratch_used = true;
+    return SR_OK;
+}
 template <class F>
 int rt_fwd(sr_ctx *c, uint64_t *d, size_t batch, hipStream_t st) {
     using E = typename F::elem;
     if (int rc = rt_ensure_scratch(c, 1, (batch << c->k) * sizeof(E))) return rc;
-    return sr::rt::fwd<F>(c->rt_hooks, reinterpret_cast<typename F::storage *>(d), batch, make_rt_params<F>(c, false),
-                          (E *)c->rt_scratch[0], st)
-               ? fail(SR_E_HIP, "register-tiled launch failed") : SR_OK;
+    if (int rc = rt_scratch_acquire(c, st)) return rc;
+    if (sr::rt::fwd<F>(c->rt_hooks, reinterpret_cast<typename F::storage *>(d), batch, make_rt_params<F>(c, false),
+                       (E *)c->rt_scratch[0], st))
+        return fail(SR_E_HIP, "register-tiled launch failed");
+    return rt_scratch_release(c, st);
 }
 template <class F>
 int rt_inv(sr_ctx *c, uint64_t *d, size_t batch, hipStream_t st) {
     using E = typename F::elem;
     if (int rc = rt_ensure_scratch(c, 1, (batch << c->k) * sizeof(E))) return rc;
-    return sr::rt::inv<F>(c->rt_hooks, reinterpret_cast<typename F::storage *>(d), batch, make_rt_params<F>(c, false),
-                          (E *)c->rt_scratch[0], st)
-               ? fail(SR_E_HIP, "register-tiled launch failed") : SR_OK;
+    if (int rc = rt_scratch_acquire(c, st)) return rc;
+    if (sr::rt::inv<F>(c->rt_hooks, reinterpret_cast<typename F::storage *>(d), batch, make_rt_params<F>(c, false),
+                       (E *)c->rt_scratch[0], st))
+        return fail(SR_E_HIP, "register-tiled launch failed");
+    return rt_scratch_release(c, st);
 }
 template <class F>
 int rt_ring_mul(sr_ctx *c, uint64_t *out, const uint64_t *a, uint64_t *b, size_t batch, hipStream_t st) {
     using S = typename F::storage;
     using E = typename F::elem;
     if (int rc = rt_ensure_scratch(c, 2, (batch << c->k) * sizeof(E))) return rc;
-    return sr::rt::ring_mul<F>(c->rt_hooks, reinterpret_cast<S *>(out), reinterpret_cast<const S *>(a),
-                               reinterpret_cast<const S *>(b), batch, make_rt_params<F>(c, true), (E *)c->rt_scratch[0],
-                               (E *)c->rt_scratch[1], st)
-               ? fail(SR_E_HIP, "register-tiled launch failed") : SR_OK;
+    if (int rc = rt_scratch_acquire(c, st)) return rc;
+    if (sr::rt::ring_mul<F>(c->rt_hooks, reinterpret_cast<S *>(out), reinterpret_cast<const S *>(a),
+                            reinterpret_cast<const S *>(b), batch, make_rt_params<F>(c, true), (E *)c->rt_scratch[0],
+                            (E *)c->rt_scratch[1], st))
+        return fail(SR_E_HIP, "register-tiled launch failed");
+    return rt_scratch_release(c, st);
 }
 
 bool is_pow2_ring(int ring) { return ring >= SR_RING_GOLDILOCKS_POW2 && ring <= SR_RING_STARK_POW2; }
@@ -780,6 +804,7 @@ int sr_ctx_destroy(sr_ctx *c) {
     for (int i = 0; i < 2; i++)
         if (c->rt_scratch[i]) (void)hipFree(c->rt_scratch[i]);
     if (c->out_stream) (void)hipStreamDestroy(c->out_stream);
+    if (c->rt_scratch_free) (void)hipEventDestroy(c->rt_scratch_free);
     if (c->d_counter) (void)hipFree(c->d_counter);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;

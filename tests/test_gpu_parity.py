@@ -850,3 +850,28 @@ def test_host_pointer_pipeline_chunks_equal_one_shot(torch_cuda, name, k, batch)
         del os.environ["SR_HOST_CHUNK_MB"]
     if k:
         assert np.array_equal(one_mul, O.pow2_ring_mul(F, a, b, k, batch, 4))
+
+
+def test_device_calls_on_two_streams_share_one_context(torch_cuda):
+    """Two HIP streams interleave device-resident BabyBear products (D = 2^16: the register-tiled path keeps packed
+    intermediates in context-owned scratch) on ONE context: the scratch hand-over between streams is ordered by an event."""
+    torch = torch_cuda
+    F, k, batch = O.BABYBEAR, 16, 6
+    ring = ring_for("babybear", k)
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    data = []
+    for i in range(6):
+        a = O.fill_uniform(F, 0x600 + i, 0, batch << k)
+        b = O.fill_uniform(F, 0x700 + i, 0, batch << k)
+        data.append((torch.from_numpy(a.view(np.int64)).cuda(), torch.from_numpy(b.view(np.int64)).cuda(),
+                     O.pow2_ring_mul(F, a, b, k, batch, 4)))
+    torch.cuda.synchronize()
+    outs = []
+    for i, (ta, tb, _) in enumerate(data):
+        st = streams[i & 1]
+        out = torch.empty_like(ta)
+        ring.mul_dev(out, ta, tb, stream=st)
+        outs.append(out)
+    torch.cuda.synchronize()
+    for out, (_, _, want) in zip(outs, data):
+        assert np.array_equal(out.cpu().numpy().view(np.uint64), want)
