@@ -1,0 +1,86 @@
+#!/usr/bin/env python3
+"""Randomised differential soak (not part of pytest): random ring, degree, batch and operation against the oracle for a fixed
+wall-clock budget.  usage: fuzz_random_parity.py [seconds] [seed]"""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import numpy as np
+
+import oracle_lib as O
+import pyref as P
+from stark_rings_amd import CyclotomicRing
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+rings = {}
+
+
+def ring(name, k):
+    if (name, k) not in rings:
+        rings[(name, k)] = CyclotomicRing(name, k)
+    return rings[(name, k)]
+
+
+t_end = time.time() + budget
+n_checks, by_op = 0, {}
+while time.time() < t_end:
+    name = ["goldilocks", "babybear", "stark"][int(rng.integers(0, 3))]
+    kmax = {"goldilocks": 18, "babybear": 17, "stark": 13}[name]
+    k = int(rng.integers(0, kmax + 1))
+    F = O.FIELD_ID[name]
+    p = P.PRIMES[name][0]
+    d = 1 << k
+    cap = max(1, min(40, (1 << 19) // d))
+    batch = int(rng.integers(1, cap + 1)) if rng.random() < 0.8 else int(rng.integers(0, 3))
+    r = ring(name, k)
+    seed = int(rng.integers(0, 1 << 30))
+    a = O.fill_uniform(F, seed, 0, batch * d)
+    b = O.fill_uniform(F, seed + 1, 0, batch * d)
+    if batch and rng.random() < 0.3:   # adversarial coefficients
+        special = [0, 1, p - 1, p - 2, (p - 1) // 2, (1 << 32) % p, ((1 << 32) - 1) % p, ((1 << 64) - 1) % p]
+        vals = [special[int(rng.integers(0, len(special)))] for _ in range(d)]
+        a[:d * O.LIMBS[F]] = O.to_mont(F, vals)
+    op = ["crt", "icrt", "mul", "ntt_mul", "add", "sub", "reduce", "decompose", "rot"][int(rng.integers(0, 9))]
+    ok = True
+    if op == "crt":
+        ok = np.array_equal(r.elementwise_crt(a.copy()), O.pow2_fwd(F, a, k, batch, 4)) if batch else True
+    elif op == "icrt":
+        ok = np.array_equal(r.elementwise_icrt(O.pow2_fwd(F, a, k, batch, 4)), a) if batch else True
+    elif op == "mul":
+        ok = np.array_equal(r.mul(a, b), O.pow2_ring_mul(F, a, b, k, batch, 4)) if batch else r.mul(a, b).size == 0
+    elif op == "ntt_mul":
+        ok = np.array_equal(r.ntt_mul(a.copy(), b), O.pow2_pointwise(F, a, b)) if batch else True
+    elif op in ("add", "sub"):
+        if batch:
+            sa, sb = O.from_mont(F, a), O.from_mont(F, b)
+            got = O.from_mont(F, (r.add if op == "add" else r.sub)(a.copy(), b))
+            ok = got == [((x + y) if op == "add" else (x - y)) % p for x, y in zip(sa, sb)]
+    elif op == "reduce":
+        in_len = int(rng.integers(0, 2 * d + 1))
+        src = O.fill_uniform(F, seed + 2, 0, max(batch, 1) * in_len) if in_len else np.zeros(0, dtype=np.uint64)
+        got = r.reduce(src, in_len, max(batch, 1))
+        L = O.LIMBS[F]
+        for e in range(max(batch, 1)):
+            want = O.pow2_reduce(F, src[e * in_len * L:(e + 1) * in_len * L], in_len, k) if in_len else np.zeros(d * L, dtype=np.uint64)
+            ok = ok and np.array_equal(got[e * d * L:(e + 1) * d * L], want)
+    elif op == "decompose" and batch:
+        basis = [2, 4, 6, 16, 1 << 10, 1 << 16, 1 << 32, 10, 1000][int(rng.integers(0, 9))]
+        pad = 1
+        while (basis // 2) * (basis ** pad - 1) // (basis - 1) < (p - 1) // 2:
+            pad += 1
+        pad += int(rng.integers(1, 3))
+        want, over = O.decompose_balanced(F, a, d, batch, basis, pad)
+        got = r.gadget_decompose(a, basis, pad)
+        ok = (not over) and np.array_equal(got, want) and np.array_equal(r.gadget_recompose(got, basis, pad), a)
+    elif op == "rot" and batch and d > 1:
+        ok = np.array_equal(r.rot(a.copy()), O.rot(F, a, d, False))
+    n_checks += 1
+    by_op[op] = by_op.get(op, 0) + 1
+    if not ok:
+        print("MISMATCH: %s k=%d batch=%d op=%s seed=%d" % (name, k, batch, op, seed))
+        sys.exit(1)
+print("random differential soak: %d checks in %.0f s, 0 mismatches; per op %s" % (n_checks, budget, by_op))
