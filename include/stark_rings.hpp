@@ -28,6 +28,12 @@
 //     for &[R] / Vec<R>                  mod.rs:163-206                (digit j of element e = element e * k + j; throws where it panics)
 //   SparseMatrix<RqNTT>                  sparse_matrix.rs:17-22      class SparseMatrixNTT  (coeffs: rows of (element, column))
 //     checked_mul_vec / try_mul_vec      sparse_matrix.rs:201-216      same contract; an out-of-range column throws (the reference panics)
+//   CanonicalSerialize / Deserialize     coeff_form.rs:154-189,      serialize_compressed(vec / matrix) -> bytes, deserialize_*(cfg, bytes):
+//     for ring elements, Vec, Matrix,    ntt_form.rs:24,               the element bytes come from the device codec (sr_serialize_batch), the
+//     SparseMatrix                       matrix.rs:111-145,            u64 length words and (R, usize) pairs are written here; InvalidData and
+//                                        sparse_matrix.rs:158-200      short input throw
+//   monomial / unit_monomial / psi /     crates/ring/src/            same names; BaseRing scalars are passed as their signed representative
+//     exp / exp_signed / psi_range_check monomial.rs:17-93             (Zq::center and sign, ring.rs:160-181) in an int64_t
 //
 // What is deliberately narrowed: ring elements of degree 2^16 are 512 KiB, so the per-element `Copy` value type of
 // the reference (ring.rs:13-15) is not mirrored; the drop-in seam is the batch (hard part 4).
@@ -58,6 +64,8 @@ public:
     size_t dimension() const { return degree_; }            // PolyRing::dimension()
     int limbs() const { return limbs_; }                    // N
     size_t words_per_elem() const { return degree_ * (size_t)limbs_; }
+    size_t wire_coeff_bytes() const { return sr_wire_coeff_bytes(raw()); }   // bytes of one serialised coefficient
+    size_t wire_elem_bytes() const { return degree_ * wire_coeff_bytes(); }
     int crt_field_extension_degree() const {
         return ring_ == SR_RING_GOLDILOCKS_24 ? 3 : (ring_ == SR_RING_BABYBEAR_72 ? 9 : (ring_ == SR_RING_FROG_16 ? 4 : 1));
     }
@@ -295,6 +303,176 @@ private:
     std::vector<uint64_t> vals_, row_ptr_;
     std::vector<uint32_t> cols_;
 };
+
+// ---- CanonicalSerialize / CanonicalDeserialize (ark-serialize; Compress and Validate make no difference for these types) ----
+namespace wire_detail {
+inline void put_u64(std::vector<uint8_t> &out, uint64_t v) {
+    for (int i = 0; i < 8; i++) out.push_back((uint8_t)(v >> (8 * i)));
+}
+inline uint64_t get_u64(const std::vector<uint8_t> &in, size_t &pos) {
+    if (pos + 8 > in.size()) throw std::runtime_error("deserialize: unexpected end of input");
+    uint64_t v = 0;
+    for (int i = 0; i < 8; i++) v |= (uint64_t)in[pos + i] << (8 * i);
+    pos += 8;
+    return v;
+}
+// the elements alone (what [Fp; D] / RqNTT serialise to, coeff_form.rs:157-163), appended to out
+inline void put_elems(const CyclotomicConfig &cfg, std::vector<uint8_t> &out, const uint64_t *words, size_t n_elems) {
+    if (!n_elems) return;
+    const size_t at = out.size();
+    out.resize(at + n_elems * cfg.wire_elem_bytes());
+    CyclotomicConfig::check(sr_serialize_batch(cfg.raw(), out.data() + at, words, n_elems), "serialize");
+}
+inline std::vector<uint64_t> get_elems(const CyclotomicConfig &cfg, const uint8_t *bytes, size_t n_elems) {
+    std::vector<uint64_t> w(n_elems * cfg.words_per_elem());
+    if (n_elems) CyclotomicConfig::check(sr_deserialize_batch(cfg.raw(), w.data(), bytes, n_elems), "deserialize");
+    return w;
+}
+}  // namespace wire_detail
+
+// Vec<RqPoly> / Vec<RqNTT>: u64 length, then the elements
+template <class V>
+inline std::vector<uint8_t> serialize_compressed(const V &v) {
+    std::vector<uint8_t> out;
+    wire_detail::put_u64(out, v.len());
+    wire_detail::put_elems(v.config(), out, v.words().data(), v.len());
+    return out;
+}
+template <class V>
+inline V deserialize_vec(const CyclotomicConfig &cfg, const std::vector<uint8_t> &in, size_t *pos_io = nullptr) {
+    size_t pos = pos_io ? *pos_io : 0;
+    const uint64_t n = wire_detail::get_u64(in, pos);
+    if (n > (in.size() - pos) / cfg.wire_elem_bytes()) throw std::runtime_error("deserialize: unexpected end of input");
+    V v(cfg, wire_detail::get_elems(cfg, in.data() + pos, n));
+    pos += n * cfg.wire_elem_bytes();
+    if (pos_io) *pos_io = pos;
+    return v;
+}
+// Matrix<RqNTT> = Vec<Vec<RqNTT>> (matrix.rs:111-124)
+inline std::vector<uint8_t> serialize_compressed(const MatrixNTT &m, const CyclotomicConfig &cfg) {
+    std::vector<uint8_t> out;
+    wire_detail::put_u64(out, m.nrows());
+    for (size_t r = 0; r < m.nrows(); r++) {
+        wire_detail::put_u64(out, m.ncols());
+        wire_detail::put_elems(cfg, out, m.words().data() + r * m.ncols() * cfg.words_per_elem(), m.ncols());
+    }
+    return out;
+}
+// matrix.rs:132-144: ncols is the first row's length; ragged rows (which the reference accepts and trips over later) throw
+inline MatrixNTT deserialize_matrix(const CyclotomicConfig &cfg, const std::vector<uint8_t> &in) {
+    size_t pos = 0;
+    const uint64_t nrows = wire_detail::get_u64(in, pos);
+    uint64_t ncols = 0;
+    std::vector<uint64_t> words;
+    for (uint64_t r = 0; r < nrows; r++) {
+        RqNTTVec row = deserialize_vec<RqNTTVec>(cfg, in, &pos);
+        if (r == 0) ncols = row.len();
+        if (row.len() != ncols) throw std::runtime_error("deserialize: ragged matrix rows");
+        words.insert(words.end(), row.words().begin(), row.words().end());
+    }
+    return MatrixNTT(cfg, nrows, ncols, std::move(words));
+}
+// SparseMatrix<RqNTT>: nrows, ncols, Vec<Vec<(RqNTT, usize)>> (sparse_matrix.rs:158-175)
+inline std::vector<uint8_t> serialize_compressed(const CyclotomicConfig &cfg, size_t nrows, size_t ncols,
+                                                 const std::vector<std::vector<SparseMatrixNTT::Entry>> &coeffs) {
+    std::vector<uint8_t> out;
+    wire_detail::put_u64(out, nrows);
+    wire_detail::put_u64(out, ncols);
+    wire_detail::put_u64(out, coeffs.size());
+    for (const auto &row : coeffs) {
+        wire_detail::put_u64(out, row.size());
+        for (const auto &e : row) {
+            if (e.first.size() != cfg.words_per_elem()) throw std::length_error("Wrong length");
+            wire_detail::put_elems(cfg, out, e.first.data(), 1);
+            wire_detail::put_u64(out, e.second);
+        }
+    }
+    return out;
+}
+struct SparseParts {
+    size_t nrows, ncols;
+    std::vector<std::vector<SparseMatrixNTT::Entry>> coeffs;
+};
+inline SparseParts deserialize_sparse(const CyclotomicConfig &cfg, const std::vector<uint8_t> &in) {  // sparse_matrix.rs:183-199
+    size_t pos = 0;
+    SparseParts s;
+    s.nrows = wire_detail::get_u64(in, pos);
+    s.ncols = wire_detail::get_u64(in, pos);
+    const uint64_t nlists = wire_detail::get_u64(in, pos);
+    for (uint64_t r = 0; r < nlists; r++) {
+        const uint64_t n = wire_detail::get_u64(in, pos);
+        std::vector<SparseMatrixNTT::Entry> row;
+        for (uint64_t j = 0; j < n; j++) {
+            if (pos + cfg.wire_elem_bytes() > in.size()) throw std::runtime_error("deserialize: unexpected end of input");
+            std::vector<uint64_t> e = wire_detail::get_elems(cfg, in.data() + pos, 1);
+            pos += cfg.wire_elem_bytes();
+            const uint64_t col = wire_detail::get_u64(in, pos);
+            row.emplace_back(std::move(e), (size_t)col);
+        }
+        s.coeffs.push_back(std::move(row));
+    }
+    return s;
+}
+
+// ---- monomial helpers (crates/ring/src/monomial.rs:17-93), coefficient form, one element each ----------------------------
+namespace monomial_detail {
+// ring element from signed small integers: each coefficient's standard form is c mod p, written as wire bytes (p - |c| needs
+// the modulus: a negative coefficient is produced on the device as 0 - |c|)
+inline RqPolyVec from_signed(const CyclotomicConfig &cfg, const std::vector<int64_t> &coeffs) {
+    const size_t d = cfg.dimension(), w = cfg.wire_coeff_bytes();
+    if (coeffs.size() != d) throw std::length_error("Wrong length");
+    std::vector<uint8_t> pos_b(d * w, 0), neg_b(d * w, 0);
+    for (size_t i = 0; i < d; i++) {
+        const uint64_t mag = coeffs[i] < 0 ? (uint64_t)0 - (uint64_t)coeffs[i] : (uint64_t)coeffs[i];
+        std::vector<uint8_t> &dst = coeffs[i] < 0 ? neg_b : pos_b;
+        for (size_t b = 0; b < w && b < 8; b++) dst[i * w + b] = (uint8_t)(mag >> (8 * b));
+        if (w < 8 && (mag >> (8 * w))) throw std::runtime_error("coefficient magnitude does not fit the field");
+    }
+    RqPolyVec pos(cfg, wire_detail::get_elems(cfg, pos_b.data(), 1));
+    RqPolyVec neg(cfg, wire_detail::get_elems(cfg, neg_b.data(), 1));
+    pos -= neg;
+    return pos;
+}
+}  // namespace monomial_detail
+
+inline RqPolyVec monomial(const CyclotomicConfig &cfg, size_t i, int64_t coeff) {   // monomial.rs:17-21; index past D panics there
+    if (i >= cfg.dimension()) throw std::out_of_range("monomial: index outside the ring's dimension");
+    std::vector<int64_t> c(cfg.dimension(), 0);
+    c[i] = coeff;
+    return monomial_detail::from_signed(cfg, c);
+}
+inline RqPolyVec zero_monomial(const CyclotomicConfig &cfg) { return RqPolyVec(cfg, std::vector<uint64_t>(cfg.words_per_elem(), 0)); }
+inline RqPolyVec unit_monomial(const CyclotomicConfig &cfg, size_t i) { return monomial(cfg, i, 1); }
+inline RqPolyVec psi(const CyclotomicConfig &cfg) {                                   // monomial.rs:36-49
+    const size_t d = cfg.dimension();
+    std::vector<int64_t> c(d, 0);
+    for (size_t i = 1; i < d / 2; i++) {
+        c[i] += (int64_t)i;
+        c[d - i] -= (int64_t)i;
+    }
+    return monomial_detail::from_signed(cfg, c);
+}
+// a: the signed representative of the scalar (sign(a), center(a) = |a|)
+inline RqPolyVec exp(const CyclotomicConfig &cfg, int64_t a) {                        // monomial.rs:56-66
+    const uint64_t mag = a < 0 ? (uint64_t)0 - (uint64_t)a : (uint64_t)a;
+    if (a >= 0) return unit_monomial(cfg, mag);
+    if (mag > cfg.dimension()) throw std::out_of_range("monomial: index outside the ring's dimension");
+    return unit_monomial(cfg, cfg.dimension() - mag);
+}
+inline RqPolyVec exp_signed(const CyclotomicConfig &cfg, int64_t a) {                 // monomial.rs:72-78
+    const uint64_t mag = a < 0 ? (uint64_t)0 - (uint64_t)a : (uint64_t)a;
+    return monomial(cfg, mag, a < 0 ? -1 : 1);
+}
+// Ok(()) -> true, MonomialError::RangeCheck -> false                                  // monomial.rs:84-93
+inline bool psi_range_check(const CyclotomicConfig &cfg, int64_t a) {
+    RqPolyVec prod = psi(cfg) * exp(cfg, a);
+    std::vector<int64_t> want(cfg.dimension(), 0);
+    want[0] = a;
+    RqPolyVec a_elem = monomial_detail::from_signed(cfg, want);
+    for (int l = 0; l < cfg.limbs(); l++)
+        if (prod.words()[l] != a_elem.words()[l]) return false;   // ct(): coefficient 0, compared in the memory image
+    return true;
+}
 
 // Flatten (flatten.rs:10-34): the flat coefficient vector IS the batch's storage; both directions are moves.
 template <class V>

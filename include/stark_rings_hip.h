@@ -147,6 +147,26 @@ int sr_recompose_batch_dev(sr_ctx *ctx, uint64_t *d_out, const uint64_t *d_in, u
                            size_t batch_out, void *stream);
 int sr_decompose_balanced_batch(sr_ctx *ctx, uint64_t *out, const uint64_t *in, uint64_t basis, size_t padding_size, size_t batch);
 int sr_recompose_batch(sr_ctx *ctx, uint64_t *out, const uint64_t *in, uint64_t basis, size_t padding_size, size_t batch_out);
+/* Third "next" row: the ark-serialize canonical wire format of a batch of ring elements --
+ * CanonicalSerialize / CanonicalDeserialize for RqPoly (crates/ring/src/cyclotomic_ring/coeff_form.rs:154-189) and RqNTT
+ * (ntt_form.rs:24, derived), both the flat coefficient array: each coefficient is the standard-form integer (out of
+ * Montgomery form) as sr_wire_coeff_bytes() little-endian bytes (8 Goldilocks / frog, 4 BabyBear, 32 Stark; ark-ff 0.4.2
+ * Fp::serialize_with_flags with EmptyFlags, third party: the byte layout is restated from the published format and is
+ * PARITY UNPINNED -- the reference holds no serialised golden bytes).  An element is D * sr_wire_coeff_bytes() bytes; no
+ * length prefix (the u64 length words of Vec / Matrix / SparseMatrix, matrix.rs:111-145, sparse_matrix.rs:158-200, are
+ * host-side framing: include/stark_rings.hpp, stark_rings_amd/wire.py).
+ * d_offsets (optional, device, one u64 per element): byte offset of the element inside the wire buffer, multiples of 8, so the
+ * caller can leave room for its framing words; NULL = densely packed.  Wire and element buffers must not overlap.
+ * Deserialising a coefficient >= p is ark's SerializationError::InvalidData: the device form stores 0 for it and counts it
+ * (sr_wire_invalid_count reads and clears the count, synchronising the stream; misaligned offsets are counted there too and
+ * their elements skipped); the host form returns SR_E_INVALID. */
+size_t sr_wire_coeff_bytes(const sr_ctx *ctx);
+int sr_serialize_batch_dev(sr_ctx *ctx, uint8_t *d_wire, const uint64_t *d_in, const uint64_t *d_offsets, size_t batch, void *stream);
+int sr_deserialize_batch_dev(sr_ctx *ctx, uint64_t *d_out, const uint8_t *d_wire, const uint64_t *d_offsets, size_t batch,
+                             void *stream);
+int sr_wire_invalid_count(sr_ctx *ctx, unsigned long long *out, void *stream);
+int sr_serialize_batch(sr_ctx *ctx, uint8_t *wire, const uint64_t *in, size_t batch);
+int sr_deserialize_batch(sr_ctx *ctx, uint64_t *out, const uint8_t *wire, size_t batch);
 /* d_b is used as scratch and holds crt(b) afterwards when D exceeds one LDS tile; d_out may alias d_a. */
 int sr_ring_mul_batch_dev(sr_ctx *ctx, uint64_t *d_out, const uint64_t *d_a, uint64_t *d_b, size_t batch, void *stream);
 int sr_reduce_batch_dev(sr_ctx *ctx, const uint64_t *d_in, size_t in_len_per_elem, uint64_t *d_out, size_t batch, void *stream);

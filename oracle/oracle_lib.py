@@ -45,6 +45,9 @@ def lib():
             "sro_pow2_reduce": (i, [i, _u64p, sz, _u64p, i]),
             "sro_schoolbook": (i, [i, _u64p, _u64p, sz, _u64p]),
             "sro_rot": (None, [i, _u64p, sz, i, _u64p]),
+            "sro_wire_bytes": (sz, [i]),
+            "sro_serialize": (None, [i, _u64p, sz, ctypes.c_void_p]),
+            "sro_deserialize": (sz, [i, ctypes.c_void_p, sz, _u64p]),
             "sro_decompose_balanced": (i, [i, _u64p, sz, sz, ctypes.c_uint64, sz, _u64p]),
             "sro_recompose": (i, [i, _u64p, sz, sz, ctypes.c_uint64, sz, _u64p]),
             "sro_pow2_ring_mul": (i, [i, _u64p, _u64p, _u64p, i]),
@@ -192,6 +195,29 @@ def recompose(field, digits, d, batch_out, b, k):
     out = np.empty(batch_out * d * LIMBS[field], dtype=np.uint64)
     assert lib().sro_recompose(field, ptr(digits), d, batch_out, b, k, ptr(out)) == 0
     return out
+
+
+def wire_bytes(field):
+    return int(lib().sro_wire_bytes(field))
+
+
+def serialize(field, a):
+    """ark-serialize bytes of the flat coefficients (uint8 array)."""
+    a = np.ascontiguousarray(a, dtype=np.uint64)
+    n = a.size // LIMBS[field]
+    out = np.zeros(max(n * wire_bytes(field), 1), dtype=np.uint8)
+    lib().sro_serialize(field, ptr(a), n, out.ctypes.data_as(ctypes.c_void_p))
+    return out[:n * wire_bytes(field)]
+
+
+def deserialize(field, wire):
+    """-> (coefficients in Montgomery form, number of coefficients >= p)"""
+    wire = np.ascontiguousarray(wire, dtype=np.uint8)
+    n = wire.size // wire_bytes(field)
+    out = np.zeros(max(n * LIMBS[field], 1), dtype=np.uint64)
+    src = wire if wire.size else np.zeros(8, dtype=np.uint8)
+    bad = lib().sro_deserialize(field, src.ctypes.data_as(ctypes.c_void_p), n, ptr(out))
+    return out[:n * LIMBS[field]], int(bad)
 
 
 def small(fn_name, a, b=None):

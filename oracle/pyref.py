@@ -562,3 +562,95 @@ def rot(c, p, trinomial=False):
     if trinomial:
         out[len(c) // 2] = (out[len(c) // 2] + last) % p
     return out
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# ark-serialize wire format: coeff_form.rs:154-189 / ntt_form.rs:24 serialise the flat coefficient array;
+# each coefficient is ark-ff 0.4.2 Fp::serialize_with_flags with EmptyFlags (third party, restated from the published format):
+# the standard-form integer as ceil(MODULUS_BIT_SIZE / 8) little-endian bytes.  Parity unpinned (no golden bytes in the reference).
+def wire_bytes(name):
+    return (PRIMES[name][0].bit_length() + 7) // 8
+
+
+def serialize(name, std_coeffs):
+    w = wire_bytes(name)
+    return b"".join(int(x).to_bytes(w, "little") for x in std_coeffs)
+
+
+def deserialize(name, data):
+    """-> list of standard-form integers; ValueError("InvalidData") for an integer >= p (Fp::from_bigint -> None)."""
+    w, p = wire_bytes(name), PRIMES[name][0]
+    if len(data) % w:
+        raise ValueError("truncated")
+    out = [int.from_bytes(data[i:i + w], "little") for i in range(0, len(data), w)]
+    if any(x >= p for x in out):
+        raise ValueError("InvalidData")
+    return out
+
+
+def serialize_vec(name, elems):
+    """Vec<R>: u64 little-endian length, then the elements (ark-serialize Vec<T>)."""
+    return len(elems).to_bytes(8, "little") + b"".join(serialize(name, e) for e in elems)
+
+
+def serialize_matrix(name, rows):
+    """Matrix<R> = its Vec<Vec<R>> (crates/linear_algebra/src/matrix.rs:111-124)."""
+    return len(rows).to_bytes(8, "little") + b"".join(serialize_vec(name, r) for r in rows)
+
+
+def serialize_sparse(name, nrows, ncols, rows):
+    """SparseMatrix<R>: nrows u64, ncols u64, then Vec<Vec<(R, usize)>> (sparse_matrix.rs:158-175); usize goes out as u64."""
+    out = nrows.to_bytes(8, "little") + ncols.to_bytes(8, "little") + len(rows).to_bytes(8, "little")
+    for row in rows:
+        out += len(row).to_bytes(8, "little")
+        for elem, col in row:
+            out += serialize(name, elem) + int(col).to_bytes(8, "little")
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Monomial helpers (crates/ring/src/monomial.rs:17-93), standard-form coefficient lists; Zq::center / sign ring.rs:160-181
+def monomial(d, i, coeff):
+    m = [0] * d                      # monomial.rs:17-21 (index out of range panics there: IndexError here)
+    m[i] = coeff
+    return m
+
+
+def psi_table(d, p):
+    """psi = sum_{i in [1, d/2)} i (X^i - X^(d-i))  (monomial.rs:36-49)"""
+    out = [0] * d
+    for i in range(1, d // 2):
+        out[i] = (out[i] + i) % p
+        out[d - i] = (out[d - i] - i) % p
+    return out
+
+
+def center(a, p):
+    return p - a if a > (p - 1) // 2 else a
+
+
+def exp_monomial(d, a, p):
+    """exp(a) = sign(a) X^a as the reference computes it: the UNIT monomial X^centered for a >= 0 and X^(d - centered) otherwise
+    (monomial.rs:56-66); centered must fit usize and index the array"""
+    c = center(a, p)
+    idx = c if a <= (p - 1) // 2 else d - c
+    if not 0 <= idx < d:
+        raise IndexError("monomial index out of range")
+    return monomial(d, idx, 1)
+
+
+def exp_signed(d, a, p):
+    """monomial(centered, 1) * sign(a)  (monomial.rs:72-78)"""
+    c = center(a, p)
+    if not 0 <= c < d:
+        raise IndexError("monomial index out of range")
+    return monomial(d, c, 1 if a <= (p - 1) // 2 else p - 1)
+
+
+def psi_range_check(name, log2_d, a):
+    """ct(exp(a) * psi) == a  (monomial.rs:84-93); the product is the ring product modulo X^d + 1"""
+    p = PRIMES[name][0]
+    d = 1 << log2_d
+    b = exp_monomial(d, a, p)
+    prod = pow2_reduce(name, schoolbook(name, psi_table(d, p), b), log2_d)
+    return prod[0] == a % p

@@ -230,6 +230,51 @@ void sro_from_mont(int field, const uint64_t *in, uint64_t *out, size_t n) {
 }
 
 /* ======================================================================================
+ * ark-serialize wire format of field elements -- SURVEY 8f #3.
+ *   RqPoly = [Fp; D] coeff_form.rs:154-189; RqNTT ntt_form.rs:24 (derived): a ring element is its flat coefficients.
+ *   Per coefficient: ark-ff 0.4.2 Fp::serialize_with_flags / deserialize_with_flags with EmptyFlags (third party,
+ *   Cargo.lock:59-62, not in the tree; restated from the published algorithm): the standard-form integer as
+ *   ceil(MODULUS_BIT_SIZE / 8) little-endian bytes; reading rejects an integer >= p (InvalidData).
+ *   PARITY UNPINNED for the byte layout: the reference holds no serialised golden bytes. */
+size_t sro_wire_bytes(int field) { return field == SRO_STARK ? 32 : (field == SRO_BABYBEAR ? 4 : 8); }
+
+void sro_serialize(int field, const uint64_t *in, size_t n, uint8_t *out) {
+    const size_t w = sro_wire_bytes(field);
+    const int L = sro_limbs(field);
+    uint64_t std[4];
+    for (size_t i = 0; i < n; i++) {
+        sro_from_mont(field, in + (size_t)L * i, std, 1);
+        for (size_t b = 0; b < w; b++) out[i * w + b] = (uint8_t)(std[b / 8] >> (8 * (b % 8)));
+    }
+}
+
+/* returns the number of coefficients that are not below the modulus (each reads as 0) */
+size_t sro_deserialize(int field, const uint8_t *in, size_t n, uint64_t *out) {
+    const size_t w = sro_wire_bytes(field);
+    const int L = sro_limbs(field);
+    size_t bad = 0;
+    if (field == SRO_STARK) pthread_once(&g_once, init_all);
+    for (size_t i = 0; i < n; i++) {
+        uint64_t std[4] = {0, 0, 0, 0};
+        for (size_t b = 0; b < w; b++) std[b / 8] |= (uint64_t)in[i * w + b] << (8 * (b % 8));
+        int ok;
+        if (field == SRO_STARK) {
+            fe4 s;
+            memcpy(&s, std, 32);
+            ok = !fe4_geq(&s, &STARK_P);
+        } else {
+            ok = std[0] < cfg64(field)->p;
+        }
+        if (!ok) {
+            bad++;
+            std[0] = std[1] = std[2] = std[3] = 0;
+        }
+        sro_to_mont(field, std, out + (size_t)L * i, 1);
+    }
+    return bad;
+}
+
+/* ======================================================================================
  * Balanced (gadget) decomposition -- SURVEY 8f #2.
  *   decompose_balanced_in_place  crates/ring/src/balanced_decomposition/mod.rs:62-117
  *   signed representative        fq_convertible.rs:21-35 (Fp64), stark_prime/decomposition.rs:41-53 (Fp256):

@@ -31,6 +31,13 @@ int sro_limbs(int field);
 void sro_to_mont(int field, const uint64_t *std_in, uint64_t *mont_out, size_t n);
 void sro_from_mont(int field, const uint64_t *mont_in, uint64_t *std_out, size_t n);
 
+/* ark-serialize wire format (coeff_form.rs:154-189, ntt_form.rs:24; ark-ff 0.4.2 Fp::serialize_with_flags):
+ * n coefficients <-> n * sro_wire_bytes(field) bytes, little-endian standard form.  sro_deserialize returns the number of
+ * coefficients >= p (ark: InvalidData), each read as 0.  Byte layout restated from the published format: parity unpinned. */
+size_t sro_wire_bytes(int field);
+void sro_serialize(int field, const uint64_t *in, size_t n, uint8_t *out);
+size_t sro_deserialize(int field, const uint8_t *in, size_t n, uint64_t *out);
+
 /* ---- generalised power-of-two ring  Fp[X]/(X^D+1), D = 2^log2d  (SURVEY a10, Appendix A;
  *      algorithm of stark_prime/ntt.rs:121-346 with psi = g^((p-1)/2D)) ---- */
 int sro_pow2_fwd(int field, uint64_t *a, int log2d);                       /* crt_in_place  */

@@ -44,6 +44,12 @@ SYMBOLS = {
     "sr_recompose_batch_dev": (_c.c_int, [_c.c_void_p] * 3 + [_c.c_uint64, _c.c_size_t, _c.c_size_t, _c.c_void_p]),
     "sr_decompose_balanced_batch": (_c.c_int, [_c.c_void_p] * 3 + [_c.c_uint64, _c.c_size_t, _c.c_size_t]),
     "sr_recompose_batch": (_c.c_int, [_c.c_void_p] * 3 + [_c.c_uint64, _c.c_size_t, _c.c_size_t]),
+    "sr_wire_coeff_bytes": (_c.c_size_t, [_c.c_void_p]),
+    "sr_serialize_batch_dev": (_c.c_int, [_c.c_void_p] * 4 + [_c.c_size_t, _c.c_void_p]),
+    "sr_deserialize_batch_dev": (_c.c_int, [_c.c_void_p] * 4 + [_c.c_size_t, _c.c_void_p]),
+    "sr_wire_invalid_count": (_c.c_int, [_c.c_void_p, _c.POINTER(_c.c_ulonglong), _c.c_void_p]),
+    "sr_serialize_batch": (_c.c_int, [_c.c_void_p] * 3 + [_c.c_size_t]),
+    "sr_deserialize_batch": (_c.c_int, [_c.c_void_p] * 3 + [_c.c_size_t]),
     "sr_rot_batch_dev": (_c.c_int, [_c.c_void_p] * 3 + [_c.c_size_t, _c.c_void_p]),
     "sr_rot_batch": (_c.c_int, [_c.c_void_p, u64p, _c.c_size_t]),
     "sr_ring_mul_batch_dev": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_size_t, _c.c_void_p]),

@@ -22,6 +22,7 @@
 #include "ntt_regtile.hpp"
 #include "small_rings.hpp"
 #include "decompose.hpp"
+#include "wire.hpp"
 #include "frog_ring.hpp"
 
 namespace {
@@ -601,6 +602,40 @@ int rot_dev(sr_ctx *c, uint64_t *out, const uint64_t *in, size_t batch, hipStrea
     return SR_OK;
 }
 }
+extern "C++" {
+template <class F>
+int wire_dev(sr_ctx *c, bool ser, void *out, const void *in, const uint64_t *offsets, size_t batch, hipStream_t st) {
+    using S = typename F::storage;
+    const size_t n = batch * c->degree;
+    if (n == 0) return SR_OK;
+    size_t blocks = (n + 255) / 256;
+    if (blocks > 1u << 20) blocks = 1u << 20;
+    ProfScope ps(c, st, K_OTHER);
+    if (ser)
+        hipLaunchKernelGGL((sr::wire::serialize_kernel<F>), dim3((unsigned)blocks), dim3(256), 0, st, (uint8_t *)out,
+                           reinterpret_cast<const S *>(in), c->degree, batch, offsets, c->d_counter + 3);
+    else
+        hipLaunchKernelGGL((sr::wire::deserialize_kernel<F>), dim3((unsigned)blocks), dim3(256), 0, st, reinterpret_cast<S *>(out),
+                           (const uint8_t *)in, c->degree, batch, offsets, c->d_counter + 3);
+    HIP_TRY(hipGetLastError());
+    return SR_OK;
+}
+template <class F>
+size_t wire_width() {
+    return sr::wire::Codec<F>::W;
+}
+}
+int dev_wire(sr_ctx *c, bool ser, void *out, const void *in, const uint64_t *offsets, size_t batch, hipStream_t st) {
+    DISPATCH_FIELD(c, (wire_dev<F>(c, ser, out, in, offsets, batch, st)));
+}
+size_t wire_coeff_bytes(const sr_ctx *c) {
+    switch (c->ring) {
+        case SR_RING_BABYBEAR_POW2: case SR_RING_BABYBEAR_72: return wire_width<sr::BabyBear>();
+        case SR_RING_STARK_POW2: return wire_width<sr::Stark>();
+        case SR_RING_FROG_16: return wire_width<sr::Frog>();
+        default: return wire_width<sr::Goldilocks>();
+    }
+}
 int dev_rot(sr_ctx *c, uint64_t *out, const uint64_t *in, size_t batch, hipStream_t st) {
     DISPATCH_FIELD(c, (rot_dev<F>(c, out, in, batch, st)));
 }
@@ -745,8 +780,8 @@ int sr_ctx_create(int ring, int log2_degree, int device, sr_ctx **out) {
     if (hipStreamCreateWithFlags(&c->out_stream, hipStreamNonBlocking) != hipSuccess) return bail(fail(SR_E_HIP, "hipStreamCreate failed"));
     // three words: [0] scratch counter of count_noncanonical, [1] out-of-range column indices seen by spmv, [2] coefficients
     // that needed more digits than padding_size in a decomposition (both sticky until read)
-    if (hipMalloc(&c->d_counter, 3 * sizeof(unsigned long long)) != hipSuccess) return bail(fail(SR_E_ALLOC, "hipMalloc counter failed"));
-    if (hipMemset(c->d_counter, 0, 3 * sizeof(unsigned long long)) != hipSuccess) return bail(fail(SR_E_HIP, "hipMemset counter failed"));
+    if (hipMalloc(&c->d_counter, 4 * sizeof(unsigned long long)) != hipSuccess) return bail(fail(SR_E_ALLOC, "hipMalloc counter failed"));
+    if (hipMemset(c->d_counter, 0, 4 * sizeof(unsigned long long)) != hipSuccess) return bail(fail(SR_E_HIP, "hipMemset counter failed"));
     if (is_pow2_ring(ring)) {
         c->k = log2_degree;
         c->degree = (size_t)1 << log2_degree;
@@ -921,6 +956,31 @@ int sr_rot_batch(sr_ctx *c, uint64_t *data, size_t batch) {
     HIP_TRY(hipStreamSynchronize(c->stream));
     return SR_OK;
 }
+size_t sr_wire_coeff_bytes(const sr_ctx *c) { return c ? wire_coeff_bytes(c) : 0; }
+int sr_serialize_batch_dev(sr_ctx *c, uint8_t *wire, const uint64_t *in, const uint64_t *offsets, size_t batch, void *stream) {
+    if (int rc = check(c, wire, in)) return rc;
+    if ((const void *)wire == (const void *)in) return fail(SR_E_INVALID, "serialize: wire must not alias in");
+    std::lock_guard<std::mutex> lk(c->mu);
+    DeviceGuard g(c->device);
+    return dev_wire(c, true, wire, in, offsets, batch, (hipStream_t)stream);
+}
+int sr_deserialize_batch_dev(sr_ctx *c, uint64_t *out, const uint8_t *wire, const uint64_t *offsets, size_t batch, void *stream) {
+    if (int rc = check(c, out, wire)) return rc;
+    if ((const void *)wire == (const void *)out) return fail(SR_E_INVALID, "deserialize: out must not alias wire");
+    std::lock_guard<std::mutex> lk(c->mu);
+    DeviceGuard g(c->device);
+    return dev_wire(c, false, out, wire, offsets, batch, (hipStream_t)stream);
+}
+int sr_wire_invalid_count(sr_ctx *c, unsigned long long *out, void *stream) {
+    if (int rc = check(c, out)) return rc;
+    std::lock_guard<std::mutex> lk(c->mu);
+    DeviceGuard g(c->device);
+    hipStream_t st = (hipStream_t)stream;
+    HIP_TRY(hipMemcpyAsync(out, c->d_counter + 3, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemsetAsync(c->d_counter + 3, 0, sizeof(unsigned long long), st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return SR_OK;
+}
 int sr_decompose_balanced_batch_dev(sr_ctx *c, uint64_t *out, const uint64_t *in, uint64_t basis, size_t padding_size, size_t batch,
                                     void *stream) {
     if (int rc = check(c, out, in)) return rc;
@@ -1047,6 +1107,43 @@ int sr_decompose_balanced_batch(sr_ctx *c, uint64_t *out, const uint64_t *in, ui
     HIP_TRY(hipMemsetAsync(c->d_counter + 2, 0, sizeof(unsigned long long), c->stream));
     // the reference indexes out[padding_size] and panics (mod.rs:81-91)
     if (over) return fail(SR_E_INVALID, "decompose: a coefficient needs more than padding_size digits");
+    return SR_OK;
+}
+int sr_serialize_batch(sr_ctx *c, uint8_t *wire, const uint64_t *in, size_t batch) {
+    if (int rc = check(c, wire, in)) return rc;
+    std::lock_guard<std::mutex> lk(c->mu);
+    DeviceGuard g(c->device);
+    const size_t n = batch * c->degree;
+    if (n == 0) return SR_OK;
+    DevBuf din, dw;
+    if (int rc = din.alloc(n * c->limbs * 8)) return rc;
+    if (int rc = dw.alloc(n * wire_coeff_bytes(c))) return rc;
+    HIP_TRY(hipMemcpyAsync(din.p, in, n * c->limbs * 8, hipMemcpyHostToDevice, c->stream));
+    if (int rc = dev_wire(c, true, dw.p, din.p, nullptr, batch, c->stream)) return rc;
+    HIP_TRY(hipMemcpyAsync(wire, dw.p, n * wire_coeff_bytes(c), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return SR_OK;
+}
+int sr_deserialize_batch(sr_ctx *c, uint64_t *out, const uint8_t *wire, size_t batch) {
+    if (int rc = check(c, out, wire)) return rc;
+    std::lock_guard<std::mutex> lk(c->mu);
+    DeviceGuard g(c->device);
+    const size_t n = batch * c->degree;
+    if (n == 0) return SR_OK;
+    DevBuf dout, dw;
+    if (int rc = dout.alloc(n * c->limbs * 8)) return rc;
+    if (int rc = dw.alloc(n * wire_coeff_bytes(c))) return rc;
+    HIP_TRY(hipMemcpyAsync(dw.p, wire, n * wire_coeff_bytes(c), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemsetAsync(c->d_counter + 3, 0, sizeof(unsigned long long), c->stream));
+    if (int rc = dev_wire(c, false, dout.p, dw.p, nullptr, batch, c->stream)) return rc;
+    unsigned long long bad = 0;
+    HIP_TRY(hipMemcpyAsync(&bad, c->d_counter + 3, sizeof bad, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipMemsetAsync(c->d_counter + 3, 0, sizeof(unsigned long long), c->stream));
+    // Fp::deserialize_with_flags: from_bigint(..) is None for an integer >= p -> SerializationError::InvalidData
+    if (bad) return fail(SR_E_INVALID, "deserialize: a coefficient is not below the modulus (InvalidData)");
+    HIP_TRY(hipMemcpyAsync(out, dout.p, n * c->limbs * 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
     return SR_OK;
 }
 int sr_recompose_batch(sr_ctx *c, uint64_t *out, const uint64_t *in, uint64_t basis, size_t padding_size, size_t batch_out) {

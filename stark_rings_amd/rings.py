@@ -35,6 +35,15 @@ _RING_NAMES = {
 }
 
 
+# BaseFieldConfig moduli: goldilocks/mod.rs:20-24, babybear/mod.rs:21-25, stark_prime/mod.rs:20-24, frog_ring/mod.rs:19-25
+_MODULUS = {
+    GOLDILOCKS_POW2: 2**64 - 2**32 + 1, GOLDILOCKS_24: 2**64 - 2**32 + 1,
+    BABYBEAR_POW2: 2013265921, BABYBEAR_72: 2013265921,
+    STARK_POW2: 2**251 + 17 * 2**192 + 1,
+    FROG_16: 15912092521325583641,
+}
+
+
 class RingError(RuntimeError):
     pass
 
@@ -66,6 +75,7 @@ class CyclotomicRing:
         self.degree = d.value          # PolyRing::dimension()
         self.limbs = l.value           # N
         self.words_per_elem = self.degree * self.limbs
+        self.modulus = _MODULUS[self.ring]
 
     # -- lifetime --------------------------------------------------------------------------
     def close(self):
@@ -217,6 +227,32 @@ class CyclotomicRing:
         self._check(self._lib.sr_recompose_batch(self._ctx, _np_ptr(out), _np_ptr(src), basis, padding_size, batch_out))
         return out[:batch_out * self.words_per_elem]
 
+    @property
+    def wire_coeff_bytes(self):
+        """Bytes per coefficient on the ark-serialize wire: 8 (Goldilocks, frog), 4 (BabyBear), 32 (Stark)."""
+        return int(self._lib.sr_wire_coeff_bytes(self._ctx))
+
+    def serialize(self, a):
+        """CanonicalSerialize of every ring element of the batch (coeff_form.rs:154-189, ntt_form.rs:24): the flat coefficients as
+        little-endian standard-form integers, wire_coeff_bytes each, no length prefix.  Returns a uint8 array."""
+        batch = self._batch_of(a.size)
+        out = np.empty(max(batch * self.degree * self.wire_coeff_bytes, 1), dtype=np.uint8)
+        src = a if a.size else np.zeros(1, dtype=np.uint64)
+        self._check(self._lib.sr_serialize_batch(self._ctx, out.ctypes.data_as(ctypes.c_void_p), _np_ptr(src), batch))
+        return out[:batch * self.degree * self.wire_coeff_bytes]
+
+    def deserialize(self, wire):
+        """CanonicalDeserialize of a whole number of ring elements; RingError (ark: InvalidData) when a coefficient is >= p."""
+        wire = np.ascontiguousarray(wire, dtype=np.uint8)
+        per = self.degree * self.wire_coeff_bytes
+        if wire.size % per:
+            raise RingError("deserialize: not a whole number of ring elements")
+        batch = wire.size // per
+        out = np.empty(max(batch * self.words_per_elem, 1), dtype=np.uint64)
+        src = wire if wire.size else np.zeros(8, dtype=np.uint8)
+        self._check(self._lib.sr_deserialize_batch(self._ctx, _np_ptr(out), src.ctypes.data_as(ctypes.c_void_p), batch))
+        return out[:batch * self.words_per_elem]
+
     def reduce(self, coeffs, in_len_per_elem, batch):
         """CyclotomicConfig::reduce_in_place (ring_config.rs:23): (batch, in_len) -> (batch, D)."""
         if coeffs.size != batch * in_len_per_elem * self.limbs:
@@ -354,6 +390,50 @@ class CyclotomicRing:
             raise RingError("recompose: digits must hold len(out) * padding_size elements")
         self._check(self._lib.sr_recompose_batch_dev(self._ctx, po, pd, basis, padding_size, self._batch_of(n), self._stream(stream)))
         return out
+
+    def serialize_dev(self, wire, a, offsets=None, stream=None):
+        """wire: uint8 CUDA tensor; a: ring elements; offsets: optional int64 CUDA tensor, one byte offset (multiple of 8) per
+        element, for callers that interleave framing words; None = densely packed."""
+        import torch
+
+        pa, n = self._dev(a)
+        batch = self._batch_of(n)
+        if wire.dtype != torch.uint8 or not wire.is_cuda or not wire.is_contiguous():
+            raise RingError("serialize: wire must be a contiguous uint8 CUDA tensor")
+        if offsets is None:
+            if wire.numel() != batch * self.degree * self.wire_coeff_bytes:
+                raise RingError("serialize: wire must hold len * D * wire_coeff_bytes bytes")
+            po = 0
+        else:
+            if offsets.dtype != torch.int64 or offsets.numel() != batch or not offsets.is_cuda:
+                raise RingError("serialize: offsets must be an int64 CUDA tensor with one entry per element")
+            po = offsets.data_ptr()
+        self._check(self._lib.sr_serialize_batch_dev(self._ctx, wire.data_ptr(), pa, po, batch, self._stream(stream)))
+        return wire
+
+    def deserialize_dev(self, out, wire, offsets=None, stream=None):
+        """Inverse of serialize_dev; coefficients >= p are stored as 0 and counted (wire_invalid_count)."""
+        import torch
+
+        po_, n = self._dev(out)
+        batch = self._batch_of(n)
+        if wire.dtype != torch.uint8 or not wire.is_cuda or not wire.is_contiguous():
+            raise RingError("deserialize: wire must be a contiguous uint8 CUDA tensor")
+        if offsets is None:
+            if wire.numel() != batch * self.degree * self.wire_coeff_bytes:
+                raise RingError("deserialize: wire must hold len * D * wire_coeff_bytes bytes")
+            po = 0
+        else:
+            if offsets.dtype != torch.int64 or offsets.numel() != batch or not offsets.is_cuda:
+                raise RingError("deserialize: offsets must be an int64 CUDA tensor with one entry per element")
+            po = offsets.data_ptr()
+        self._check(self._lib.sr_deserialize_batch_dev(self._ctx, po_, wire.data_ptr(), po, batch, self._stream(stream)))
+        return out
+
+    def wire_invalid_count(self, stream=None):
+        n = ctypes.c_ulonglong(0)
+        self._check(self._lib.sr_wire_invalid_count(self._ctx, ctypes.byref(n), self._stream(stream)))
+        return int(n.value)
 
     def mul_dev(self, out, a, b, stream=None):
         """out = a * b; b is clobbered (holds crt(b)) when D exceeds one LDS tile; out may be a."""

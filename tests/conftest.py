@@ -30,4 +30,5 @@ def kats():
         d = json.load(f)
     rings = dict(d["rings"])
     rings["decomposition"] = d["decomposition"]   # balanced-decomposition KATs ("next" row 2) ride along under their own key
+    rings["monomial"] = d["monomial"]             # monomial.rs tests ("next" row 4)
     return rings

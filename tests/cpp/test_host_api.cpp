@@ -211,6 +211,92 @@ static void gadget_suite(sr_ring ring, int field, int log2d) {
     EXPECT(threw);
 }
 
+// CanonicalSerialize / CanonicalDeserialize round trips and parity with the oracle's restatement of the ark-serialize bytes
+// (coeff_form.rs:154-189, matrix.rs:111-145, sparse_matrix.rs:158-200)
+static void wire_suite(sr_ring ring, int field, int log2d) {
+    CyclotomicConfig cfg(ring, log2d);
+    const size_t d = cfg.dimension(), L = cfg.limbs(), batch = 5, wb = sro_wire_bytes(field);
+    EXPECT(cfg.wire_coeff_bytes() == wb);
+    auto a = uniform(field, 41, batch * d);
+    RqPolyVec v(cfg, a);
+    std::vector<uint8_t> bytes = serialize_compressed(v);
+    EXPECT(bytes.size() == 8 + batch * d * wb);
+    EXPECT(bytes[0] == batch && bytes[1] == 0 && bytes[7] == 0);
+    std::vector<uint8_t> want(batch * d * wb);
+    sro_serialize(field, a.data(), batch * d, want.data());
+    EXPECT(std::vector<uint8_t>(bytes.begin() + 8, bytes.end()) == want);
+    EXPECT(deserialize_vec<RqPolyVec>(cfg, bytes) == v);
+    // an integer >= p is InvalidData: all-ones bytes in one coefficient
+    std::vector<uint8_t> bad = bytes;
+    for (size_t b = 0; b < wb; b++) bad[8 + 3 * wb + b] = 0xFF;
+    bool threw = false;
+    try {
+        deserialize_vec<RqPolyVec>(cfg, bad);
+    } catch (const std::runtime_error &) {
+        threw = true;
+    }
+    EXPECT(threw);
+    threw = false;
+    try {
+        deserialize_vec<RqPolyVec>(cfg, std::vector<uint8_t>(bytes.begin(), bytes.end() - 1));   // short input
+    } catch (const std::runtime_error &) {
+        threw = true;
+    }
+    EXPECT(threw);
+    // Matrix and SparseMatrix framing
+    const size_t nrows = 2, ncols = 2;
+    MatrixNTT m(cfg, nrows, ncols, std::vector<uint64_t>(a.begin(), a.begin() + nrows * ncols * d * L));
+    std::vector<uint8_t> mb = serialize_compressed(m, cfg);
+    EXPECT(mb.size() == 8 + nrows * (8 + ncols * d * wb));
+    MatrixNTT m2 = deserialize_matrix(cfg, mb);
+    EXPECT(m2.nrows() == nrows && m2.ncols() == ncols && m2.words() == m.words());
+    std::vector<std::vector<SparseMatrixNTT::Entry>> rows(3);
+    rows[0].emplace_back(std::vector<uint64_t>(a.begin(), a.begin() + d * L), 4);
+    rows[2].emplace_back(std::vector<uint64_t>(a.begin() + d * L, a.begin() + 2 * d * L), 0);
+    rows[2].emplace_back(std::vector<uint64_t>(a.begin() + 2 * d * L, a.begin() + 3 * d * L), 6);
+    std::vector<uint8_t> sb = serialize_compressed(cfg, 3, 7, rows);
+    EXPECT(sb.size() == 24 + 3 * 8 + 3 * (d * wb + 8));
+    SparseParts sp = deserialize_sparse(cfg, sb);
+    EXPECT(sp.nrows == 3 && sp.ncols == 7 && sp.coeffs == rows);
+}
+
+// test_monomial_ops / test_monomial_range_check (crates/ring/src/monomial.rs:100-137) on the ring they use (frog, D = 16), and
+// on power-of-two rings of the other fields
+static void monomial_suite(sr_ring ring, int field, int log2d) {
+    CyclotomicConfig cfg(ring, log2d);
+    const size_t d = cfg.dimension(), L = cfg.limbs();
+    const int64_t half = (int64_t)d / 2;
+    RqPolyVec zero = zero_monomial(cfg), one = unit_monomial(cfg, 0);
+    RqPolyVec s = zero;
+    s += one;
+    EXPECT(s == one);                                            // 0 + 1 = 1
+    std::vector<uint64_t> std_one(4, 0), mont(4, 0);
+    std_one[0] = 1;
+    sro_to_mont(field, std_one.data(), mont.data(), 1);
+    for (size_t l = 0; l < L; l++) EXPECT(one.words()[l] == mont[l]);
+    if (d >= 16) {
+        RqPolyVec x2 = monomial(cfg, 2, 1), x15 = monomial(cfg, d - 1, 1);
+        RqPolyVec p = x2 * x15;                                  // X^2 * X^(d-1) = -X
+        RqPolyVec minus_x = monomial(cfg, 1, -1);
+        EXPECT(p == minus_x);
+    }
+    EXPECT(psi_range_check(cfg, 1));
+    EXPECT(psi_range_check(cfg, half - 1));
+    EXPECT(!psi_range_check(cfg, half));
+    EXPECT(psi_range_check(cfg, -1));
+    EXPECT(psi_range_check(cfg, -(half - 1)));
+    EXPECT(!psi_range_check(cfg, -half));
+    EXPECT(psi_range_check(cfg, 0));
+    bool threw = false;
+    try {
+        psi_range_check(cfg, (int64_t)d + 3);                    // unit_monomial indexes past the array: panic in the reference
+    } catch (const std::out_of_range &) {
+        threw = true;
+    }
+    EXPECT(threw);
+    EXPECT(exp_signed(cfg, -3) == monomial(cfg, 3, -1));
+}
+
 int main() {
     try {
         pow2_suite(SR_RING_GOLDILOCKS_POW2, SRO_GOLDILOCKS, 10, 3);   // BASELINE configs[0]: D = 2^10 (batch 1 is element 0)
@@ -224,6 +310,14 @@ int main() {
         linalg_suite(SR_RING_GOLDILOCKS_POW2, SRO_GOLDILOCKS, 6);
         linalg_suite(SR_RING_BABYBEAR_POW2, SRO_BABYBEAR, 5);
         linalg_suite(SR_RING_STARK_POW2, SRO_STARK, 4);
+        wire_suite(SR_RING_GOLDILOCKS_POW2, SRO_GOLDILOCKS, 6);
+        wire_suite(SR_RING_BABYBEAR_POW2, SRO_BABYBEAR, 5);
+        wire_suite(SR_RING_STARK_POW2, SRO_STARK, 4);
+        wire_suite(SR_RING_FROG_16, SRO_FROG, 0);
+        monomial_suite(SR_RING_FROG_16, SRO_FROG, 0);                 // the reference's own test ring
+        monomial_suite(SR_RING_GOLDILOCKS_POW2, SRO_GOLDILOCKS, 6);
+        monomial_suite(SR_RING_BABYBEAR_POW2, SRO_BABYBEAR, 5);
+        monomial_suite(SR_RING_STARK_POW2, SRO_STARK, 4);
         small_suite(SR_RING_GOLDILOCKS_24, SRO_GOLDILOCKS, 24, 3, sro_g24_crt, sro_g24_ntt_mul, sro_g24_icrt);
         small_suite(SR_RING_BABYBEAR_72, SRO_BABYBEAR, 72, 9, sro_bb72_crt, sro_bb72_ntt_mul, sro_bb72_icrt);
         small_suite(SR_RING_FROG_16, SRO_FROG, 16, 4, sro_frog16_crt, sro_frog16_ntt_mul, sro_frog16_icrt);   // frog_ring/mod.rs tests

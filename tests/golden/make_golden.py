@@ -14,6 +14,7 @@ Sources:
   stark_prime/decomposition.rs  test_stark_prime_decomposition (balanced digits of one Fq, basis 2^16)
   balanced_decomposition/mod.rs test_gadget_decompose / test_gadget_recompose / test_sparse_matrix_gadget_decompose and the
                                 parameters of the property tests (Q, D, BASIS_TEST_RANGE)
+  monomial.rs        test_monomial_range_check (which scalars pass psi_range_check on the frog ring) and test_monomial_ops
 """
 import json
 import os
@@ -237,6 +238,23 @@ def main():
         "bases": [int(v) for v in re.search(r"BASIS_TEST_RANGE: \[u128; \d+\] = \[([^\]]+)\]", consts).group(1).split(",")],
         "scalar_padding": 32, "vector_padding": 16}
     out["decomposition"] = dec
+
+    # ---------------- monomial helpers ("next" row 4): crates/ring/src/monomial.rs tests ----------------
+    rel = "monomial.rs"
+    L = read(os.path.join(REF, "crates/ring/src", rel))
+    a, b = fn_span(L, "test_monomial_range_check")
+    text = "\n".join(L[a - 1:b])
+    names = {}
+    for m in re.finditer(r"let (\w+) = <RqPoly as PolyRing>::BaseRing::from\((\d+)u128\)( - (\w+))?;", text):
+        names[m.group(1)] = int(m.group(2)) - (names[m.group(4)] if m.group(4) else 0)
+    checks = [[names[m.group(1)], m.group(2) == "ok"]
+              for m in re.finditer(r"psi_range_check::<RqPoly>\((\w+)\)\.is_(ok|err)\(\)", text)]
+    a2, b2 = fn_span(L, "test_monomial_ops")
+    ops = "\n".join(L[a2 - 1:b2])
+    mono = {m.group(1): int(m.group(2)) for m in re.finditer(r"let (x\d+) = monomial::<RqPoly>\((\d+),", ops)}
+    out["monomial"] = {"source": rel, "ring": "frog16", "range_check": {"lines": [a, b], "cases": checks},
+                       "ops": {"lines": [a2, b2], "monomial_degrees": mono,
+                               "facts": ["0 + 1 = 1", "X^2 + X^2 has coefficient 2 at index 2", "X^2 * X^15 has coefficient -1 at index 1"]}}
 
     with open(OUT, "w") as f:
         json.dump(out, f, indent=1)

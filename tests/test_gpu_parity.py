@@ -875,3 +875,145 @@ def test_device_calls_on_two_streams_share_one_context(torch_cuda):
     torch.cuda.synchronize()
     for out, (_, _, want) in zip(outs, data):
         assert np.array_equal(out.cpu().numpy().view(np.uint64), want)
+
+
+# ----------------------------------------------------------------------------- "next" row 3: ark-serialize wire format
+WIRE_CASES = [("goldilocks", 6), ("goldilocks", 0), ("babybear", 5), ("babybear", 1), ("stark", 4), ("goldilocks24", 0),
+              ("babybear72", 0), ("frog16", 0)]
+
+
+def _base_field(name):
+    return O.FIELD_ID[{"goldilocks24": "goldilocks", "babybear72": "babybear", "frog16": "frog"}.get(name, name)]
+
+
+@pytest.mark.parametrize("name,k", WIRE_CASES)
+def test_wire_format_matches_oracle(torch_cuda, name, k):
+    """CanonicalSerialize / CanonicalDeserialize of ring elements (coeff_form.rs:154-189, ntt_form.rs:24) through the C ABI, host and
+    device entry points, against the oracle's restatement of the ark-serialize bytes; round trip; InvalidData for an integer >= p."""
+    from stark_rings_amd import RingError
+
+    torch = torch_cuda
+    F = _base_field(name)
+    ring = ring_for(name, k)
+    d, wb, batch = ring.degree, ring.wire_coeff_bytes, 37
+    assert wb == O.wire_bytes(F)
+    p = ring.modulus
+    a = O.fill_uniform(F, 0xA1, 0, batch * d)
+    a[:O.LIMBS[F] * min(d, 4)] = O.to_mont(F, [0, p - 1, 1, (p - 1) // 2][:min(d, 4)])
+    want = O.serialize(F, a)
+    got = ring.serialize(a)
+    assert got.dtype == np.uint8 and got.size == batch * d * wb
+    assert np.array_equal(got, want)
+    assert np.array_equal(ring.deserialize(got), a)
+    ta = torch.from_numpy(a.view(np.int64)).cuda()
+    tw = torch.empty(batch * d * wb, dtype=torch.uint8, device="cuda")
+    ring.serialize_dev(tw, ta)
+    assert np.array_equal(tw.cpu().numpy(), want)
+    tb = torch.zeros_like(ta)
+    ring.deserialize_dev(tb, tw)
+    assert torch.equal(ta, tb) and ring.wire_invalid_count() == 0
+    # empty batch
+    assert ring.serialize(np.zeros(0, dtype=np.uint64)).size == 0 and ring.deserialize(np.zeros(0, dtype=np.uint8)).size == 0
+    # coefficients that are not below the modulus: the host form refuses, the device form reads 0 and counts them
+    bad = want.copy()
+    for coeff, v in ((1, p), (d * batch - 1, (1 << (8 * wb)) - 1)):
+        bad[coeff * wb:(coeff + 1) * wb] = np.frombuffer(v.to_bytes(wb, "little"), dtype=np.uint8)
+    with pytest.raises(RingError):
+        ring.deserialize(bad)
+    ring.deserialize_dev(tb, torch.from_numpy(bad).cuda())
+    n_bad = 2 if d * batch - 1 != 1 else 1
+    assert ring.wire_invalid_count() == n_bad and ring.wire_invalid_count() == 0
+    ref, obad = O.deserialize(F, bad)
+    assert obad == n_bad and np.array_equal(tb.cpu().numpy().view(np.uint64), ref)
+    with pytest.raises(RingError):
+        ring.deserialize(want[:-1])          # not a whole number of elements
+
+
+@pytest.mark.parametrize("name,k", [("goldilocks", 5), ("babybear", 4), ("stark", 4), ("frog16", 0)])
+def test_wire_container_framing(torch_cuda, name, k):
+    """Vec<R>, Matrix<R> and SparseMatrix<R> (matrix.rs:111-145, sparse_matrix.rs:158-200) against the Python model's bytes; the
+    device-resident sparse writer (elements encoded at their framed offsets) produces the same bytes."""
+    from stark_rings_amd import wire
+
+    torch = torch_cuda
+    base = {"frog16": "frog"}.get(name, name)
+    F = O.FIELD_ID[base]
+    ring = ring_for(name, k)
+    d, w = ring.degree, ring.words_per_elem
+    n = 6
+    a = O.fill_uniform(F, 0xA2, 0, n * d)
+    std = O.from_mont(F, a)
+    elems = [std[e * d:(e + 1) * d] for e in range(n)]
+    v = wire.serialize_vec(ring, a)
+    assert v.tobytes() == P.serialize_vec(base, elems)
+    back, end = wire.deserialize_vec(ring, v)
+    assert end == v.size and np.array_equal(back, a)
+    m = wire.serialize_matrix(ring, a, 2, 3)
+    assert m.tobytes() == P.serialize_matrix(base, [elems[0:3], elems[3:6]])
+    mb, nr, nc = wire.deserialize_matrix(ring, m)
+    assert (nr, nc) == (2, 3) and np.array_equal(mb, a)
+    assert wire.serialize_matrix(ring, a[:0], 0, 0).tobytes() == (0).to_bytes(8, "little")
+    rows = [[(a[0:w], 5), (a[w:2 * w], 0)], [], [(a[2 * w:3 * w], 11)], [(a[3 * w:4 * w], 2), (a[4 * w:5 * w], 3), (a[5 * w:6 * w], 4)]]
+    model_rows = [[(elems[0], 5), (elems[1], 0)], [], [(elems[2], 11)], [(elems[3], 2), (elems[4], 3), (elems[5], 4)]]
+    s = wire.serialize_sparse(ring, 4, 12, rows)
+    assert s.tobytes() == P.serialize_sparse(base, 4, 12, model_rows)
+    nr, nc, back_rows = wire.deserialize_sparse(ring, s)
+    assert (nr, nc) == (4, 12) and [[c for _, c in r] for r in back_rows] == [[c for _, c in r] for r in rows]
+    assert all(np.array_equal(x[0], y[0]) for rx, ry in zip(back_rows, rows) for x, y in zip(rx, ry))
+    vals = torch.from_numpy(a.view(np.int64)).cuda()
+    cols = torch.tensor([5, 0, 11, 2, 3, 4], dtype=torch.int32, device="cuda")
+    row_ptr = torch.tensor([0, 2, 2, 3, 6], dtype=torch.int64, device="cuda")
+    sd = wire.serialize_sparse_dev(ring, 4, 12, vals, cols, row_ptr)
+    assert sd.cpu().numpy().tobytes() == s.tobytes()
+    assert ring.wire_invalid_count() == 0
+    # a misaligned element offset is refused on the device (counted, element skipped)
+    offs = torch.tensor([0, 4], dtype=torch.int64, device="cuda")
+    buf = torch.zeros(4 * d * ring.wire_coeff_bytes, dtype=torch.uint8, device="cuda")
+    ring.serialize_dev(buf, vals[:2 * w], offsets=offs)
+    assert ring.wire_invalid_count() == 1
+
+
+# ----------------------------------------------------------------------------- "next" row 4: monomial helpers
+def test_monomial_reference_kats_on_gpu(torch_cuda, kats):
+    """test_monomial_ops / test_monomial_range_check (crates/ring/src/monomial.rs:100-137) on the ring they use (frog, D = 16),
+    with the product taken by the ring multiplication of the C ABI."""
+    from stark_rings_amd import RingError, monomial as M
+
+    ring = ring_for("frog16", 0)
+    kat = kats["monomial"]
+    p = ring.modulus
+    for a, ok in kat["range_check"]["cases"]:
+        if ok:
+            M.psi_range_check(ring, a % p)
+        else:
+            with pytest.raises(RingError):
+                M.psi_range_check(ring, a % p)
+    zero, one = M.zero_monomial(ring), M.unit_monomial(ring, 0)
+    assert np.array_equal(ring.add(zero.copy(), one), one)
+    x2 = M.monomial(ring, kat["ops"]["monomial_degrees"]["x2"], 1)
+    x15 = M.monomial(ring, kat["ops"]["monomial_degrees"]["x15"], 1)
+    assert M.to_ints(ring, ring.add(x2.copy(), x2))[2] == 2
+    assert M.to_ints(ring, ring.mul(x2, x15))[1] == p - 1
+
+
+@pytest.mark.parametrize("name,k", [("goldilocks", 6), ("babybear", 5), ("stark", 4), ("frog16", 0), ("goldilocks", 10)])
+def test_monomial_helpers_match_model(torch_cuda, name, k):
+    """psi, exp, exp_signed and the batched range check against the Python model (monomial.rs:36-93)."""
+    from stark_rings_amd import RingError, monomial as M
+
+    base = {"frog16": "frog"}.get(name, name)
+    ring = ring_for(name, k)
+    p, d = ring.modulus, ring.degree
+    assert M.to_ints(ring, M.psi(ring)) == P.psi_table(d, p)
+    for a in (0, 1, 5, d // 2 - 1, d // 2, d - 1, p - 1, p - 3, p - d // 2, p - d):
+        assert M.to_ints(ring, M.exp(ring, a)) == P.exp_monomial(d, a, p)
+        if P.center(a, p) < d:
+            assert M.to_ints(ring, M.exp_signed(ring, a)) == P.exp_signed(d, a, p)
+    with pytest.raises(RingError):
+        M.exp(ring, d + 2)                    # the reference indexes past the coefficient array and panics
+    log2d = d.bit_length() - 1
+    vals = list(range(0, d)) + [p - v for v in range(1, d + 1)]
+    got = M.psi_range_check_batch(ring, vals)
+    assert got == [abs(v if v < d + 1 else v - p) < d // 2 for v in vals]
+    if d <= 64:
+        assert got == [P.psi_range_check(base, log2d, v) for v in vals]

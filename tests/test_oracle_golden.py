@@ -350,3 +350,76 @@ def test_rot_is_multiplication_by_x(name, d, tri):
         m = O.rot(F, m, d, tri)
         assert O.from_mont(F, m) == cur
     assert P.rot(a, p, tri) == times_x(a)
+
+
+# ----------------------------------------------------------------------------- ark-serialize wire format ("next" row 3)
+@pytest.mark.parametrize("name", ["goldilocks", "babybear", "stark", "frog"])
+def test_wire_format_c_vs_python(name):
+    """coeff_form.rs:154-189 / ntt_form.rs:24: a ring element serialises as its flat coefficients, each the standard-form integer
+    in ceil(bits / 8) little-endian bytes (ark-ff 0.4.2, restated -- the reference holds no golden bytes, so this pins the C
+    restatement to the Python one and both to the documented widths 8 / 4 / 32 / 8)."""
+    F, p = O.FIELD_ID[name], P.PRIMES[name][0]
+    assert O.wire_bytes(F) == P.wire_bytes(name) == {"goldilocks": 8, "babybear": 4, "stark": 32, "frog": 8}[name]
+    vals = [0, 1, 2, 255, 256, p - 1, p - 2, (p - 1) // 2, (1 << 31) % p, 0x0102030405060708 % p]
+    img = O.to_mont(F, vals)
+    wire = O.serialize(F, img)
+    assert wire.tobytes() == P.serialize(name, vals)
+    assert wire[:O.wire_bytes(F)].tolist() == [0] * O.wire_bytes(F)
+    assert wire[O.wire_bytes(F)] == 1 and wire[3 * O.wire_bytes(F)] == 255          # little-endian
+    back, bad = O.deserialize(F, wire)
+    assert bad == 0 and np.array_equal(back, img)
+    assert P.deserialize(name, wire.tobytes()) == vals
+    # an integer >= p is InvalidData (Fp::from_bigint -> None); p itself and all-ones
+    w = O.wire_bytes(F)
+    for v in (p, (1 << (8 * w)) - 1):
+        raw = np.frombuffer(v.to_bytes(w, "little"), dtype=np.uint8)
+        _, bad = O.deserialize(F, raw)
+        assert bad == 1
+        with pytest.raises(ValueError):
+            P.deserialize(name, raw.tobytes())
+    rnd = O.fill_uniform(F, 77, 0, 500)
+    assert O.serialize(F, rnd).tobytes() == P.serialize(name, O.from_mont(F, rnd))
+
+
+def test_wire_container_framing_model():
+    """Vec / Matrix / SparseMatrix framing of the Python model (matrix.rs:111-124, sparse_matrix.rs:158-175): lengths are u64
+    little-endian, a sparse entry is the element followed by its column as u64."""
+    e0, e1 = [1, 2], [3, 4]
+    v = P.serialize_vec("babybear", [e0, e1])
+    assert v == (2).to_bytes(8, "little") + bytes([1, 0, 0, 0, 2, 0, 0, 0, 3, 0, 0, 0, 4, 0, 0, 0])
+    m = P.serialize_matrix("babybear", [[e0], [e1]])
+    assert m == (2).to_bytes(8, "little") + (1).to_bytes(8, "little") + bytes([1, 0, 0, 0, 2, 0, 0, 0]) + \
+        (1).to_bytes(8, "little") + bytes([3, 0, 0, 0, 4, 0, 0, 0])
+    s = P.serialize_sparse("babybear", 2, 9, [[(e0, 7)], []])
+    assert s == (2).to_bytes(8, "little") + (9).to_bytes(8, "little") + (2).to_bytes(8, "little") + (1).to_bytes(8, "little") + \
+        bytes([1, 0, 0, 0, 2, 0, 0, 0]) + (7).to_bytes(8, "little") + (0).to_bytes(8, "little")
+
+
+# ----------------------------------------------------------------------------- monomial helpers ("next" row 4)
+def test_monomial_reference_kats(kats):
+    """crates/ring/src/monomial.rs:100-137 on the ring the reference tests use (frog, D = 16): which scalars pass
+    psi_range_check, and the three monomial facts."""
+    kat = kats["monomial"]
+    assert kat["ring"] == "frog16"
+    p, d = P.FROG_P, 16
+    for a, ok in kat["range_check"]["cases"]:
+        assert P.psi_range_check("frog", 4, a % p) is ok
+    x2 = P.monomial(d, kat["ops"]["monomial_degrees"]["x2"], 1)
+    x15 = P.monomial(d, kat["ops"]["monomial_degrees"]["x15"], 1)
+    zero, one = [0] * d, P.monomial(d, 0, 1)
+    assert [(x + y) % p for x, y in zip(zero, one)] == one
+    assert [(x + y) % p for x, y in zip(x2, x2)][2] == 2
+    assert P.pow2_reduce("frog", P.schoolbook("frog", x2, x15), 4)[1] == p - 1
+
+
+@pytest.mark.parametrize("name,k", [("goldilocks", 5), ("babybear", 3), ("stark", 4), ("frog", 4)])
+def test_psi_range_check_accepts_exactly_the_open_interval(name, k):
+    """monomial.rs:80-83: the check holds exactly for a in (-d/2, d/2); an index past the dimension panics in the reference."""
+    p, d = P.PRIMES[name][0], 1 << k
+    for a in range(-d, d + 1):
+        if abs(a) > d or a == d:
+            continue
+        assert P.psi_range_check(name, k, a % p) == (abs(a) < d // 2), a
+    with pytest.raises(IndexError):
+        P.psi_range_check(name, k, d + 5)
+    assert P.exp_signed(d, (p - 3), p) == P.monomial(d, 3, p - 1)

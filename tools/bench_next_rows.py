@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Throughput of the "next" rows (SURVEY 8f #1, #2) on one GPU, JSON lines: sparse mat-vec, dense mat-mat, balanced gadget
-decomposition and recomposition.  All are single streaming passes: the figure of merit is bytes moved / time against HBM."""
+"""Throughput of the "next" rows (SURVEY 8f #1, #2, #3) on one GPU, JSON lines: sparse mat-vec, dense mat-mat, balanced gadget
+decomposition and recomposition, the ark-serialize wire codec.  All are single streaming passes: the figure of merit is bytes moved / time against HBM."""
 import json
 import os
 import sys
@@ -73,4 +73,18 @@ for name, k, nrows, ncols, per_row in (("goldilocks", 16, 64, 1024, 64), ("babyb
         emit(op="gadget_recompose", ring=name, log2_degree=k, basis=basis, padding_size=padn, batch=batch, ms=dt * 1e3,
              gbytes_per_s=(src.numel() + dig.numel()) * 8 / 1e9 / dt, coefficients_per_s=batch * ring.degree / dt)
         del src, dig, back
+    # ark-serialize wire codec (8f #3): memory image -> wire bytes and back, one streaming pass each
+    batch = (1 << 31) // (ring.degree * ring.limbs * 8)           # 2 GiB of ring elements
+    src = torch.empty(batch * w, dtype=torch.int64, device="cuda")
+    ring.fill_uniform_dev(src, 9)
+    wire = torch.empty(batch * ring.degree * ring.wire_coeff_bytes, dtype=torch.uint8, device="cuda")
+    dt = timed(lambda: ring.serialize_dev(wire, src))
+    emit(op="serialize", ring=name, log2_degree=k, batch=batch, wire_coeff_bytes=ring.wire_coeff_bytes, ms=dt * 1e3,
+         gbytes_per_s=(src.numel() * 8 + wire.numel()) / 1e9 / dt, coefficients_per_s=batch * ring.degree / dt)
+    back = torch.empty_like(src)
+    dt = timed(lambda: ring.deserialize_dev(back, wire))
+    assert ring.wire_invalid_count() == 0 and torch.equal(back, src)
+    emit(op="deserialize", ring=name, log2_degree=k, batch=batch, wire_coeff_bytes=ring.wire_coeff_bytes, ms=dt * 1e3,
+         gbytes_per_s=(src.numel() * 8 + wire.numel()) / 1e9 / dt, coefficients_per_s=batch * ring.degree / dt)
+    del src, wire, back
     ring.close()
