@@ -669,6 +669,13 @@ int check(sr_ctx *c, const void *p0, const void *p1 = (const void *)1, const voi
     return SR_OK;
 }
 
+// element counts are bounded so that no byte count or shift below can wrap (64 TiB of ring elements is far past any device)
+int check_count(const sr_ctx *c, size_t n_elems, size_t per_elem = 1) {
+    const size_t cap = ((size_t)1 << 46) / (c->degree * (size_t)c->limbs * 8);
+    if (n_elems > cap || (per_elem > 1 && n_elems && per_elem > cap / n_elems)) return fail(SR_E_INVALID, "element count too large");
+    return SR_OK;
+}
+
 // ---- per-ring device dispatch (pow2 rings and the reference-native small rings) --------------
 int dev_fwd(sr_ctx *c, uint64_t *d, size_t batch, hipStream_t st) {
     if (c->ring == SR_RING_FROG_16) return sr::frog_launch(c->frog, sr::FROG_CRT, d, nullptr, 0, d, batch, st) ? fail(SR_E_HIP, "frog-ring launch failed") : SR_OK;
@@ -778,8 +785,9 @@ int sr_ctx_create(int ring, int log2_degree, int device, sr_ctx **out) {
     };
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) return bail(fail(SR_E_HIP, "hipStreamCreate failed"));
     if (hipStreamCreateWithFlags(&c->out_stream, hipStreamNonBlocking) != hipSuccess) return bail(fail(SR_E_HIP, "hipStreamCreate failed"));
-    // three words: [0] scratch counter of count_noncanonical, [1] out-of-range column indices seen by spmv, [2] coefficients
-    // that needed more digits than padding_size in a decomposition (both sticky until read)
+    // four words: [0] scratch counter of count_noncanonical, [1] out-of-range column indices seen by spmv, [2] coefficients
+    // that needed more digits than padding_size in a decomposition, [3] wire coefficients >= p / misaligned wire offsets
+    // ([1]..[3] sticky until read)
     if (hipMalloc(&c->d_counter, 4 * sizeof(unsigned long long)) != hipSuccess) return bail(fail(SR_E_ALLOC, "hipMalloc counter failed"));
     if (hipMemset(c->d_counter, 0, 4 * sizeof(unsigned long long)) != hipSuccess) return bail(fail(SR_E_HIP, "hipMemset counter failed"));
     if (is_pow2_ring(ring)) {
@@ -874,36 +882,42 @@ int sr_ctx_twiddles_updated(sr_ctx *c) {
 // ---- device-resident entry points ----
 int sr_ntt_fwd_batch_dev(sr_ctx *c, uint64_t *d, size_t batch, void *stream) {
     if (int rc = check(c, d)) return rc;
+    if (int rc = check_count(c, batch)) return rc;
     std::lock_guard<std::mutex> lk(c->mu);
     DeviceGuard g(c->device);
     return dev_fwd(c, d, batch, (hipStream_t)stream);
 }
 int sr_ntt_inv_batch_dev(sr_ctx *c, uint64_t *d, size_t batch, void *stream) {
     if (int rc = check(c, d)) return rc;
+    if (int rc = check_count(c, batch)) return rc;
     std::lock_guard<std::mutex> lk(c->mu);
     DeviceGuard g(c->device);
     return dev_inv(c, d, batch, (hipStream_t)stream);
 }
 int sr_pointwise_mul_batch_dev(sr_ctx *c, uint64_t *l, const uint64_t *r, size_t batch, void *stream) {
     if (int rc = check(c, l, r)) return rc;
+    if (int rc = check_count(c, batch)) return rc;
     std::lock_guard<std::mutex> lk(c->mu);
     DeviceGuard g(c->device);
     return dev_pointwise(c, l, r, batch, (hipStream_t)stream);
 }
 int sr_add_batch_dev(sr_ctx *c, uint64_t *l, const uint64_t *r, size_t batch, void *stream) {
     if (int rc = check(c, l, r)) return rc;
+    if (int rc = check_count(c, batch)) return rc;
     std::lock_guard<std::mutex> lk(c->mu);
     DeviceGuard g(c->device);
     return dev_addsub(c, l, r, batch, false, (hipStream_t)stream);
 }
 int sr_sub_batch_dev(sr_ctx *c, uint64_t *l, const uint64_t *r, size_t batch, void *stream) {
     if (int rc = check(c, l, r)) return rc;
+    if (int rc = check_count(c, batch)) return rc;
     std::lock_guard<std::mutex> lk(c->mu);
     DeviceGuard g(c->device);
     return dev_addsub(c, l, r, batch, true, (hipStream_t)stream);
 }
 int sr_matvec_ntt_dev(sr_ctx *c, uint64_t *y, const uint64_t *m, const uint64_t *v, size_t nrows, size_t ncols, void *stream) {
     if (int rc = check(c, y, m, v)) return rc;
+    if (check_count(c, nrows, ncols)) return SR_E_INVALID;
     if (y == m || y == v) return fail(SR_E_INVALID, "matvec: y must not alias M or v");
     std::lock_guard<std::mutex> lk(c->mu);
     DeviceGuard g(c->device);
@@ -912,6 +926,7 @@ int sr_matvec_ntt_dev(sr_ctx *c, uint64_t *y, const uint64_t *m, const uint64_t 
 int sr_spmv_ntt_dev(sr_ctx *c, uint64_t *y, const uint64_t *vals, const uint32_t *cols, const uint64_t *row_ptr, const uint64_t *v,
                     size_t nrows, size_t ncols, void *stream) {
     if (int rc = check(c, y, row_ptr, v)) return rc;
+    if (check_count(c, nrows) || check_count(c, ncols)) return SR_E_INVALID;   // the dense product nrows * ncols is irrelevant here
     if (y == v || y == vals) return fail(SR_E_INVALID, "spmv: y must not alias the matrix or v");
     std::lock_guard<std::mutex> lk(c->mu);
     DeviceGuard g(c->device);
@@ -929,6 +944,7 @@ int sr_spmv_bad_index_count(sr_ctx *c, unsigned long long *out, void *stream) {
 }
 int sr_matmul_ntt_dev(sr_ctx *c, uint64_t *y, const uint64_t *a, const uint64_t *b, size_t n, size_t m, size_t p, void *stream) {
     if (int rc = check(c, y, a, b)) return rc;
+    if (check_count(c, n, m) || check_count(c, m, p) || check_count(c, n, p)) return SR_E_INVALID;
     if (y == a || y == b) return fail(SR_E_INVALID, "matmul: y must not alias A or B");
     std::lock_guard<std::mutex> lk(c->mu);
     DeviceGuard g(c->device);
@@ -937,6 +953,7 @@ int sr_matmul_ntt_dev(sr_ctx *c, uint64_t *y, const uint64_t *a, const uint64_t 
 
 int sr_rot_batch_dev(sr_ctx *c, uint64_t *out, const uint64_t *in, size_t batch, void *stream) {
     if (int rc = check(c, out, in)) return rc;
+    if (int rc = check_count(c, batch)) return rc;
     if (out == in) return fail(SR_E_INVALID, "rot: out must not alias in");
     std::lock_guard<std::mutex> lk(c->mu);
     DeviceGuard g(c->device);
@@ -944,6 +961,7 @@ int sr_rot_batch_dev(sr_ctx *c, uint64_t *out, const uint64_t *in, size_t batch,
 }
 int sr_rot_batch(sr_ctx *c, uint64_t *data, size_t batch) {
     if (int rc = check(c, data)) return rc;
+    if (int rc = check_count(c, batch)) return rc;
     std::lock_guard<std::mutex> lk(c->mu);
     DeviceGuard g(c->device);
     const size_t bytes = batch * c->degree * c->limbs * 8;
@@ -959,6 +977,7 @@ int sr_rot_batch(sr_ctx *c, uint64_t *data, size_t batch) {
 size_t sr_wire_coeff_bytes(const sr_ctx *c) { return c ? wire_coeff_bytes(c) : 0; }
 int sr_serialize_batch_dev(sr_ctx *c, uint8_t *wire, const uint64_t *in, const uint64_t *offsets, size_t batch, void *stream) {
     if (int rc = check(c, wire, in)) return rc;
+    if (int rc = check_count(c, batch)) return rc;
     if ((const void *)wire == (const void *)in) return fail(SR_E_INVALID, "serialize: wire must not alias in");
     std::lock_guard<std::mutex> lk(c->mu);
     DeviceGuard g(c->device);
@@ -966,6 +985,7 @@ int sr_serialize_batch_dev(sr_ctx *c, uint8_t *wire, const uint64_t *in, const u
 }
 int sr_deserialize_batch_dev(sr_ctx *c, uint64_t *out, const uint8_t *wire, const uint64_t *offsets, size_t batch, void *stream) {
     if (int rc = check(c, out, wire)) return rc;
+    if (int rc = check_count(c, batch)) return rc;
     if ((const void *)wire == (const void *)out) return fail(SR_E_INVALID, "deserialize: out must not alias wire");
     std::lock_guard<std::mutex> lk(c->mu);
     DeviceGuard g(c->device);
@@ -984,6 +1004,7 @@ int sr_wire_invalid_count(sr_ctx *c, unsigned long long *out, void *stream) {
 int sr_decompose_balanced_batch_dev(sr_ctx *c, uint64_t *out, const uint64_t *in, uint64_t basis, size_t padding_size, size_t batch,
                                     void *stream) {
     if (int rc = check(c, out, in)) return rc;
+    if (int rc = check_count(c, batch, padding_size)) return rc;
     if (int rc = check_basis(basis)) return rc;
     if (out == in) return fail(SR_E_INVALID, "decompose: out must not alias in");
     std::lock_guard<std::mutex> lk(c->mu);
@@ -1003,6 +1024,7 @@ int sr_decompose_overflow_count(sr_ctx *c, unsigned long long *out, void *stream
 int sr_recompose_batch_dev(sr_ctx *c, uint64_t *out, const uint64_t *in, uint64_t basis, size_t padding_size, size_t batch_out,
                            void *stream) {
     if (int rc = check(c, out, in)) return rc;
+    if (int rc = check_count(c, batch_out, padding_size)) return rc;
     if (basis > (1ull << 32)) return fail(SR_E_INVALID, "recomposition basis above 2^32 is not supported");
     if (out == in) return fail(SR_E_INVALID, "recompose: out must not alias in");
     std::lock_guard<std::mutex> lk(c->mu);
@@ -1026,6 +1048,7 @@ struct DevBuf {
 }  // namespace
 int sr_matmul_ntt(sr_ctx *c, uint64_t *y, const uint64_t *a, const uint64_t *b, size_t n, size_t m, size_t p) {
     if (int rc = check(c, y, a, b)) return rc;
+    if (check_count(c, n, m) || check_count(c, m, p) || check_count(c, n, p)) return SR_E_INVALID;
     std::lock_guard<std::mutex> lk(c->mu);
     DeviceGuard g(c->device);
     const size_t w = c->degree * c->limbs * 8;
@@ -1042,6 +1065,7 @@ int sr_matmul_ntt(sr_ctx *c, uint64_t *y, const uint64_t *a, const uint64_t *b, 
 }
 int sr_matvec_ntt(sr_ctx *c, uint64_t *y, const uint64_t *m, const uint64_t *v, size_t nrows, size_t ncols) {
     if (int rc = check(c, y, m, v)) return rc;
+    if (check_count(c, nrows, ncols)) return SR_E_INVALID;
     std::lock_guard<std::mutex> lk(c->mu);
     DeviceGuard g(c->device);
     const size_t w = c->degree * c->limbs * 8;
@@ -1059,6 +1083,7 @@ int sr_matvec_ntt(sr_ctx *c, uint64_t *y, const uint64_t *m, const uint64_t *v, 
 int sr_spmv_ntt(sr_ctx *c, uint64_t *y, const uint64_t *vals, const uint32_t *cols, const uint64_t *row_ptr, const uint64_t *v,
                 size_t nrows, size_t ncols) {
     if (int rc = check(c, y, row_ptr, v)) return rc;
+    if (check_count(c, nrows) || check_count(c, ncols)) return SR_E_INVALID;
     const size_t nnz = (size_t)row_ptr[nrows];
     if (nnz && (!vals || !cols)) return fail(SR_E_INVALID, "null buffer");
     for (size_t r = 0; r < nrows; r++)
@@ -1089,6 +1114,7 @@ int sr_spmv_ntt(sr_ctx *c, uint64_t *y, const uint64_t *vals, const uint32_t *co
 }
 int sr_decompose_balanced_batch(sr_ctx *c, uint64_t *out, const uint64_t *in, uint64_t basis, size_t padding_size, size_t batch) {
     if (int rc = check(c, out, in)) return rc;
+    if (int rc = check_count(c, batch, padding_size)) return rc;
     if (int rc = check_basis(basis)) return rc;
     std::lock_guard<std::mutex> lk(c->mu);
     DeviceGuard g(c->device);
@@ -1111,6 +1137,7 @@ int sr_decompose_balanced_batch(sr_ctx *c, uint64_t *out, const uint64_t *in, ui
 }
 int sr_serialize_batch(sr_ctx *c, uint8_t *wire, const uint64_t *in, size_t batch) {
     if (int rc = check(c, wire, in)) return rc;
+    if (int rc = check_count(c, batch)) return rc;
     std::lock_guard<std::mutex> lk(c->mu);
     DeviceGuard g(c->device);
     const size_t n = batch * c->degree;
@@ -1126,6 +1153,7 @@ int sr_serialize_batch(sr_ctx *c, uint8_t *wire, const uint64_t *in, size_t batc
 }
 int sr_deserialize_batch(sr_ctx *c, uint64_t *out, const uint8_t *wire, size_t batch) {
     if (int rc = check(c, out, wire)) return rc;
+    if (int rc = check_count(c, batch)) return rc;
     std::lock_guard<std::mutex> lk(c->mu);
     DeviceGuard g(c->device);
     const size_t n = batch * c->degree;
@@ -1148,6 +1176,7 @@ int sr_deserialize_batch(sr_ctx *c, uint64_t *out, const uint8_t *wire, size_t b
 }
 int sr_recompose_batch(sr_ctx *c, uint64_t *out, const uint64_t *in, uint64_t basis, size_t padding_size, size_t batch_out) {
     if (int rc = check(c, out, in)) return rc;
+    if (int rc = check_count(c, batch_out, padding_size)) return rc;
     if (basis > (1ull << 32)) return fail(SR_E_INVALID, "recomposition basis above 2^32 is not supported");
     std::lock_guard<std::mutex> lk(c->mu);
     DeviceGuard g(c->device);
@@ -1164,6 +1193,7 @@ int sr_recompose_batch(sr_ctx *c, uint64_t *out, const uint64_t *in, uint64_t ba
 }
 int sr_ring_mul_batch_dev(sr_ctx *c, uint64_t *out, const uint64_t *a, uint64_t *b, size_t batch, void *stream) {
     if (int rc = check(c, out, a, b)) return rc;
+    if (int rc = check_count(c, batch)) return rc;
     if ((const uint64_t *)b == a || b == out) return fail(SR_E_INVALID, "ring_mul: b must not alias a or out");
     std::lock_guard<std::mutex> lk(c->mu);
     DeviceGuard g(c->device);
@@ -1171,6 +1201,7 @@ int sr_ring_mul_batch_dev(sr_ctx *c, uint64_t *out, const uint64_t *a, uint64_t 
 }
 int sr_reduce_batch_dev(sr_ctx *c, const uint64_t *in, size_t in_len, uint64_t *out, size_t batch, void *stream) {
     if (int rc = check(c, in, out)) return rc;
+    if (int rc = check_count(c, batch)) return rc;
     std::lock_guard<std::mutex> lk(c->mu);
     DeviceGuard g(c->device);
     return dev_reduce(c, in, in_len, out, batch, (hipStream_t)stream);
@@ -1318,6 +1349,7 @@ static int host_pipeline(sr_ctx *c, uint64_t *out, const uint64_t *a, const uint
 }  // extern "C++"
 static int host_inplace(sr_ctx *c, uint64_t *data, size_t batch, bool fwd) {
     if (int rc = check(c, data)) return rc;
+    if (int rc = check_count(c, batch)) return rc;
     std::lock_guard<std::mutex> lk(c->mu);
     DeviceGuard g(c->device);
     return host_pipeline(c, data, data, nullptr, batch, [&](uint64_t *s0, uint64_t *, size_t n, hipStream_t st) {
@@ -1330,6 +1362,7 @@ int sr_ntt_inv_batch(sr_ctx *c, uint64_t *data, size_t batch) { return host_inpl
 enum { HB_POINTWISE = 0, HB_RING_MUL = 1, HB_ADD = 2, HB_SUB = 3 };
 static int host_binary(sr_ctx *c, uint64_t *out, const uint64_t *a, const uint64_t *b, size_t batch, int op) {
     if (int rc = check(c, out, a, b)) return rc;
+    if (int rc = check_count(c, batch)) return rc;
     std::lock_guard<std::mutex> lk(c->mu);
     DeviceGuard g(c->device);
     return host_pipeline(c, out, a, b, batch, [&](uint64_t *s0, uint64_t *s1, size_t n, hipStream_t st) {
@@ -1348,6 +1381,7 @@ int sr_ring_mul_batch(sr_ctx *c, uint64_t *out, const uint64_t *a, const uint64_
 }
 int sr_reduce_batch(sr_ctx *c, const uint64_t *in, size_t in_len, uint64_t *out, size_t batch) {
     if (int rc = check(c, in, out)) return rc;
+    if (int rc = check_count(c, batch)) return rc;
     if (in_len > 2 * c->degree) return fail(SR_E_INVALID, "reduce: in_len_per_elem > 2D");
     std::lock_guard<std::mutex> lk(c->mu);
     DeviceGuard g(c->device);

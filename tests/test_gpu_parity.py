@@ -1017,3 +1017,20 @@ def test_monomial_helpers_match_model(torch_cuda, name, k):
     assert got == [abs(v if v < d + 1 else v - p) < d // 2 for v in vals]
     if d <= 64:
         assert got == [P.psi_range_check(base, log2d, v) for v in vals]
+
+
+def test_absurd_element_counts_are_refused(torch_cuda):
+    """Counts whose byte size would wrap size_t are rejected before any size arithmetic (SR_E_INVALID), not launched."""
+    from stark_rings_amd import _lib
+
+    ring = ring_for("goldilocks", 10)
+    lib = _lib.load()
+    buf = np.zeros(1024, dtype=np.uint64)
+    ptr = buf.ctypes.data_as(_lib.u64p)
+    huge = (1 << 63) // 1024
+    assert lib.sr_ntt_fwd_batch(ring._ctx, ptr, huge) != 0
+    assert lib.sr_ring_mul_batch(ring._ctx, ptr, ptr, ptr, huge) != 0
+    assert lib.sr_decompose_balanced_batch(ring._ctx, ptr, ptr, 4, 1 << 40, 1 << 30) != 0
+    assert lib.sr_matvec_ntt(ring._ctx, ptr, ptr, ptr, 1 << 40, 1 << 30) != 0
+    assert "too large" in _lib.last_error()
+    assert np.array_equal(ring.elementwise_icrt(ring.elementwise_crt(buf.copy())), buf)   # the context is still usable
