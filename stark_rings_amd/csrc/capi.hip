@@ -24,6 +24,7 @@
 #include "decompose.hpp"
 #include "wire.hpp"
 #include "frog_ring.hpp"
+#include "ntt_stark.hpp"
 
 namespace {
 
@@ -74,7 +75,9 @@ struct sr_ctx {
     void *tables = nullptr;  // [tw (D elems) | itw (D elems)] in table form
     size_t table_bytes = 0;
     // inverse stage-0 constants (table form): plain inverse, and fused ring-mul (with boundary correction)
-    unsigned char inv_scale0[32], inv_scale1[32], mul_scale0[32], mul_scale1[32];
+    unsigned char inv_scale0[40], inv_scale1[40], mul_scale0[40], mul_scale1[40];
+    bool stark_tuned = false;  // and k >= 9: the register-tiled kernels of ntt_stark.hpp (SR_STARK_TUNED=0: generic kernels on StarkL)
+    bool stark_lazy = false;  // Stark rings: transforms run on StarkL (nine 28-bit limbs, lazy carries; stark_lazy.hpp)
     // staging for host-pointer entry points
     void *stage[4] = {nullptr, nullptr, nullptr, nullptr};  // [2], [3]: second lane of the chunked host pipeline
     size_t stage_bytes[4] = {0, 0, 0, 0};
@@ -161,6 +164,10 @@ void exponent_pm1_shift<sr::Stark>(int shift, uint64_t out[4]) {
         out[i] = bs ? (lo >> bs) | (hi << (64 - bs)) : lo;
     }
 }
+template <>
+void exponent_pm1_shift<sr::StarkL>(int shift, uint64_t out[4]) {
+    exponent_pm1_shift<sr::Stark>(shift, out);
+}
 template <class F>
 void exponent_pm2(uint64_t out[4]);  // p - 2
 template <>
@@ -178,15 +185,20 @@ void exponent_pm2<sr::Stark>(uint64_t out[4]) {
     out[0] = out[1] = out[2] = ~0ull;
     out[3] = 0x0800000000000010ull;
 }
+template <>
+void exponent_pm2<sr::StarkL>(uint64_t out[4]) {
+    exponent_pm2<sr::Stark>(out);
+}
 template <class F>
 constexpr int kappa_bits() {  // mul_tw(x, y) = x * y * 2^-kappa_bits
-    return std::is_same<F, sr::Goldilocks>::value ? 0 : (std::is_same<F, sr::BabyBear>::value ? 32 : 256);
+    return std::is_same<F, sr::Goldilocks>::value ? 0
+           : (std::is_same<F, sr::BabyBear>::value ? 32 : (std::is_same<F, sr::StarkL>::value ? sr::StarkL::kTableBits : 256));
 }
 template <class F>
 constexpr int default_log_tile() {
     // Stark: 512 coefficients x 32 B = 16 KiB per tile (two tiles in the fused product): five workgroups per CU.  With 1024
     // coefficients (two per CU) the rows kernel took 3.23 ms at D = 2^12, batch 2^12; with 512 it takes 2.39 ms.
-    return std::is_same<F, sr::Stark>::value ? 9 : 12;
+    return (std::is_same<F, sr::Stark>::value || std::is_same<F, sr::StarkL>::value) ? 9 : 12;
 }
 
 template <class F>
@@ -211,7 +223,7 @@ int init_pow2(sr_ctx *c) {
         const int v = atoi(lt);
         if (v >= 8 && v <= 12) c->log_tile = v;
     }
-    if (k > 2 * c->log_tile) return fail(SR_E_INVALID, "log2_degree too large for the two-level kernels");
+    if (k > 2 * c->log_tile && !c->stark_tuned) return fail(SR_E_INVALID, "log2_degree too large for the two-level kernels");
     const size_t d = c->degree;
     size_t extra = 0;
     if constexpr (std::is_same<F, sr::Goldilocks>::value) extra = sr::gl_fast_extra_bytes(k);
@@ -251,8 +263,8 @@ int init_pow2(sr_ctx *c) {
     E rb_inv = inv_tw<F>(pow_small<F>(two, F::kBoundaryBits));
     E fused = F::mul_tw(dinv, F::mul_tw(kappa, rb_inv));
     E half_turn_inv = k >= 1 ? ipows[k - 1] : F::tw_one();  // psi^-(D/2) = itw[1]
-    E s0 = dinv, s1 = F::mul_tw(dinv, half_turn_inv);
-    E m0 = fused, m1 = F::mul_tw(fused, half_turn_inv);
+    E s0 = sr::Lazy<F>::table(dinv), s1 = sr::Lazy<F>::table(F::mul_tw(dinv, half_turn_inv));
+    E m0 = sr::Lazy<F>::table(fused), m1 = sr::Lazy<F>::table(F::mul_tw(fused, half_turn_inv));
     memcpy(c->inv_scale0, &s0, sizeof(E));
     memcpy(c->inv_scale1, &s1, sizeof(E));
     memcpy(c->mul_scale0, &m0, sizeof(E));
@@ -402,9 +414,11 @@ template <class F>
 int ring_mul_dev(sr_ctx *c, uint64_t *out, const uint64_t *a, uint64_t *b, size_t batch, hipStream_t st) {
     using S = typename F::storage;
     if (batch == 0) return SR_OK;
-    if (c->k == 0) {  // D = 1: the ring is Fp itself
-        if (out != a) HIP_TRY(hipMemcpyAsync(out, a, batch * sizeof(S), hipMemcpyDeviceToDevice, st));
-        return pointwise_dev<F>(c, out, b, batch, st);
+    if constexpr (!sr::Lazy<F>::value) {  // (a lazy field is never selected for D = 1)
+        if (c->k == 0) {  // D = 1: the ring is Fp itself
+            if (out != a) HIP_TRY(hipMemcpyAsync(out, a, batch * sizeof(S), hipMemcpyDeviceToDevice, st));
+            return pointwise_dev<F>(c, out, b, batch, st);
+        }
     }
     if (c->k > c->log_tile) {
         // first (strided) forward stages of both operands; a's go to out so that a stays intact
@@ -535,6 +549,50 @@ int rt_ring_mul(sr_ctx *c, uint64_t *out, const uint64_t *a, uint64_t *b, size_t
                             (E *)c->rt_scratch[1], st))
         return fail(SR_E_HIP, "register-tiled launch failed");
     return rt_scratch_release(c, st);
+}
+
+// ---- Stark rings, k >= 9: ntt_stark.hpp ----
+int st_fwd(sr_ctx *c, uint64_t *d, size_t batch, hipStream_t st) {
+    if (batch == 0) return SR_OK;
+    auto p = make_params<sr::StarkL>(c, false);
+    auto *a = reinterpret_cast<sr::U256Storage *>(d);
+    auto hook = [&](bool begin) { begin ? gl_prof_begin(c, 0, st) : gl_prof_end(c, st); };
+    if (sr::st::fwd_cols(a, batch, p, st, hook)) return fail(SR_E_HIP, "stark strided launch failed");
+    ProfScope ps(c, st, K_ROWS);
+    if (sr::st::launch_rows<sr::MODE_FWD>(a, nullptr, a, batch, p, st)) return fail(SR_E_HIP, "stark rows launch failed");
+    return SR_OK;
+}
+int st_inv(sr_ctx *c, uint64_t *d, size_t batch, hipStream_t st) {
+    if (batch == 0) return SR_OK;
+    auto p = make_params<sr::StarkL>(c, false);
+    auto *a = reinterpret_cast<sr::U256Storage *>(d);
+    {
+        ProfScope ps(c, st, K_ROWS);
+        if (sr::st::launch_rows<sr::MODE_INV>(a, nullptr, a, batch, p, st)) return fail(SR_E_HIP, "stark rows launch failed");
+    }
+    auto hook = [&](bool begin) { begin ? gl_prof_begin(c, 2, st) : gl_prof_end(c, st); };
+    if (sr::st::inv_cols(a, batch, p, st, hook)) return fail(SR_E_HIP, "stark strided launch failed");
+    return SR_OK;
+}
+int st_ring_mul(sr_ctx *c, uint64_t *out, const uint64_t *a, uint64_t *b, size_t batch, hipStream_t st) {
+    if (batch == 0) return SR_OK;
+    using S = sr::U256Storage;
+    auto p = make_params<sr::StarkL>(c, true);
+    S *o = reinterpret_cast<S *>(out), *pb = reinterpret_cast<S *>(b);
+    if (c->k > sr::st::kTileLog) {  // strided stages of both operands first; a's go to out so that a stays intact
+        if (out != a) HIP_TRY(hipMemcpyAsync(out, a, (batch << c->k) * sizeof(S), hipMemcpyDeviceToDevice, st));
+        auto hook = [&](bool begin) { begin ? gl_prof_begin(c, 0, st) : gl_prof_end(c, st); };
+        if (sr::st::fwd_cols(o, batch, p, st, hook)) return fail(SR_E_HIP, "stark strided launch failed");
+        if (sr::st::fwd_cols(pb, batch, p, st, hook)) return fail(SR_E_HIP, "stark strided launch failed");
+    }
+    {
+        ProfScope ps(c, st, K_ROWS);
+        const S *src = c->k > sr::st::kTileLog ? o : reinterpret_cast<const S *>(a);
+        if (sr::st::launch_rows<sr::MODE_MUL>(const_cast<S *>(src), pb, o, batch, p, st)) return fail(SR_E_HIP, "stark rows launch failed");
+    }
+    auto hook = [&](bool begin) { begin ? gl_prof_begin(c, 2, st) : gl_prof_end(c, st); };
+    if (sr::st::inv_cols(o, batch, p, st, hook)) return fail(SR_E_HIP, "stark strided launch failed");
+    return SR_OK;
 }
 
 bool is_pow2_ring(int ring) { return ring >= SR_RING_GOLDILOCKS_POW2 && ring <= SR_RING_STARK_POW2; }
@@ -688,6 +746,8 @@ int dev_fwd(sr_ctx *c, uint64_t *d, size_t batch, hipStream_t st) {
     if (c->ring == SR_RING_GOLDILOCKS_POW2 && c->fast_goldilocks && sr::gl_fast_supported(c->gl_fast)) {
         return sr::gl_fast_fwd(c->gl_fast, d, batch, st) ? fail(SR_E_HIP, "goldilocks fast-path launch failed") : SR_OK;
     }
+    if (c->stark_tuned) return st_fwd(c, d, batch, st);
+    if (c->stark_lazy) return fwd_dev<sr::StarkL>(c, d, batch, st);
     DISPATCH_POW2(c, (fwd_dev<F>(c, d, batch, st)));
 }
 int dev_inv(sr_ctx *c, uint64_t *d, size_t batch, hipStream_t st) {
@@ -701,6 +761,8 @@ int dev_inv(sr_ctx *c, uint64_t *d, size_t batch, hipStream_t st) {
     if (c->ring == SR_RING_GOLDILOCKS_POW2 && c->fast_goldilocks && sr::gl_fast_supported(c->gl_fast)) {
         return sr::gl_fast_inv(c->gl_fast, d, batch, st) ? fail(SR_E_HIP, "goldilocks fast-path launch failed") : SR_OK;
     }
+    if (c->stark_tuned) return st_inv(c, d, batch, st);
+    if (c->stark_lazy) return inv_dev<sr::StarkL>(c, d, batch, st);
     DISPATCH_POW2(c, (inv_dev<F>(c, d, batch, st)));
 }
 int dev_pointwise(sr_ctx *c, uint64_t *l, const uint64_t *r, size_t batch, hipStream_t st) {
@@ -741,6 +803,8 @@ int dev_ring_mul(sr_ctx *c, uint64_t *out, const uint64_t *a, uint64_t *b, size_
     if (c->ring == SR_RING_GOLDILOCKS_POW2 && c->fast_goldilocks && sr::gl_fast_supported(c->gl_fast)) {
         return sr::gl_fast_ring_mul(c->gl_fast, out, a, b, batch, st) ? fail(SR_E_HIP, "goldilocks fast-path launch failed") : SR_OK;
     }
+    if (c->stark_tuned) return st_ring_mul(c, out, a, b, batch, st);
+    if (c->stark_lazy) return ring_mul_dev<sr::StarkL>(c, out, a, b, batch, st);
     DISPATCH_POW2(c, (ring_mul_dev<F>(c, out, a, b, batch, st)));
 }
 int dev_reduce(sr_ctx *c, const uint64_t *in, size_t in_len, uint64_t *out, size_t batch, hipStream_t st) {
@@ -797,7 +861,15 @@ int sr_ctx_create(int ring, int log2_degree, int device, sr_ctx **out) {
         switch (ring) {
             case SR_RING_GOLDILOCKS_POW2: rc = init_pow2<sr::Goldilocks>(c); break;
             case SR_RING_BABYBEAR_POW2: rc = init_pow2<sr::BabyBear>(c); break;
-            default: rc = init_pow2<sr::Stark>(c); break;
+            default: {
+                // SR_STARK_LAZY=0 keeps the transforms on the 8 x 32-bit-limb arithmetic (differential tests); D = 1 has none
+                const char *env = getenv("SR_STARK_LAZY");
+                c->stark_lazy = !(env && env[0] == '0') && log2_degree >= 1;
+                const char *tuned = getenv("SR_STARK_TUNED");
+                c->stark_tuned = c->stark_lazy && !(tuned && tuned[0] == '0') && sr::st::supported(log2_degree);
+                rc = c->stark_lazy ? init_pow2<sr::StarkL>(c) : init_pow2<sr::Stark>(c);
+                break;
+            }
         }
         if (rc) return bail(rc);
         if (ring == SR_RING_GOLDILOCKS_POW2) {
@@ -1416,11 +1488,51 @@ static int selftest_op(int op, const uint64_t *a, const uint64_t *b, uint64_t *o
     F::store(reinterpret_cast<S *>(out), r);
     return SR_OK;
 }
+// StarkL (stark_lazy.hpp): 0 add, 1 sub, 3 mul_tw, 4 table form, 5 a chain of six lazy additions and subtractions feeding
+// mul_tw and mul_data, 6 repeated quadrupling with weak reductions, 7 / 8 signed combinations -- results leave through the
+// canonicalising store
+static int selftest_lazy(int op, const uint64_t *a, const uint64_t *b, uint64_t *out) {
+    using F = sr::StarkL;
+    using S = F::storage;
+    F::elem x = F::load(reinterpret_cast<const S *>(a)), y = F::load(reinterpret_cast<const S *>(b)), r;
+    switch (op) {
+        case 0: r = F::add(x, y); break;
+        case 1: r = F::sub(x, y); break;
+        case 3: r = F::mul_tw(x, y); break;
+        case 4: r = F::tw_from_u64(a[0]); break;
+        case 5: {
+            F::elem s = x, d = x;
+            for (int i = 0; i < 6; i++) {
+                s = F::add(s, y);
+                d = F::sub(d, y);
+            }
+            r = F::add(F::mul_tw(s, y), F::mul_data(d, s));
+            break;
+        }
+        case 6: {
+            r = x;
+            for (int i = 0; i < 4; i++) r = F::weak_reduce(F::add(F::add(r, r), F::add(r, r)));  // 256 a, reduced weakly on the way
+            break;
+        }
+        case 7: {  // 3 a - 5 b and, case 8, 7 a - 2 b without any carry in between: canonical() on signed lazy states
+            r = F::sub(F::add(F::add(x, x), x), F::add(F::add(F::add(y, y), F::add(y, y)), y));
+            break;
+        }
+        case 8: {
+            F::elem x2 = F::add(x, x), x4 = F::add(x2, x2);
+            r = F::sub(F::add(F::add(x4, x2), x), F::add(y, y));
+            break;
+        }
+        default: return fail(SR_E_INVALID, "selftest: unknown op");
+    }
+    F::store(reinterpret_cast<S *>(out), r);
+    return SR_OK;
+}
 }  // extern "C++"
 int sr_selftest_field_op(int field, int op, const uint64_t *a, const uint64_t *b, uint64_t *out) {
     if (!a || !b || !out) return fail(SR_E_INVALID, "null argument");
     alignas(16) uint64_t ta[4] = {0, 0, 0, 0}, tb[4] = {0, 0, 0, 0}, to[4] = {0, 0, 0, 0};
-    int words = field == 2 ? 4 : 1;
+    int words = (field == 2 || field == 4) ? 4 : 1;
     memcpy(ta, a, words * 8);
     memcpy(tb, b, words * 8);
     int rc;
@@ -1429,6 +1541,7 @@ int sr_selftest_field_op(int field, int op, const uint64_t *a, const uint64_t *b
         case 1: rc = selftest_op<sr::BabyBear>(op, ta, tb, to); break;
         case 2: rc = selftest_op<sr::Stark>(op, ta, tb, to); break;
         case 3: rc = selftest_op<sr::Frog>(op, ta, tb, to); break;
+        case 4: rc = selftest_lazy(op, ta, tb, to); break;
         default: return fail(SR_E_INVALID, "selftest: unknown field");
     }
     memcpy(out, to, words * 8);

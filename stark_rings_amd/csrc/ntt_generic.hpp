@@ -18,6 +18,7 @@
 // barrier per stage); ntt_goldilocks.hpp holds the tuned Goldilocks path.
 #pragma once
 #include "fields.hpp"
+#include "stark_lazy.hpp"
 
 namespace sr {
 
@@ -37,7 +38,7 @@ struct NttParams {
 
 template <class F>
 __device__ __forceinline__ void fwd_stage_lds(uint32_t *lds, int n_tile, int n_loc, size_t off, int k, int s,
-                                              const typename F::elem *tw) {
+                                              const typename F::elem *tw, bool relax = false) {
     const int lh = k - s - 1;
     const int half = 1 << lh;
     for (int j = threadIdx.x; j < (n_tile >> 1); j += kThreads) {
@@ -50,8 +51,13 @@ __device__ __forceinline__ void fwd_stage_lds(uint32_t *lds, int n_tile, int n_l
             typename F::elem w = tw[(1u << s) + b];
             typename F::elem u = F::lds_get(lds, lo, n_tile);
             typename F::elem v = F::mul_tw(F::lds_get(lds, hi, n_tile), w);
-            F::lds_put(lds, lo, n_tile, F::add(u, v));
-            F::lds_put(lds, hi, n_tile, F::sub(u, v));
+            if (Lazy<F>::value && relax) {  // lazy fields: every sixth stage pulls limbs and value back in (stark_lazy.hpp)
+                F::lds_put(lds, lo, n_tile, Lazy<F>::weak(F::add(u, v)));
+                F::lds_put(lds, hi, n_tile, Lazy<F>::weak(F::sub(u, v)));
+            } else {
+                F::lds_put(lds, lo, n_tile, F::add(u, v));
+                F::lds_put(lds, hi, n_tile, F::sub(u, v));
+            }
         }
     }
 }
@@ -75,7 +81,7 @@ __device__ __forceinline__ void inv_stage_lds(uint32_t *lds, int n_tile, int n_l
             } else {
                 size_t g = off + lo;
                 uint32_t b = (uint32_t)(g >> (lh + 1)) & ((1u << s) - 1u);
-                F::lds_put(lds, lo, n_tile, sum);
+                F::lds_put(lds, lo, n_tile, Lazy<F>::weak(sum));  // the sum leg doubles every stage: lazy fields reduce it weakly
                 F::lds_put(lds, hi, n_tile, F::mul_tw(dif, p.itw[(1u << s) + b]));
             }
         }
@@ -102,14 +108,15 @@ __global__ __launch_bounds__(kThreads) void rows_kernel(typename F::storage *a, 
 
     if (MODE == MODE_FWD || MODE == MODE_MUL) {
         for (int s = p.s_rows; s < p.k; s++) {
-            fwd_stage_lds<F>(la, n_tile, n_loc, off, p.k, s, p.tw);
-            if (MODE == MODE_MUL) fwd_stage_lds<F>(lb, n_tile, n_loc, off, p.k, s, p.tw);
+            const bool relax = (s - p.s_rows) % 6 == 5;
+            fwd_stage_lds<F>(la, n_tile, n_loc, off, p.k, s, p.tw, relax);
+            if (MODE == MODE_MUL) fwd_stage_lds<F>(lb, n_tile, n_loc, off, p.k, s, p.tw, relax);
             __syncthreads();
         }
     }
     if (MODE == MODE_MUL) {
         for (int i = threadIdx.x; i < n_loc; i += kThreads)
-            F::lds_put(la, i, n_tile, F::mul_tw(F::lds_get(la, i, n_tile), F::lds_get(lb, i, n_tile)));
+            F::lds_put(la, i, n_tile, Lazy<F>::mul_data(F::lds_get(la, i, n_tile), F::lds_get(lb, i, n_tile)));
         __syncthreads();
     }
     if (MODE == MODE_INV || MODE == MODE_MUL) {
@@ -154,8 +161,13 @@ __global__ __launch_bounds__(kThreads) void cols_kernel(typename F::storage *a, 
                 typename F::elem tw = p.tw[(1u << s) + grp];
                 typename F::elem u = F::lds_get(smem, lo, n_tile);
                 typename F::elem v = F::mul_tw(F::lds_get(smem, hi, n_tile), tw);
-                F::lds_put(smem, lo, n_tile, F::add(u, v));
-                F::lds_put(smem, hi, n_tile, F::sub(u, v));
+                if (Lazy<F>::value && s % 6 == 5) {
+                    F::lds_put(smem, lo, n_tile, Lazy<F>::weak(F::add(u, v)));
+                    F::lds_put(smem, hi, n_tile, Lazy<F>::weak(F::sub(u, v)));
+                } else {
+                    F::lds_put(smem, lo, n_tile, F::add(u, v));
+                    F::lds_put(smem, hi, n_tile, F::sub(u, v));
+                }
             }
             __syncthreads();
         }
@@ -174,7 +186,7 @@ __global__ __launch_bounds__(kThreads) void cols_kernel(typename F::storage *a, 
                     F::lds_put(smem, lo, n_tile, F::mul_tw(sum, p.scale0));
                     F::lds_put(smem, hi, n_tile, F::mul_tw(dif, p.scale1));
                 } else {
-                    F::lds_put(smem, lo, n_tile, sum);
+                    F::lds_put(smem, lo, n_tile, Lazy<F>::weak(sum));
                     F::lds_put(smem, hi, n_tile, F::mul_tw(dif, p.itw[(1u << s) + grp]));
                 }
             }
@@ -335,8 +347,8 @@ __global__ void build_tables_kernel(typename F::elem *tw, typename F::elem *itw,
                 acc = F::mul_tw(acc, pows[j]);
                 iacc = F::mul_tw(iacc, ipows[j]);
             }
-        tw[i] = acc;
-        itw[i] = iacc;
+        tw[i] = Lazy<F>::table(acc);
+        itw[i] = Lazy<F>::table(iacc);
     }
 }
 

@@ -370,8 +370,45 @@ def test_babybear_older_plan_equals_cols256_plan(torch_cuda, k, batch):
         del os.environ["SR_RT_COLS256"]
 
 
+@pytest.mark.parametrize("k,batch", [(4, 37), (8, 5), (9, 7), (10, 3), (11, 3), (12, 5), (13, 2), (14, 2), (15, 1), (16, 1)])
+def test_stark_three_kernel_families_agree(torch_cuda, k, batch):
+    """Stark rings run on three kernel families that must produce the same bytes: the register-tiled kernels on 28-bit lazy limbs
+    (ntt_stark.hpp, k >= 9: the strided passes take 1, 2 or 3 stages at a time -- k = 10..16 walks every combination), the generic
+    LDS kernels on the same arithmetic (SR_STARK_TUNED=0, every k >= 1) and the generic kernels on 8 x 32-bit limbs
+    (SR_STARK_LAZY=0, what every size ran before).  Inputs include all-zero, all-(p-1), 1 and X^(D-1); the oracle pins the values."""
+    import os
+
+    from stark_rings_amd import CyclotomicRing
+
+    F = O.STARK
+    a = edge_and_random(F, k, batch, 0x2A0 + k)
+    b = np.ascontiguousarray(edge_and_random(F, k, batch, 0x2B0 + k).reshape(batch, -1)[::-1]).reshape(-1)   # edge elements last
+    ring = ring_for("stark", k)
+    fa = ring.elementwise_crt(a.copy())
+    prod = ring.mul(a, b)
+    assert np.array_equal(ring.elementwise_icrt(fa.copy()), a)
+    if k <= 12:
+        assert np.array_equal(fa, O.pow2_fwd(F, a, k, batch, 4))
+        assert np.array_equal(prod, O.pow2_ring_mul(F, a, b, k, batch, 4))
+    else:
+        e = batch - 1
+        d4 = 4 << k
+        assert np.array_equal(fa[e * d4:(e + 1) * d4], O.pow2_fwd(F, a[e * d4:(e + 1) * d4], k, 1))
+        assert np.array_equal(prod[e * d4:(e + 1) * d4], O.pow2_ring_mul(F, a[e * d4:(e + 1) * d4], b[e * d4:(e + 1) * d4], k, 1))
+    for var in ("SR_STARK_TUNED", "SR_STARK_LAZY"):
+        os.environ[var] = "0"
+        try:
+            other = CyclotomicRing("stark", k, device=0)
+            assert np.array_equal(other.elementwise_crt(a.copy()), fa), var
+            assert np.array_equal(other.elementwise_icrt(fa.copy()), a), var
+            assert np.array_equal(other.mul(a, b), prod), var
+            other.close()
+        finally:
+            del os.environ[var]
+
+
 # ----------------------------------------------------------------------------- maximum sizes and BASELINE full sizes
-@pytest.mark.parametrize("name,k", [("goldilocks", 22), ("goldilocks", 24), ("babybear", 24), ("stark", 18)])
+@pytest.mark.parametrize("name,k", [("goldilocks", 22), ("goldilocks", 24), ("babybear", 24), ("stark", 18), ("stark", 20)])
 def test_maximum_degrees_single_element(torch_cuda, name, k):
     """Largest degrees each kernel family accepts (tuned Goldilocks <= 2^22, generic / register-tiled <= 2^24, Stark <= 2^20)."""
     F = O.FIELD_ID[name]

@@ -78,3 +78,39 @@ def test_no_device_means_loud_failure():
 
     with pytest.raises(RingError, match="no HIP device|no CPU fallback"):
         CyclotomicRing("goldilocks", 10)
+
+
+def test_stark_lazy_limb_arithmetic_matches_python_model():
+    """stark_lazy.hpp (nine signed 28-bit limbs, lazy carries, R = 2^280) through the selftest hook, field id 4: sums,
+    differences, the Montgomery product, the table form, a chain of six uncarried additions / subtractions feeding both
+    product forms, and repeated doubling with weak reduction -- every result leaves through the canonicalising store."""
+    p = P.STARK_P
+    rng = random.Random(41)
+    r_inv = pow(pow(2, 280, p), -1, p)
+    edge = [0, 1, 2, p - 1, p - 2, (p - 1) // 2, 2**28 - 1, 2**28, 2**224, 2**251, 2**251 - 1, 17 * 2**192, (1 << 250) + 12345,
+            sum(((1 << 28) - 1) << (28 * i) for i in range(9)) % p]
+    vals = edge + [rng.randrange(p) for _ in range(400)]
+    for i in range(len(vals)):
+        a, b = vals[i], vals[(i * 5 + 2) % len(vals)]
+        assert _op(4, 0, a, b, 4) == (a + b) % p
+        assert _op(4, 1, a, b, 4) == (a - b) % p
+        assert _op(4, 3, a, b, 4) == a * b * r_inv % p
+        s, d = (a + 6 * b), (a - 6 * b)
+        assert _op(4, 5, a, b, 4) == (s * b * r_inv + d * s * r_inv) % p
+        assert _op(4, 6, a, b, 4) == 256 * a % p
+    for x in (0, 1, 7, 2**40, 2**64 - 1):
+        assert _op(4, 4, x, 0, 4) == x * pow(2, 280, p) % p
+    # the slow path of canonical(): a borrow out of limb 0 after the fold (value still >= 0), and values that fold to < 0
+    h = 2**250 + 17 * 2**192
+    for a, b in ((h, h), (2**251, 0), (2**251 + 2**28, 0), (0, 1), (1, 2**251), (2**251 + 2**56, 2**251 + 2**84), (p - 1, p - 1)):
+        assert _op(4, 0, a, b, 4) == (a + b) % p
+        assert _op(4, 1, a, b, 4) == (a - b) % p
+        assert _op(4, 1, b, a, 4) == (b - a) % p
+    # canonical() on signed lazy states around every boundary it distinguishes (multiples of 2^251, of p, limb borders)
+    bnd = sorted({v % p for base in (0, 2**251, p, 2**28, 2**196, 17 * 2**192, 2**224, (p - 1) // 2, (p + 1) // 3, (2 * p) // 5,
+                                     (p + 2**251) // 7, 2**251 // 3, 2**251 // 5)
+                  for v in (base - 2, base - 1, base, base + 1, base + 2, base + 2**28, base - 2**28)})
+    for a in bnd:
+        for b in bnd:
+            assert _op(4, 7, a, b, 4) == (3 * a - 5 * b) % p
+            assert _op(4, 8, a, b, 4) == (7 * a - 2 * b) % p
