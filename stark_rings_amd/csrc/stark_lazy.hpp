@@ -165,11 +165,26 @@ struct StarkL {
         return same;
     }
 
-    // a * w * 2^-280 mod p (see the header comment for the operand ranges)
+    // a * w * 2^-280 mod p (see the header comment for the operand ranges).  One 64-bit accumulator runs through all eighteen
+    // columns; on the device the multiply-adds are single-instruction asm statements, because left to itself the compiler
+    // starts every column in a fresh accumulator and joins it to the running one with an extra 64-bit add (18 per product).
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(SR_ST_NO_ASM_MAD)
+    static __device__ __forceinline__ void mac_s(int64_t &acc, int32_t x, int32_t y) {
+        uint64_t cy;
+        asm("v_mad_i64_i32 %0, %1, %2, %3, %0" : "+v"(acc), "=s"(cy) : "v"(x), "v"(y));
+    }
+    static __device__ __forceinline__ void mac_u(int64_t &acc, uint32_t x, uint32_t y) {
+        uint64_t cy;
+        asm("v_mad_u64_u32 %0, %1, %2, %3, %0" : "+v"(acc), "=s"(cy) : "v"(x), "s"(y));
+    }
+#else
+    SR_HD static void mac_s(int64_t &acc, int32_t x, int32_t y) { acc += (int64_t)x * (int64_t)y; }
+    SR_HD static void mac_u(int64_t &acc, uint32_t x, uint32_t y) { acc = (int64_t)((uint64_t)acc + (uint64_t)x * y); }
+#endif
     SR_HD static elem mul_tw(const elem &a, const elem &w) {
         uint32_t c24 = 1u << 24, c27 = 1u << 27, c1 = 1u;
 #if defined(__HIP_DEVICE_COMPILE__)
-        asm("" : "+s"(c24));  // opaque: keeps m * 2^24 etc. one v_mad_u64_u32 instead of a 64-bit shift and a two-word add
+        asm("" : "+s"(c24));  // opaque scalars: m * 2^24 etc. stay one v_mad_u64_u32 instead of a 64-bit shift and a two-word add
         asm("" : "+s"(c27));
         asm("" : "+s"(c1));
 #endif
@@ -181,20 +196,20 @@ struct StarkL {
 #pragma unroll
             for (int i = 0; i < 9; i++) {
                 const int j = k - i;
-                if (j >= 0 && j < 9) acc += (int64_t)a.l[i] * (int64_t)w.l[j];
+                if (j >= 0 && j < 9) mac_s(acc, a.l[i], w.l[j]);
             }
 #pragma unroll
             for (int i = 0; i < 10; i++) {
                 const int j = k - i;
                 if (i < k || k >= 10) {
-                    if (j == 6) acc = (int64_t)((uint64_t)acc + (uint64_t)m[i] * c24);
-                    if (j == 7) acc = (int64_t)((uint64_t)acc + (uint64_t)m[i] * c1);
-                    if (j == 8) acc = (int64_t)((uint64_t)acc + (uint64_t)m[i] * c27);
+                    if (j == 6) mac_u(acc, m[i], c24);
+                    if (j == 7) mac_u(acc, m[i], c1);
+                    if (j == 8) mac_u(acc, m[i], c27);
                 }
             }
             if (k < 10) {
                 m[k] = (0u - (uint32_t)acc) & M28;
-                acc = (int64_t)((uint64_t)acc + (uint64_t)m[k] * c1);  // + m_k p_0: the low 28 bits are now zero
+                mac_u(acc, m[k], c1);  // + m_k p_0: the low 28 bits are now zero
                 acc >>= 28;
             } else {
                 r.l[k - 10] = (int32_t)((uint32_t)acc & M28);
