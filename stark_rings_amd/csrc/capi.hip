@@ -579,7 +579,8 @@ int st_ring_mul(sr_ctx *c, uint64_t *out, const uint64_t *a, uint64_t *b, size_t
     using S = sr::U256Storage;
     auto p = make_params<sr::StarkL>(c, true);
     S *o = reinterpret_cast<S *>(out), *pb = reinterpret_cast<S *>(b);
-    if (c->k > sr::st::kTileLog) {  // strided stages of both operands first; a's go to out so that a stays intact
+    const bool strided = !sr::st::whole(c->k);
+    if (strided) {  // strided stages of both operands first; a's go to out so that a stays intact
         if (out != a) HIP_TRY(hipMemcpyAsync(out, a, (batch << c->k) * sizeof(S), hipMemcpyDeviceToDevice, st));
         auto hook = [&](bool begin) { begin ? gl_prof_begin(c, 0, st) : gl_prof_end(c, st); };
         if (sr::st::fwd_cols(o, batch, p, st, hook)) return fail(SR_E_HIP, "stark strided launch failed");
@@ -587,7 +588,7 @@ int st_ring_mul(sr_ctx *c, uint64_t *out, const uint64_t *a, uint64_t *b, size_t
     }
     {
         ProfScope ps(c, st, K_ROWS);
-        const S *src = c->k > sr::st::kTileLog ? o : reinterpret_cast<const S *>(a);
+        const S *src = strided ? o : reinterpret_cast<const S *>(a);
         if (sr::st::launch_rows<sr::MODE_MUL>(const_cast<S *>(src), pb, o, batch, p, st)) return fail(SR_E_HIP, "stark rows launch failed");
     }
     auto hook = [&](bool begin) { begin ? gl_prof_begin(c, 2, st) : gl_prof_end(c, st); };

@@ -5,18 +5,22 @@
 //
 // What is different is where the data lives between stages: a lane keeps several coefficients in registers and runs two or
 // three stages on them before anything is exchanged (the table indices of consecutive stages are 2 t0 + {0, 1}, 4 t0 + {0..3}):
-//   rows512_kernel  the last nine stages: a 128-lane workgroup owns a tile of 512 consecutive coefficients, FOUR per lane (36
-//                   VGPRs) -- five register passes (2, 2, 2, 2, 1 stages) with four LDS transposes in between.  MODE_MUL keeps
-//                   fwd(a) in registers while b goes through the same LDS tile, multiplies the slots in registers and runs the
-//                   inverse passes in the mirrored order; global loads and stores use the lane-contiguous layout (coefficient
-//                   t + 128 j); the first pass' twiddles are wave-uniform.  Four per lane, not eight: with eight the kernel
-//                   needed 256+ VGPRs, one wave per SIMD, and lost more to latency than the saved transposes gained.
+//   tile_kernel     the last LOGT stages: a workgroup of 2^(LOGT-2) lanes owns a tile of 2^LOGT consecutive coefficients, FOUR per
+//                   lane (36 VGPRs) -- register passes of two stages with LDS transposes in between.  MODE_MUL keeps fwd(a) in
+//                   registers while b goes through the same LDS tile, multiplies the slots in registers and runs the inverse
+//                   passes in the mirrored order; global loads and stores use the lane-contiguous layout; the first pass'
+//                   twiddles are wave-uniform.  For 512 <= D <= 4096 the tile is the ring element (LOGT = k): the whole ring
+//                   product is one launch and one trip over HBM.  Above, LOGT = 9 after the strided passes.  Four per lane, not
+//                   eight: with eight the kernel needed 256+ VGPRs, one wave per SIMD, and lost more to latency than the saved
+//                   transposes gained.
 //   cols_kernel<M>  the first k - 9 stages, M <= 3 at a time (2^M coefficients per lane), straight from and to global memory
 //                   (legs 2^(k - s0 - M) >= 512 coefficients apart: every leg is a lane-contiguous 32-byte stream), no LDS.
 // Lazy-carry bookkeeping (stark_lazy.hpp): a forward stage adds at most 2^28 per limb, so one weak reduction after the sixth
 // rows stage keeps every limb below 2^31; an inverse group reduces its sum legs weakly at its end (a three-stage group also
 // relaxes its twice-summed legs before the third stage).  Loads take canonical memory images, stores canonicalise.
 #pragma once
+#include <cstdlib>
+
 #include "ntt_generic.hpp"
 #include "stark_lazy.hpp"
 
@@ -148,116 +152,151 @@ __global__ __launch_bounds__(256, 2) void cols_kernel(S *data, size_t batch, int
     for (int j = 0; j < (1 << M); j++) F::store(base + ((size_t)j << ls), x[j]);
 }
 
-// ---- the last nine stages: a 128-lane workgroup (two waves) per 512-coefficient tile, four coefficients per lane ------------
-// register layouts of lane t, leg j (two stages per pass pair legs 2 and 1 apart; the fifth pass is a single stage):
-//   L1: e = t + 128 j                      halves 256, 128   block = tile                (wave-uniform twiddles)
-//   L2: e = 128 (t >> 5) + 32 j + (t & 31) halves  64,  32   block = t >> 5
-//   L3: e =  32 (t >> 3) +  8 j + (t & 7)  halves  16,   8   block = t >> 3
-//   L4: e =   8 (t >> 1) +  2 j + (t & 1)  halves   4,   2   block = t >> 1
-//   L5: e = 4 t + j                        half     1        blocks 2 t, 2 t + 1
-// LDS: limb-major rows of pad(511) + 1 words, pad(e) = e + 5 (e >> 5): conflict-free for L1, L2, L5, two-way for L3, L4
-// (tools search in DESIGN.md 5.3).
-constexpr int kLanes = 128;
-__device__ __forceinline__ int pad(int e) { return e + 5 * (e >> 5); }
-constexpr int kLdsRow = 511 + 5 * 15 + 1;
-constexpr int kLdsWords = 9 * kLdsRow;
-template <int L>
-__device__ __forceinline__ int pos(int t, int j) {
-    if constexpr (L == 1) return t + 128 * j;
-    else if constexpr (L == 2) return ((t >> 5) << 7) + 32 * j + (t & 31);
-    else if constexpr (L == 3) return ((t >> 3) << 5) + 8 * j + (t & 7);
-    else if constexpr (L == 4) return ((t >> 1) << 3) + 2 * j + (t & 1);
-    else return 4 * t + j;
-}
-template <int FROM, int TO>
-__device__ __forceinline__ void exchange(E *x, uint32_t *lds, int t) {
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-        const int a = pad(pos<FROM>(t, j));
-#pragma unroll
-        for (int i = 0; i < 9; i++) lds[i * kLdsRow + a] = (uint32_t)x[j].l[i];
+// ---- the last LOGT stages: a workgroup of 2^(LOGT-2) lanes per tile of 2^LOGT consecutive coefficients, four per lane ---------
+// LOGT = 9 for D > 4096 (after the strided passes); LOGT = k for 512 <= D <= 4096: the whole transform -- and in MODE_MUL the
+// whole ring product -- is ONE launch and one trip over HBM (D = 4096: 1024 lanes, 157 KB of the CU's 160 KB LDS).
+// Pass q = 0 .. LOGT/2 - 1 runs stages 2q, 2q + 1 of the tile on the register layout
+//     e = ((t >> ls) << (ls + 2)) + (j << ls) + (t & (2^ls - 1)),   ls = LOGT - 2q - 2      (legs 2^ls apart, block t >> ls)
+// and an odd LOGT ends with the single stage of half 1 on e = 4 t + j (blocks 2 t, 2 t + 1).  Pass 0's twiddles are uniform.
+// LDS: limb-major rows, pad(e) = e + PM (e >> 5): conflict-free or two-way for every layout (PM = 5 at LOGT = 9, else 3).
+template <int LOGT>
+struct Tile {
+    static constexpr int kLanes = 1 << (LOGT - 2);
+    static constexpr int kPM = LOGT == 9 ? 5 : 3;
+    static constexpr int kRow = ((1 << LOGT) - 1) + kPM * (((1 << LOGT) - 1) >> 5) + 1;
+    static constexpr int kWords = 9 * kRow;
+    static constexpr int kPasses = LOGT / 2;     // two-stage passes
+    static constexpr bool kOdd = LOGT & 1;
+    static constexpr int kLayouts = kPasses + (kOdd ? 1 : 0);
+    __device__ static __forceinline__ int pad(int e) { return e + kPM * (e >> 5); }
+    template <int Q>
+    __device__ static __forceinline__ int pos(int t, int j) {
+        if constexpr (Q >= kPasses) {
+            return 4 * t + j;
+        } else {
+            constexpr int ls = LOGT - 2 * Q - 2;
+            return ((t >> ls) << (ls + 2)) + (j << ls) + (t & ((1 << ls) - 1));
+        }
     }
-    __syncthreads();
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-        const int a = pad(pos<TO>(t, j));
-#pragma unroll
-        for (int i = 0; i < 9; i++) x[j].l[i] = (int32_t)lds[i * kLdsRow + a];
+    template <int Q>
+    __device__ static __forceinline__ uint32_t block(int t) {
+        constexpr int ls = LOGT - 2 * Q - 2;
+        return (uint32_t)(t >> ls);
     }
-    __syncthreads();
-}
+    template <int FROM, int TO>
+    __device__ static __forceinline__ void exchange(E *x, uint32_t *lds, int t) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int a = pad(pos<FROM>(t, j));
+#pragma unroll
+            for (int i = 0; i < 9; i++) lds[i * kRow + a] = (uint32_t)x[j].l[i];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int a = pad(pos<TO>(t, j));
+#pragma unroll
+            for (int i = 0; i < 9; i++) x[j].l[i] = (int32_t)lds[i * kRow + a];
+        }
+        __syncthreads();
+    }
+    // forward passes Q .. : registers in layout Q -> registers in the last layout.  tix = table index of the tile's block at its
+    // first stage (2^(k - LOGT) + tile index inside the ring element).  Every third pass ends with a weak reduction (six
+    // stages of uncarried sums reach 7 * 2^28 per limb).
+    template <int Q>
+    __device__ static __forceinline__ void fwd_from(E *x, uint32_t *lds, int t, const P &p, uint32_t tix) {
+        if constexpr (Q < kPasses) {
+            fwd_group<2>(x, p.tw, (tix << (2 * Q)) + block<Q>(t));
+            if constexpr (Q % 3 == 2 && Q + 1 < kLayouts) {
+#pragma unroll
+                for (int j = 0; j < 4; j++) x[j] = F::weak_reduce(x[j]);
+            }
+            if constexpr (Q + 1 < kLayouts) {
+                exchange<Q, Q + 1>(x, lds, t);
+                fwd_from<Q + 1>(x, lds, t, p, tix);
+            }
+        } else {  // the single last stage of an odd LOGT
+            ct(x[0], x[1], p.tw[(tix << (LOGT - 1)) + 2 * t]);
+            ct(x[2], x[3], p.tw[(tix << (LOGT - 1)) + 2 * t + 1]);
+        }
+    }
+    // inverse passes Q .. 0: registers in layout Q -> registers in layout 0 after the tile's first stage.  WHOLE: the tile's
+    // first stage is stage 0 of the transform (scaled legs).
+    template <int Q, bool WHOLE>
+    __device__ static __forceinline__ void inv_from(E *x, uint32_t *lds, int t, const P &p, uint32_t tix) {
+        if constexpr (Q >= kPasses) {
+            gs(x[0], x[1], p.itw[(tix << (LOGT - 1)) + 2 * t]);
+            gs(x[2], x[3], p.itw[(tix << (LOGT - 1)) + 2 * t + 1]);
+            x[0] = F::weak_reduce(x[0]);
+            x[2] = F::weak_reduce(x[2]);
+        } else if constexpr (Q == 0) {
+            inv_group<2, WHOLE>(x, p, tix);
+        } else {
+            inv_group<2, false>(x, p, (tix << (2 * Q)) + block<Q>(t));
+        }
+        if constexpr (Q > 0) {
+            exchange<Q, Q - 1>(x, lds, t);
+            inv_from<Q - 1, WHOLE>(x, lds, t, p, tix);
+        }
+    }
+    __device__ static __forceinline__ void load(const S *src, E *x, int t) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) x[j] = F::load(src + pos<0>(t, j));
+    }
+    __device__ static __forceinline__ void store(S *dst, const E *x, int t) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) F::store(dst + pos<0>(t, j), x[j]);
+    }
+};
 
-// forward stages k-9 .. k-1 of one tile: canonical memory images in (layout L1), L5 registers out.  tix = 2^(k-9) + tile index
-// inside its ring element = the table index of the tile's block at stage k-9.
-__device__ __forceinline__ void tile_fwd(const S *src, E *x, uint32_t *lds, int t, const P &p, uint32_t tix) {
-#pragma unroll
-    for (int j = 0; j < 4; j++) x[j] = F::load(src + pos<1>(t, j));
-    fwd_group<2>(x, p.tw, tix);
-    exchange<1, 2>(x, lds, t);
-    fwd_group<2>(x, p.tw, tix * 4 + (t >> 5));
-    exchange<2, 3>(x, lds, t);
-    fwd_group<2>(x, p.tw, tix * 16 + (t >> 3));
-#pragma unroll
-    for (int j = 0; j < 4; j++) x[j] = F::weak_reduce(x[j]);  // six stages of uncarried sums: limbs up to 7 * 2^28
-    exchange<3, 4>(x, lds, t);
-    fwd_group<2>(x, p.tw, tix * 64 + (t >> 1));
-    exchange<4, 5>(x, lds, t);
-    ct(x[0], x[1], p.tw[tix * 256 + 2 * t]);
-    ct(x[2], x[3], p.tw[tix * 256 + 2 * t + 1]);
-}
-// inverse stages k-1 .. k-9: L5 registers in, canonical memory images out (layout L1); for k == 9 the last group ends with
-// stage 0 of the transform
-__device__ __forceinline__ void tile_inv(E *x, S *dst, uint32_t *lds, int t, const P &p, uint32_t tix) {
-    gs(x[0], x[1], p.itw[tix * 256 + 2 * t]);
-    gs(x[2], x[3], p.itw[tix * 256 + 2 * t + 1]);
-    x[0] = F::weak_reduce(x[0]);
-    x[2] = F::weak_reduce(x[2]);
-    exchange<5, 4>(x, lds, t);
-    inv_group<2, false>(x, p, tix * 64 + (t >> 1));
-    exchange<4, 3>(x, lds, t);
-    inv_group<2, false>(x, p, tix * 16 + (t >> 3));
-    exchange<3, 2>(x, lds, t);
-    inv_group<2, false>(x, p, tix * 4 + (t >> 5));
-    exchange<2, 1>(x, lds, t);
-    if (p.k == kTileLog) inv_group<2, true>(x, p, tix);
-    else inv_group<2, false>(x, p, tix);
-#pragma unroll
-    for (int j = 0; j < 4; j++) F::store(dst + pos<1>(t, j), x[j]);
-}
-
-// grid.x = batch * D / 512, 128 lanes.  a, b, out: flat batches (out may be a).
 #ifndef SR_ST_WAVES
-#define SR_ST_WAVES 3  /* measured at D = 2^12, batch 2^12: 1.72 ms with 2 waves per SIMD, 1.64 with 3, 1.79 with 4 */
+#define SR_ST_WAVES 3  /* 512-tiles at D = 2^12, batch 2^12: 1.72 ms with 2 waves per SIMD, 1.64 with 3, 1.79 with 4 */
 #endif
-template <int MODE>
-__global__ __launch_bounds__(kLanes, SR_ST_WAVES) void rows512_kernel(S *a, const S *b, S *out, P p) {
-    __shared__ uint32_t lds[kLdsWords];
+// grid.x = batch * D / 2^LOGT.  a, b, out: flat batches (out may be a).  WHOLE: LOGT == k.
+template <int LOGT, int MODE, bool WHOLE>
+__global__ __launch_bounds__(1 << (LOGT - 2), (LOGT == 9 ? SR_ST_WAVES : 4)) void tile_kernel(S *a, const S *b, S *out, P p) {
+    using T = Tile<LOGT>;
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const int t = threadIdx.x;
     const size_t tile = blockIdx.x;
-    const size_t off = tile << kTileLog;
-    const uint32_t tix = (1u << (p.k - kTileLog)) + (uint32_t)(tile & (((size_t)1 << (p.k - kTileLog)) - 1));
+    const size_t off = tile << LOGT;
+    const uint32_t tix = WHOLE ? 1u : (1u << (p.k - LOGT)) + (uint32_t)(tile & (((size_t)1 << (p.k - LOGT)) - 1));
+    constexpr int LAST = T::kLayouts - 1;
     E x[4];
     if constexpr (MODE == MODE_FWD) {
-        tile_fwd(a + off, x, lds, t, p, tix);
-        exchange<5, 1>(x, lds, t);
-#pragma unroll
-        for (int j = 0; j < 4; j++) F::store(out + off + pos<1>(t, j), x[j]);
+        T::load(a + off, x, t);
+        T::template fwd_from<0>(x, lds, t, p, tix);
+        T::template exchange<LAST, 0>(x, lds, t);
+        T::store(out + off, x, t);
     } else if constexpr (MODE == MODE_INV) {
-#pragma unroll
-        for (int j = 0; j < 4; j++) x[j] = F::load(a + off + pos<1>(t, j));
-        exchange<1, 5>(x, lds, t);
-        tile_inv(x, out + off, lds, t, p, tix);
+        T::load(a + off, x, t);
+        T::template exchange<0, LAST>(x, lds, t);
+        T::template inv_from<LAST, WHOLE>(x, lds, t, p, tix);
+        T::store(out + off, x, t);
     } else {
         E y[4];
-        tile_fwd(a + off, y, lds, t, p, tix);
-        tile_fwd(b + off, x, lds, t, p, tix);
+        T::load(a + off, y, t);
+        T::template fwd_from<0>(y, lds, t, p, tix);
+        T::load(b + off, x, t);
+        T::template fwd_from<0>(x, lds, t, p, tix);
 #pragma unroll
         for (int j = 0; j < 4; j++) x[j] = F::mul_data(x[j], y[j]);
-        tile_inv(x, out + off, lds, t, p, tix);
+        T::template inv_from<LAST, WHOLE>(x, lds, t, p, tix);
+        T::store(out + off, x, t);
     }
 }
 
 inline bool supported(int k) { return k >= kTileLog && k <= 20; }
+// 512 <= D <= 4096: the tile kernel takes the whole transform; above, the last nine stages after the strided passes
+// Largest log2 D taken as one tile.  Measured over 2^24 coefficients (ring product, ms): D = 1024 one tile 1.96 / strided + 512-tiles
+// 2.48; D = 2048 2.22 / 2.46; D = 4096 2.86 / 2.57 (1024 lanes and 157 KB of LDS leave one workgroup per CU and every transpose
+// stalls all sixteen waves).  SR_ST_WHOLE_MAX overrides (9..12; read per call so that tests can switch it).
+inline int whole_max() {
+    const char *e = getenv("SR_ST_WHOLE_MAX");
+    const int x = e ? atoi(e) : 11;
+    return x < 9 ? 9 : (x > 12 ? 12 : x);
+}
+inline bool whole(int k) { return k >= kTileLog && k <= whole_max(); }
 
 template <int DIR>
 inline int launch_cols(S *d, size_t batch, int s0, int m, const P &p, hipStream_t st) {
@@ -281,7 +320,7 @@ inline int launch_cols(S *d, size_t batch, int s0, int m, const P &p, hipStream_
 // the strided stages 0 .. k-10 as passes of (c mod 3), 3, 3, ... stages; begin / end bracket each launch for the profiler
 template <class Hook>
 inline int fwd_cols(S *d, size_t batch, const P &p, hipStream_t st, Hook &&hook) {
-    int c = p.k - kTileLog, s0 = 0;
+    int c = whole(p.k) ? 0 : p.k - kTileLog, s0 = 0;
     while (c > 0) {
         const int m = c % 3 ? c % 3 : 3;
         hook(true);
@@ -295,7 +334,7 @@ inline int fwd_cols(S *d, size_t batch, const P &p, hipStream_t st, Hook &&hook)
 }
 template <class Hook>
 inline int inv_cols(S *d, size_t batch, const P &p, hipStream_t st, Hook &&hook) {
-    const int c = p.k - kTileLog;
+    const int c = whole(p.k) ? 0 : p.k - kTileLog;
     int s_hi = c;  // stages [0, s_hi) remain
     // mirror of fwd_cols: its passes were (c mod 3 or 3), 3, 3, ...; undo them last to first
     while (s_hi > 0) {
@@ -309,12 +348,37 @@ inline int inv_cols(S *d, size_t batch, const P &p, hipStream_t st, Hook &&hook)
     }
     return 0;
 }
+template <int LOGT, int MODE, bool WHOLE>
+inline int launch_tile(S *a, const S *b, S *out, size_t tiles, const P &p, hipStream_t st) {
+    using T = Tile<LOGT>;
+    constexpr size_t bytes = (size_t)T::kWords * 4;
+    if constexpr (bytes > 65536) {  // more than 64 KB of dynamic LDS has to be allowed once per kernel and device
+        static bool attr_done[64] = {};
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess) return 1;
+        if (dev < 0 || dev >= 64 || !attr_done[dev]) {
+            if (hipFuncSetAttribute((const void *)tile_kernel<LOGT, MODE, WHOLE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) !=
+                hipSuccess)
+                return 1;
+            if (dev >= 0 && dev < 64) attr_done[dev] = true;
+        }
+    }
+    hipLaunchKernelGGL((tile_kernel<LOGT, MODE, WHOLE>), dim3((unsigned)tiles), dim3(T::kLanes), bytes, st, a, b, out, p);
+    return hipGetLastError() != hipSuccess;
+}
 template <int MODE>
 inline int launch_rows(S *a, const S *b, S *out, size_t batch, const P &p, hipStream_t st) {
-    const size_t tiles = batch << (p.k - kTileLog);
+    const int logt = whole(p.k) ? p.k : kTileLog;
+    const size_t tiles = batch << (p.k - logt);
     if (tiles > 0x7FFFFFFFull) return 1;
-    hipLaunchKernelGGL((rows512_kernel<MODE>), dim3((unsigned)tiles), dim3(kLanes), 0, st, a, b, out, p);
-    return hipGetLastError() != hipSuccess;
+    if (!whole(p.k)) return launch_tile<9, MODE, false>(a, b, out, tiles, p, st);
+    switch (p.k) {
+        case 9: return launch_tile<9, MODE, true>(a, b, out, tiles, p, st);
+        case 10: return launch_tile<10, MODE, true>(a, b, out, tiles, p, st);
+        case 11: return launch_tile<11, MODE, true>(a, b, out, tiles, p, st);
+        case 12: return launch_tile<12, MODE, true>(a, b, out, tiles, p, st);
+        default: return 1;
+    }
 }
 
 }  // namespace st
