@@ -218,7 +218,10 @@ def main():
     # under profiles/) x waves per launch / measured duration, against one wave-instruction per 4 cycles per SIMD
     valu = None
     try:
-        vj = json.load(open(os.path.join(ROOT, "profiles", rounds[-1], "valu.json")))
+        vpath = os.path.join(ROOT, "profiles", rounds[-1], "valu_%s.json" % args.workload)
+        if not os.path.exists(vpath):
+            vpath = os.path.join(ROOT, "profiles", rounds[-1], "valu.json")
+        vj = json.load(open(vpath))
         if vj.get("workload") == args.workload and batch == vj.get("batch") and dom_tag in vj["kernels"]:
             kv = vj["kernels"][dom_tag]
             rate = kv["waves_per_launch"] * kv["valu_per_wave"] / (dom_avg_ms * 1e-3)
