@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Randomised differential soak (not part of pytest): random ring, degree, batch and operation against the oracle for a fixed
-wall-clock budget.  usage: fuzz_random_parity.py [seconds] [seed]"""
+wall-clock budget.  usage: fuzz_random_parity.py [seconds] [seed]   (SR_FUZZ_RINGS=stark restricts the rings drawn)"""
 import os
 import sys
 import time
@@ -28,8 +28,9 @@ def ring(name, k):
 t_end = time.time() + budget
 n_checks, by_op = 0, {}
 while time.time() < t_end:
-    name = ["goldilocks", "babybear", "stark"][int(rng.integers(0, 3))]
-    kmax = {"goldilocks": 18, "babybear": 17, "stark": 13}[name]
+    names = os.environ.get("SR_FUZZ_RINGS", "goldilocks,babybear,stark").split(",")
+    name = names[int(rng.integers(0, len(names)))]
+    kmax = {"goldilocks": 18, "babybear": 17, "stark": 14}[name]
     k = int(rng.integers(0, kmax + 1))
     F = O.FIELD_ID[name]
     p = P.PRIMES[name][0]
