@@ -76,7 +76,7 @@ struct sr_ctx {
     size_t table_bytes = 0;
     // inverse stage-0 constants (table form): plain inverse, and fused ring-mul (with boundary correction)
     unsigned char inv_scale0[40], inv_scale1[40], mul_scale0[40], mul_scale1[40];
-    bool stark_tuned = false;  // and k >= 9: the register-tiled kernels of ntt_stark.hpp (SR_STARK_TUNED=0: generic kernels on StarkL)
+    bool stark_tuned = false;  // and k >= 4: the register-tiled kernels of ntt_stark.hpp (SR_STARK_TUNED=0: generic kernels on StarkL)
     bool stark_lazy = false;  // Stark rings: transforms run on StarkL (nine 28-bit limbs, lazy carries; stark_lazy.hpp)
     // staging for host-pointer entry points
     void *stage[4] = {nullptr, nullptr, nullptr, nullptr};  // [2], [3]: second lane of the chunked host pipeline
@@ -551,7 +551,7 @@ int rt_ring_mul(sr_ctx *c, uint64_t *out, const uint64_t *a, uint64_t *b, size_t
     return rt_scratch_release(c, st);
 }
 
-// ---- Stark rings, k >= 9: ntt_stark.hpp ----
+// ---- Stark rings, k >= 4: ntt_stark.hpp ----
 int st_fwd(sr_ctx *c, uint64_t *d, size_t batch, hipStream_t st) {
     if (batch == 0) return SR_OK;
     auto p = make_params<sr::StarkL>(c, false);

@@ -1,4 +1,4 @@
-// Tuned negacyclic transforms for the Stark rings Fp[X]/(X^D+1), D = 2^k, 9 <= k <= 20, on StarkL arithmetic (stark_lazy.hpp).
+// Tuned negacyclic transforms for the Stark rings Fp[X]/(X^D+1), D = 2^k, 4 <= k <= 20, on StarkL arithmetic (stark_lazy.hpp).
 // Same algorithm, twiddle tables and slot order as the generic kernels (ntt_generic.hpp; reference
 // crates/ring/src/cyclotomic_ring/models/stark_prime/ntt.rs:121-235 forward, :245-346 inverse, generalised to 2^k): forward
 // Cooley-Tukey stages s = 0..k-1 with w = tw[2^s + block], inverse Gentleman-Sande stages k-1..0 with D^-1 in stage 0.
@@ -159,11 +159,13 @@ __global__ __launch_bounds__(256, 2) void cols_kernel(S *data, size_t batch, int
 //     e = ((t >> ls) << (ls + 2)) + (j << ls) + (t & (2^ls - 1)),   ls = LOGT - 2q - 2      (legs 2^ls apart, block t >> ls)
 // and an odd LOGT ends with the single stage of half 1 on e = 4 t + j (blocks 2 t, 2 t + 1).  Pass 0's twiddles are uniform.
 // LDS: limb-major rows, pad(e) = e + PM (e >> 5): conflict-free or two-way for every layout (PM = 5 at LOGT = 9, else 3).
-template <int LOGT>
+// TPW tiles share a workgroup (and an LDS row) when a tile has fewer than 128 lanes: D = 16 .. 256, 256 lanes per workgroup;
+// pad() is additive over tile bases (multiples of 16), so a tile addresses its slice through an offset pointer.
+template <int LOGT, int TPW = 1>
 struct Tile {
-    static constexpr int kLanes = 1 << (LOGT - 2);
+    static constexpr int kLanes = 1 << (LOGT - 2);   // per tile
     static constexpr int kPM = LOGT == 9 ? 5 : 3;
-    static constexpr int kRow = ((1 << LOGT) - 1) + kPM * (((1 << LOGT) - 1) >> 5) + 1;
+    static constexpr int kRow = ((TPW << LOGT) - 1) + kPM * (((TPW << LOGT) - 1) >> 5) + 1;
     static constexpr int kWords = 9 * kRow;
     static constexpr int kPasses = LOGT / 2;     // two-stage passes
     static constexpr bool kOdd = LOGT & 1;
@@ -252,14 +254,22 @@ struct Tile {
 #ifndef SR_ST_WAVES
 #define SR_ST_WAVES 3  /* 512-tiles at D = 2^12, batch 2^12: 1.72 ms with 2 waves per SIMD, 1.64 with 3, 1.79 with 4 */
 #endif
-// grid.x = batch * D / 2^LOGT.  a, b, out: flat batches (out may be a).  WHOLE: LOGT == k.
+constexpr int tiles_per_wg(int logt) { return logt >= 9 ? 1 : 256 >> (logt - 2); }
+// grid.x = ceil(n_tiles / TPW), n_tiles = batch * D / 2^LOGT.  a, b, out: flat batches (out may be a).  WHOLE: LOGT == k.
+// Lanes of a tile past the end (ragged last workgroup, TPW > 1) compute on zeros and store nothing: every lane reaches every
+// barrier.
 template <int LOGT, int MODE, bool WHOLE>
-__global__ __launch_bounds__(1 << (LOGT - 2), (LOGT == 9 ? SR_ST_WAVES : 4)) void tile_kernel(S *a, const S *b, S *out, P p) {
-    using T = Tile<LOGT>;
-    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
-    const int t = threadIdx.x;
-    const size_t tile = blockIdx.x;
-    const size_t off = tile << LOGT;
+__global__ __launch_bounds__((1 << (LOGT - 2)) * tiles_per_wg(LOGT), (LOGT <= 9 ? SR_ST_WAVES : 4)) void tile_kernel(S *a, const S *b, S *out,
+                                                                                                                   size_t n_tiles, P p) {
+    constexpr int TPW = tiles_per_wg(LOGT);
+    using T = Tile<LOGT, TPW>;
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds_all[];
+    const int t = threadIdx.x & (T::kLanes - 1);
+    const int tile_in_wg = threadIdx.x >> (LOGT - 2);
+    uint32_t *lds = lds_all + T::pad(tile_in_wg << LOGT);
+    const size_t tile = blockIdx.x * (size_t)TPW + tile_in_wg;
+    const bool live = TPW == 1 || tile < n_tiles;
+    const size_t off = (live ? tile : 0) << LOGT;
     const uint32_t tix = WHOLE ? 1u : (1u << (p.k - LOGT)) + (uint32_t)(tile & (((size_t)1 << (p.k - LOGT)) - 1));
     constexpr int LAST = T::kLayouts - 1;
     E x[4];
@@ -267,12 +277,12 @@ __global__ __launch_bounds__(1 << (LOGT - 2), (LOGT == 9 ? SR_ST_WAVES : 4)) voi
         T::load(a + off, x, t);
         T::template fwd_from<0>(x, lds, t, p, tix);
         T::template exchange<LAST, 0>(x, lds, t);
-        T::store(out + off, x, t);
+        if (live) T::store(out + off, x, t);
     } else if constexpr (MODE == MODE_INV) {
         T::load(a + off, x, t);
         T::template exchange<0, LAST>(x, lds, t);
         T::template inv_from<LAST, WHOLE>(x, lds, t, p, tix);
-        T::store(out + off, x, t);
+        if (live) T::store(out + off, x, t);
     } else {
         E y[4];
         T::load(a + off, y, t);
@@ -282,11 +292,12 @@ __global__ __launch_bounds__(1 << (LOGT - 2), (LOGT == 9 ? SR_ST_WAVES : 4)) voi
 #pragma unroll
         for (int j = 0; j < 4; j++) x[j] = F::mul_data(x[j], y[j]);
         T::template inv_from<LAST, WHOLE>(x, lds, t, p, tix);
-        T::store(out + off, x, t);
+        if (live) T::store(out + off, x, t);
     }
 }
 
-inline bool supported(int k) { return k >= kTileLog && k <= 20; }
+constexpr int kMinLog = 4;  // D = 16, the reference's own Stark ring (stark_prime/mod.rs:34-68), is the smallest tile
+inline bool supported(int k) { return k >= kMinLog && k <= 20; }
 // 512 <= D <= 4096: the tile kernel takes the whole transform; above, the last nine stages after the strided passes
 // Largest log2 D taken as one tile.  Measured over 2^24 coefficients (ring product, ms): D = 1024 one tile 1.96 / strided + 512-tiles
 // 2.48; D = 2048 2.22 / 2.46; D = 4096 2.86 / 2.57 (1024 lanes and 157 KB of LDS leave one workgroup per CU and every transpose
@@ -296,7 +307,7 @@ inline int whole_max() {
     const int x = e ? atoi(e) : 11;
     return x < 9 ? 9 : (x > 12 ? 12 : x);
 }
-inline bool whole(int k) { return k >= kTileLog && k <= whole_max(); }
+inline bool whole(int k) { return k >= kMinLog && k <= whole_max(); }
 
 template <int DIR>
 inline int launch_cols(S *d, size_t batch, int s0, int m, const P &p, hipStream_t st) {
@@ -350,8 +361,9 @@ inline int inv_cols(S *d, size_t batch, const P &p, hipStream_t st, Hook &&hook)
 }
 template <int LOGT, int MODE, bool WHOLE>
 inline int launch_tile(S *a, const S *b, S *out, size_t tiles, const P &p, hipStream_t st) {
-    using T = Tile<LOGT>;
+    using T = Tile<LOGT, tiles_per_wg(LOGT)>;
     constexpr size_t bytes = (size_t)T::kWords * 4;
+    const size_t wgs = (tiles + tiles_per_wg(LOGT) - 1) / tiles_per_wg(LOGT);
     if constexpr (bytes > 65536) {  // more than 64 KB of dynamic LDS has to be allowed once per kernel and device
         static bool attr_done[64] = {};
         int dev = 0;
@@ -363,7 +375,8 @@ inline int launch_tile(S *a, const S *b, S *out, size_t tiles, const P &p, hipSt
             if (dev >= 0 && dev < 64) attr_done[dev] = true;
         }
     }
-    hipLaunchKernelGGL((tile_kernel<LOGT, MODE, WHOLE>), dim3((unsigned)tiles), dim3(T::kLanes), bytes, st, a, b, out, p);
+    hipLaunchKernelGGL((tile_kernel<LOGT, MODE, WHOLE>), dim3((unsigned)wgs), dim3(T::kLanes * tiles_per_wg(LOGT)), bytes, st, a, b, out,
+                       tiles, p);
     return hipGetLastError() != hipSuccess;
 }
 template <int MODE>
@@ -373,6 +386,11 @@ inline int launch_rows(S *a, const S *b, S *out, size_t batch, const P &p, hipSt
     if (tiles > 0x7FFFFFFFull) return 1;
     if (!whole(p.k)) return launch_tile<9, MODE, false>(a, b, out, tiles, p, st);
     switch (p.k) {
+        case 4: return launch_tile<4, MODE, true>(a, b, out, tiles, p, st);
+        case 5: return launch_tile<5, MODE, true>(a, b, out, tiles, p, st);
+        case 6: return launch_tile<6, MODE, true>(a, b, out, tiles, p, st);
+        case 7: return launch_tile<7, MODE, true>(a, b, out, tiles, p, st);
+        case 8: return launch_tile<8, MODE, true>(a, b, out, tiles, p, st);
         case 9: return launch_tile<9, MODE, true>(a, b, out, tiles, p, st);
         case 10: return launch_tile<10, MODE, true>(a, b, out, tiles, p, st);
         case 11: return launch_tile<11, MODE, true>(a, b, out, tiles, p, st);

@@ -370,10 +370,12 @@ def test_babybear_older_plan_equals_cols256_plan(torch_cuda, k, batch):
         del os.environ["SR_RT_COLS256"]
 
 
-@pytest.mark.parametrize("k,batch", [(4, 37), (8, 5), (9, 7), (10, 3), (11, 3), (12, 5), (13, 2), (14, 2), (15, 1), (16, 1)])
+@pytest.mark.parametrize("k,batch", [(1, 9), (3, 70), (4, 37), (4, 131), (5, 33), (6, 17), (7, 9), (8, 5), (9, 7), (10, 3), (11, 3), (12, 5),
+                                     (13, 2), (14, 2), (15, 1), (16, 1)])
 def test_stark_three_kernel_families_agree(torch_cuda, k, batch):
     """Stark rings run on three kernel families that must produce the same bytes: the register-tiled kernels on 28-bit lazy limbs
-    (ntt_stark.hpp, k >= 9: the strided passes take 1, 2 or 3 stages at a time -- k = 10..16 walks every combination), the generic
+    (ntt_stark.hpp, k >= 4: several small ring elements share a workgroup -- the batches leave ragged last workgroups --, one
+    tile per element up to D = 2048, strided passes of 1, 2 or 3 stages above: k = 12..16 walks every combination), the generic
     LDS kernels on the same arithmetic (SR_STARK_TUNED=0, every k >= 1) and the generic kernels on 8 x 32-bit limbs
     (SR_STARK_LAZY=0, what every size ran before).  Inputs include all-zero, all-(p-1), 1 and X^(D-1); the oracle pins the values."""
     import os

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Throughput of the reference-native small rings (Goldilocks-24, BabyBear-72, Frog-16) on one GPU: CRT, ICRT, slot product,
+"""Throughput of the reference-native small rings (Goldilocks-24, BabyBear-72, Frog-16, Stark-16) on one GPU: CRT, ICRT, slot product,
 fused ring product over a large batch resident in HBM.  Prints elements/s and effective HBM GB/s (algorithmic bytes)."""
 import os
 import sys
@@ -11,10 +11,10 @@ import torch
 
 from stark_rings_amd import CyclotomicRing
 
-for name, D in (("goldilocks24", 24), ("babybear72", 72), ("frog16", 16)):
-    ring = CyclotomicRing(name)
+for name, D in (("goldilocks24", 24), ("babybear72", 72), ("frog16", 16), ("stark16", 16)):
+    ring = CyclotomicRing("stark", 4) if name == "stark16" else CyclotomicRing(name)   # stark_prime/mod.rs:34-68: X^16 + 1
     batch = 1 << 22
-    n = batch * D
+    n = batch * ring.words_per_elem
     a = torch.empty(n, dtype=torch.int64, device="cuda")
     b = torch.empty(n, dtype=torch.int64, device="cuda")
     out = torch.empty_like(a)
