@@ -202,33 +202,52 @@ __device__ __forceinline__ void small_slot_mul(typename F::elem *x, const typena
 // D * 8 bytes apart from its neighbour's: reading them lane by lane would touch 64 cache lines per load instruction.  The
 // block of 64 * D words is therefore moved between HBM and LDS with lane-contiguous accesses (512 B per instruction) and
 // each lane picks its element out of LDS (element stride D + 1 words: conflict-free).  A ragged last block clamps its reads.
+// The block goes through LDS in kRounds<D> rounds of 64 / kRounds elements (D = 72: two rounds, 9.3 KB per wave instead of 18.7,
+// so that the register file and not the LDS sets the number of resident waves).
+template <int D>
+constexpr int small_rounds() { return D > 32 ? 2 : 1; }
 template <class F, int D>
 __device__ __forceinline__ void small_block_load(typename F::elem *lds, const uint64_t *src, size_t first, size_t batch,
                                                  typename F::elem *x) {
+    constexpr int R = small_rounds<D>(), PER = 64 / R;
     const int t = threadIdx.x;
     const size_t n_valid = (batch - first < 64 ? batch - first : 64) * D;
-#pragma unroll 4
-    for (int idx = t; idx < 64 * D; idx += 64) {
-        const int el = idx / D, i = idx - el * D;
-        lds[el * (D + 1) + i] = F::load(src + first * D + ((size_t)idx < n_valid ? idx : 0));
-    }
-    __syncthreads();
 #pragma unroll
-    for (int i = 0; i < D; i++) x[i] = lds[t * (D + 1) + i];
-    __syncthreads();
+    for (int r = 0; r < R; r++) {
+#pragma unroll 4
+        for (int idx = t; idx < PER * D; idx += 64) {
+            const int el = idx / D, i = idx - el * D;
+            const size_t g = (size_t)r * PER * D + idx;
+            lds[el * (D + 1) + i] = F::load(src + first * D + (g < n_valid ? g : 0));
+        }
+        __syncthreads();
+        if (t / PER == r) {
+#pragma unroll
+            for (int i = 0; i < D; i++) x[i] = lds[(t - r * PER) * (D + 1) + i];
+        }
+        __syncthreads();
+    }
 }
 template <class F, int D>
 __device__ __forceinline__ void small_block_store(typename F::elem *lds, uint64_t *dst, size_t first, size_t batch,
                                                   const typename F::elem *x) {
+    constexpr int R = small_rounds<D>(), PER = 64 / R;
     const int t = threadIdx.x;
     const size_t n_valid = (batch - first < 64 ? batch - first : 64) * D;
 #pragma unroll
-    for (int i = 0; i < D; i++) lds[t * (D + 1) + i] = x[i];
-    __syncthreads();
+    for (int r = 0; r < R; r++) {
+        if (t / PER == r) {
+#pragma unroll
+            for (int i = 0; i < D; i++) lds[(t - r * PER) * (D + 1) + i] = x[i];
+        }
+        __syncthreads();
 #pragma unroll 4
-    for (int idx = t; idx < 64 * D; idx += 64) {
-        const int el = idx / D, i = idx - el * D;
-        if ((size_t)idx < n_valid) F::store(dst + first * D + idx, lds[el * (D + 1) + i]);
+        for (int idx = t; idx < PER * D; idx += 64) {
+            const int el = idx / D, i = idx - el * D;
+            const size_t g = (size_t)r * PER * D + idx;
+            if (g < n_valid) F::store(dst + first * D + g, lds[el * (D + 1) + i]);
+        }
+        if (r + 1 < R) __syncthreads();
     }
 }
 
@@ -255,7 +274,7 @@ __global__ __launch_bounds__(64) void small_ring_kernel(SmallRingConsts k, const
                                                         uint64_t *out, size_t batch) {
     using E = typename F::elem;
     constexpr bool STAGED = small_staged<F, D, W, OP>();
-    __shared__ E lds[STAGED ? 64 * (D + 1) : 1];
+    __shared__ E lds[STAGED ? (64 / small_rounds<D>()) * (D + 1) : 1];
     const size_t first = blockIdx.x * (size_t)64;
     E x[D];
     small_get<F, D, STAGED>(lds, a, first, batch, x);
