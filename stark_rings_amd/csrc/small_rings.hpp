@@ -232,7 +232,7 @@ __device__ __forceinline__ void small_slot_mul(typename F::elem *x, const typena
 // The block goes through LDS in kRounds<D> rounds of 64 / kRounds elements (D = 72: two rounds, 9.3 KB per wave instead of 18.7,
 // so that the register file and not the LDS sets the number of resident waves).
 template <int D>
-constexpr int small_rounds() { return D > 32 ? 2 : 1; }
+constexpr int small_rounds() { return D >= 24 ? 2 : 1; }
 template <class F, int D>
 __device__ __forceinline__ void small_block_load(typename F::elem *lds, const uint64_t *src, size_t first, size_t batch,
                                                  typename F::elem *x) {
@@ -297,7 +297,7 @@ __device__ __forceinline__ void small_get(typename F::elem *lds, const uint64_t 
     }
 }
 template <class F, int D, int W, int OP>
-__global__ __launch_bounds__(64, 3) void small_ring_kernel(SmallRingConsts k, const uint64_t *a, const uint64_t *b,
+__global__ __launch_bounds__(64, (small_staged<F, D, W, OP>() && D == 24 ? 4 : 3)) void small_ring_kernel(SmallRingConsts k, const uint64_t *a, const uint64_t *b,
                                                         uint64_t *out, size_t batch) {
     using E = typename F::elem;
     constexpr bool STAGED = small_staged<F, D, W, OP>();
