@@ -155,7 +155,8 @@ int sr_recompose_batch(sr_ctx *ctx, uint64_t *out, const uint64_t *in, uint64_t 
  * PARITY UNPINNED -- the reference holds no serialised golden bytes).  An element is D * sr_wire_coeff_bytes() bytes; no
  * length prefix (the u64 length words of Vec / Matrix / SparseMatrix, matrix.rs:111-145, sparse_matrix.rs:158-200, are
  * host-side framing: include/stark_rings.hpp, stark_rings_amd/wire.py).
- * d_offsets (optional, device, one u64 per element): byte offset of the element inside the wire buffer, multiples of 8, so the
+ * d_offsets (optional, device, one u64 per element): byte offset of the element inside the wire buffer, multiples of 8 (4 for the
+ * BabyBear rings), so the
  * caller can leave room for its framing words; NULL = densely packed.  Wire and element buffers must not overlap.
  * Deserialising a coefficient >= p is ark's SerializationError::InvalidData: the device form stores 0 for it and counts it
  * (sr_wire_invalid_count reads and clears the count, synchronising the stream; misaligned offsets are counted there too and

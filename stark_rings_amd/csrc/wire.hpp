@@ -15,8 +15,8 @@
 //
 // One lane = one coefficient.  Memory-bound: D (8 + W) bytes per element (8 = memory image, W = wire bytes per coefficient).
 // `offsets` (optional, device): byte offset of element e inside the wire buffer, so callers can interleave their own framing
-// words (row lengths, column indices); nullptr = densely packed.  Offsets must be multiples of 8; an element with a misaligned
-// offset is skipped and counted with the invalid coefficients.
+// words (row lengths, column indices); nullptr = densely packed.  Offsets must be multiples of 8 (of 4 for BabyBear, whose
+// coefficients are 4 bytes on the wire); an element with a misaligned offset is skipped and counted with the invalid coefficients.
 #pragma once
 #include "decompose.hpp"
 #include "fields.hpp"
@@ -78,12 +78,12 @@ struct Codec<Stark> {
 template <class F>
 __global__ __launch_bounds__(256) void serialize_kernel(uint8_t *out, const typename F::storage *in, size_t d, size_t batch,
                                                         const uint64_t *offsets, unsigned long long *bad) {
-    constexpr size_t W = Codec<F>::W;
+    constexpr size_t W = Codec<F>::W, ALIGN = W < 8 ? W : 8;
     const size_t n = batch * d;
     for (size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x; t < n; t += (size_t)gridDim.x * blockDim.x) {
         const size_t e = t / d, i = t - e * d;
         const size_t base = offsets ? (size_t)offsets[e] : e * d * W;
-        if (base & 7) {
+        if (offsets && (base & (ALIGN - 1))) {  // the dense layout is aligned by construction
             if (i == 0) atomicAdd(bad, 1ull);
             continue;
         }
@@ -95,12 +95,12 @@ __global__ __launch_bounds__(256) void serialize_kernel(uint8_t *out, const type
 template <class F>
 __global__ __launch_bounds__(256) void deserialize_kernel(typename F::storage *out, const uint8_t *in, size_t d, size_t batch,
                                                           const uint64_t *offsets, unsigned long long *bad) {
-    constexpr size_t W = Codec<F>::W;
+    constexpr size_t W = Codec<F>::W, ALIGN = W < 8 ? W : 8;
     const size_t n = batch * d;
     for (size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x; t < n; t += (size_t)gridDim.x * blockDim.x) {
         const size_t e = t / d, i = t - e * d;
         const size_t base = offsets ? (size_t)offsets[e] : e * d * W;
-        if (base & 7) {
+        if (offsets && (base & (ALIGN - 1))) {  // the dense layout is aligned by construction
             if (i == 0) atomicAdd(bad, 1ull);
             F::store(out + t, F::zero());
             continue;
