@@ -785,12 +785,15 @@ int dev_addsub(sr_ctx *c, uint64_t *l, const uint64_t *r, size_t batch, bool sub
 }
 int dev_spmv(sr_ctx *c, uint64_t *y, const uint64_t *vals, const uint32_t *cols, const uint64_t *row_ptr, const uint64_t *v,
              size_t nrows, size_t ncols, hipStream_t st) {
+    if (c->stark_lazy) return spmv_dev<sr::StarkL>(c, y, vals, cols, row_ptr, v, nrows, ncols, st);  // sums of products on 28-bit lazy limbs (stark_lazy.hpp)
     DISPATCH_POW2(c, (spmv_dev<F>(c, y, vals, cols, row_ptr, v, nrows, ncols, st)));
 }
 int dev_matmul(sr_ctx *c, uint64_t *y, const uint64_t *a, const uint64_t *b, size_t n, size_t m, size_t p, hipStream_t st) {
+    if (c->stark_lazy) return matmul_dev<sr::StarkL>(c, y, a, b, n, m, p, st);  // sums of products on 28-bit lazy limbs (stark_lazy.hpp)
     DISPATCH_POW2(c, (matmul_dev<F>(c, y, a, b, n, m, p, st)));
 }
 int dev_matvec(sr_ctx *c, uint64_t *y, const uint64_t *m, const uint64_t *v, size_t nrows, size_t ncols, hipStream_t st) {
+    if (c->stark_lazy) return matvec_dev<sr::StarkL>(c, y, m, v, nrows, ncols, st);  // sums of products on 28-bit lazy limbs (stark_lazy.hpp)
     DISPATCH_POW2(c, (matvec_dev<F>(c, y, m, v, nrows, ncols, st)));
 }
 int dev_ring_mul(sr_ctx *c, uint64_t *out, const uint64_t *a, uint64_t *b, size_t batch, hipStream_t st) {

@@ -455,6 +455,8 @@ struct Stark {
 #endif
     SR_HD static elem mul_tw(const elem &a, const elem &w) { return mont_mul(a, w); }
     SR_HD static elem mul_boundary(const elem &a, const elem &b) { return mont_mul(a, b); }
+    SR_HD static elem mul_boundary_pre(const elem &a, const elem &b) { return mont_mul(a, b); }
+    SR_HD static elem boundary_post(const elem &x) { return x; }
     SR_HD static elem r2() {  // 2^512 mod p
         elem e;
         e.l[0] = 0x7E000401u; e.l[1] = 0xFFFFFD73u; e.l[2] = 0x330FFFFFu; e.l[3] = 0x00000001u;

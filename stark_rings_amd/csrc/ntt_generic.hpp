@@ -235,11 +235,15 @@ __global__ __launch_bounds__(256) void matvec_kernel(typename F::storage *y, con
         const typename F::elem x = F::load(v + (c << k) + slot);
 #pragma unroll
         for (int r = 0; r < RB; r++)
-            if (r0 + r < nrows) acc[r] = F::add(acc[r], F::mul_boundary(F::load(m + (((r0 + r) * ncols + c) << k) + slot), x));
+            if (r0 + r < nrows) acc[r] = F::add(acc[r], F::mul_boundary_pre(F::load(m + (((r0 + r) * ncols + c) << k) + slot), x));
+        if (Lazy<F>::value && (c & 3) == 3) {  // lazy fields: the uncarried sum is pulled back in every four terms
+#pragma unroll
+            for (int r = 0; r < RB; r++) acc[r] = Lazy<F>::weak(acc[r]);
+        }
     }
 #pragma unroll
     for (int r = 0; r < RB; r++)
-        if (r0 + r < nrows) F::store(y + ((r0 + r) << k) + slot, acc[r]);
+        if (r0 + r < nrows) F::store(y + ((r0 + r) << k) + slot, F::boundary_post(acc[r]));  // sum of pre(), one post()
 }
 
 // y[r] = sum over the stored entries (val, col) of row r of val * v[col]: SparseMatrix<RqNTT>::checked_mul_vec
@@ -256,6 +260,7 @@ __global__ __launch_bounds__(256) void spmv_kernel(typename F::storage *y, const
     const size_t r = blockIdx.x / chunks;
     if (slot >= d) return;
     typename F::elem acc = F::zero();
+    int since = 0;
     const uint64_t j1 = row_ptr[r + 1];
     for (uint64_t j = row_ptr[r]; j < j1; j++) {
         const uint32_t c = cols[j];
@@ -263,9 +268,13 @@ __global__ __launch_bounds__(256) void spmv_kernel(typename F::storage *y, const
             if (slot == 0) atomicAdd(bad, 1ull);
             continue;
         }
-        acc = F::add(acc, F::mul_boundary(F::load(vals + (j << k) + slot), F::load(v + ((size_t)c << k) + slot)));
+        acc = F::add(acc, F::mul_boundary_pre(F::load(vals + (j << k) + slot), F::load(v + ((size_t)c << k) + slot)));
+        if (Lazy<F>::value && ++since == 4) {  // counted per term added: skipped entries must not stretch the interval
+            acc = Lazy<F>::weak(acc);
+            since = 0;
+        }
     }
-    F::store(y + (r << k) + slot, acc);
+    F::store(y + (r << k) + slot, F::boundary_post(acc));
 }
 
 // Y (n x p) = A (n x m) * B (m x p), dense row-major matrices of ring elements in CRT/NTT form:
@@ -295,13 +304,19 @@ __global__ __launch_bounds__(256) void matmul_kernel(typename F::storage *y, con
 #pragma unroll
         for (int r = 0; r < RB; r++)
 #pragma unroll
-            for (int c = 0; c < CB; c++) acc[r][c] = F::add(acc[r][c], F::mul_boundary(av[r], bv[c]));
+            for (int c = 0; c < CB; c++) acc[r][c] = F::add(acc[r][c], F::mul_boundary_pre(av[r], bv[c]));
+        if (Lazy<F>::value && (t & 3) == 3) {
+#pragma unroll
+            for (int r = 0; r < RB; r++)
+#pragma unroll
+                for (int c = 0; c < CB; c++) acc[r][c] = Lazy<F>::weak(acc[r][c]);
+        }
     }
 #pragma unroll
     for (int r = 0; r < RB; r++)
 #pragma unroll
         for (int c = 0; c < CB; c++)
-            if (r0 + r < n && c0 + c < p) F::store(y + (((r0 + r) * p + c0 + c) << k) + slot, acc[r][c]);
+            if (r0 + r < n && c0 + c < p) F::store(y + (((r0 + r) * p + c0 + c) << k) + slot, F::boundary_post(acc[r][c]));
 }
 
 // Cyclotomic::rot (crates/ring/src/traits.rs:54-66): out = X * in for every ring element of the batch.

@@ -222,6 +222,15 @@ struct StarkL {
     // the slot product inside the fused kernel: both operands are data; they are weakly reduced first
     SR_HD static elem mul_data(const elem &a, const elem &b) { return mul_tw(weak_reduce(a), weak_reduce(b)); }
 
+    // Sums of products of memory images (the linear-algebra kernels): pre(a, b) = a b 2^-280 may be summed lazily (a weak
+    // reduction every four terms); post(x) = x 2^24 = mul_tw(x, 2^304 mod p) makes the sum the memory image of sum a_i b_i.
+    SR_HD static elem mul_boundary_pre(const elem &a, const elem &b) { return mul_tw(a, b); }
+    SR_HD static elem boundary_post(const elem &x) {
+        elem c;
+        c.l[0] = 0x1; c.l[1] = 0xe000000; c.l[2] = 0xfffffff; c.l[3] = 0xfffffff; c.l[4] = 0xfffffff;
+        c.l[5] = 0xfffffff; c.l[6] = 0xffffff; c.l[7] = 0x1; c.l[8] = 0x5e00000;
+        return mul_tw(x, c);
+    }
     // table form of a small integer: x * 2^280 mod p = mul_tw(x, 2^560 mod p)
     SR_HD static elem tw_from_u64(uint64_t x) {
         elem e = zero(), r2;

@@ -1077,3 +1077,60 @@ def test_absurd_element_counts_are_refused(torch_cuda):
     assert lib.sr_matvec_ntt(ring._ctx, ptr, ptr, ptr, 1 << 40, 1 << 30) != 0
     assert "too large" in _lib.last_error()
     assert np.array_equal(ring.elementwise_icrt(ring.elementwise_crt(buf.copy())), buf)   # the context is still usable
+
+
+@pytest.mark.parametrize("name,k", [("stark", 3), ("stark", 0), ("babybear", 3), ("goldilocks", 3)])
+def test_long_sums_of_extreme_products(torch_cuda, name, k):
+    """The linear-algebra kernels sum pre(a, b) terms and apply post() once (Stark: uncarried 28-bit limbs, weakly reduced every
+    four terms).  Inner dimension 41 with every entry p - 1, then p - 1 against 1, then random: dense mat-vec, mat-mat and a
+    sparse row whose bad column indices are skipped must all equal the integer sums; SR_STARK_LAZY=0 (8 x 32-bit limbs) agrees."""
+    import os
+
+    from stark_rings_amd import CyclotomicRing
+
+    torch = torch_cuda
+    F, p = O.FIELD_ID[name], P.PRIMES[name][0]
+    ring = ring_for(name, k)
+    d, w, L = ring.degree, ring.words_per_elem, O.LIMBS[F]
+    rinv = pow(pow(2, 64 * L, p), -1, p)
+    nrows, ncols = 5, 41
+    for case in range(3):
+        if case == 0:
+            mi, vi = [p - 1] * (nrows * ncols * d), [p - 1] * (ncols * d)
+        elif case == 1:
+            mi, vi = [p - 1] * (nrows * ncols * d), [1] * (ncols * d)
+        else:
+            mi = O.from_mont(F, O.fill_uniform(F, 0x7A, 0, nrows * ncols * d))
+            vi = O.from_mont(F, O.fill_uniform(F, 0x7B, 0, ncols * d))
+        m, v = O.to_mont(F, mi), O.to_mont(F, vi)
+        want = []
+        for r in range(nrows):
+            for s_ in range(d):
+                want.append(sum(mi[(r * ncols + c) * d + s_] * vi[c * d + s_] for c in range(ncols)) % p)
+        got = ring.matvec_ntt(m, v, nrows, ncols)
+        assert O.from_mont(F, got) == want, case
+        # the same numbers as a (5 x 41) (41 x 1) matrix product
+        assert np.array_equal(ring.matmul_ntt(m, v, nrows, ncols, 1), got)
+        # sparse row 0 = dense row 0 with three out-of-range columns mixed in (skipped and counted on the device)
+        tv = torch.from_numpy(v.view(np.int64)).cuda()
+        cols = list(range(ncols))
+        vals = [m[c * w:(c + 1) * w] for c in range(ncols)]
+        for at in (3, 7, 40):
+            cols.insert(at, ncols + 5)
+            vals.insert(at, m[:w])
+        tvals = torch.from_numpy(np.concatenate(vals).view(np.int64)).cuda()
+        tcols = torch.tensor(cols, dtype=torch.int32, device="cuda")
+        tptr = torch.tensor([0, len(cols)], dtype=torch.int64, device="cuda")
+        ty = torch.empty(w, dtype=torch.int64, device="cuda")
+        ring.spmv_ntt_dev(ty, tvals, tcols, tptr, tv, 1, ncols)
+        assert ring.spmv_bad_index_count() == 3
+        assert np.array_equal(ty.cpu().numpy().view(np.uint64), got[:w])
+        if name == "stark" and k > 0:
+            os.environ["SR_STARK_LAZY"] = "0"
+            try:
+                other = CyclotomicRing("stark", k, device=0)
+                assert np.array_equal(other.matvec_ntt(m, v, nrows, ncols), got)
+                other.close()
+            finally:
+                del os.environ["SR_STARK_LAZY"]
+    assert rinv  # (Montgomery images cancel: products of images are taken by the kernels' own boundary product)
