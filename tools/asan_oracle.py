@@ -45,4 +45,16 @@ for name, w in (("g24", 24), ("bb72", 72), ("frog16", 16)):
     for n in (0, 1, w, 2*w - 1, 2*w):
         src = np.zeros(max(n,1), dtype=np.uint64)
         bind("sro_%s_reduce" % name, None, [u64p, sz, u64p])(ptr(src), n, ptr(o))
+ser = bind("sro_serialize", None, [i, u64p, sz, ctypes.c_void_p])
+des = bind("sro_deserialize", sz, [i, ctypes.c_void_p, sz, u64p])
+wb = bind("sro_wire_bytes", sz, [i])
+for field, limbs in ((0, 1), (1, 1), (2, 4), (3, 1)):
+    n = 37
+    a = np.zeros(n * limbs, dtype=np.uint64); fill(field, 5, 0, n, ptr(a))
+    wire = np.zeros(n * wb(field), dtype=np.uint8)
+    ser(field, ptr(a), n, wire.ctypes.data_as(ctypes.c_void_p))
+    back = np.zeros_like(a)
+    assert des(field, wire.ctypes.data_as(ctypes.c_void_p), n, ptr(back)) == 0 and np.array_equal(back, a)
+    wire[:] = 0xFF
+    assert des(field, wire.ctypes.data_as(ctypes.c_void_p), n, ptr(back)) == n
 print("asan/ubsan run finished")
