@@ -18,6 +18,8 @@
 // words (row lengths, column indices); nullptr = densely packed.  Offsets must be multiples of 8 (of 4 for BabyBear, whose
 // coefficients are 4 bytes on the wire); an element with a misaligned offset is skipped and counted with the invalid coefficients.
 #pragma once
+#include <type_traits>
+
 #include "decompose.hpp"
 #include "fields.hpp"
 
@@ -80,6 +82,17 @@ __global__ __launch_bounds__(256) void serialize_kernel(uint8_t *out, const type
                                                         const uint64_t *offsets, unsigned long long *bad) {
     constexpr size_t W = Codec<F>::W, ALIGN = W < 8 ? W : 8;
     const size_t n = batch * d;
+    if constexpr (std::is_same<F, BabyBear>::value) {
+        if (!offsets && !(n & 1) && !(((uintptr_t)in & 15) | ((uintptr_t)out & 7))) {  // dense BabyBear: two coefficients per lane, 16 B in, 8 B out
+            const uint4 *src = reinterpret_cast<const uint4 *>(in);
+            uint2 *dst = reinterpret_cast<uint2 *>(out);
+            for (size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x; t < n / 2; t += (size_t)gridDim.x * blockDim.x) {
+                const uint4 v = src[t];
+                dst[t] = make_uint2(BabyBear::mul_boundary(v.x, 1u), BabyBear::mul_boundary(v.z, 1u));
+            }
+            return;
+        }
+    }
     for (size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x; t < n; t += (size_t)gridDim.x * blockDim.x) {
         const size_t e = t / d, i = t - e * d;
         const size_t base = offsets ? (size_t)offsets[e] : e * d * W;
@@ -97,6 +110,22 @@ __global__ __launch_bounds__(256) void deserialize_kernel(typename F::storage *o
                                                           const uint64_t *offsets, unsigned long long *bad) {
     constexpr size_t W = Codec<F>::W, ALIGN = W < 8 ? W : 8;
     const size_t n = batch * d;
+    if constexpr (std::is_same<F, BabyBear>::value) {
+        if (!offsets && !(n & 1) && !(((uintptr_t)in & 7) | ((uintptr_t)out & 15))) {  // dense BabyBear: two coefficients per lane, 8 B in, 16 B out
+            const uint2 *src = reinterpret_cast<const uint2 *>(in);
+            uint4 *dst = reinterpret_cast<uint4 *>(out);
+            unsigned long long nbad = 0;
+            for (size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x; t < n / 2; t += (size_t)gridDim.x * blockDim.x) {
+                const uint2 v = src[t];
+                const bool ok0 = v.x < BabyBear::P, ok1 = v.y < BabyBear::P;
+                nbad += !ok0 + !ok1;
+                dst[t] = make_uint4(BabyBear::mul_boundary(ok0 ? v.x : 0u, dec::Consts<BabyBear>::r2()), 0u,
+                                    BabyBear::mul_boundary(ok1 ? v.y : 0u, dec::Consts<BabyBear>::r2()), 0u);
+            }
+            if (nbad) atomicAdd(bad, nbad);
+            return;
+        }
+    }
     for (size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x; t < n; t += (size_t)gridDim.x * blockDim.x) {
         const size_t e = t / d, i = t - e * d;
         const size_t base = offsets ? (size_t)offsets[e] : e * d * W;
