@@ -217,6 +217,62 @@ __global__ void addsub_kernel(typename F::storage *lhs, const typename F::storag
     }
 }
 
+// sum_i a_i b_i on memory images (== sum_i mul_boundary(a_i, b_i)) for the linear-algebra kernels below.
+// Generic form: sum of pre() terms, one post(); lazy fields (Stark) reduce the uncarried sum weakly every four terms.
+template <class F>
+struct SumOfProducts {
+    typename F::elem acc;
+    int since;
+    SR_HD void init() {
+        acc = F::zero();
+        since = 0;
+    }
+    SR_HD void fma(const typename F::elem &a, const typename F::elem &b) {
+        acc = F::add(acc, F::mul_boundary_pre(a, b));
+        if (Lazy<F>::value && ++since == 4) {
+            acc = Lazy<F>::weak(acc);
+            since = 0;
+        }
+    }
+    SR_HD typename F::elem finish() const { return F::boundary_post(acc); }
+};
+// Goldilocks: no reduction inside the sum at all.  With a = a0 + a1 2^32, b = b0 + b1 2^32 the four 64-bit partial products
+// a_i b_j accumulate in four 96-bit integers (a 64-bit sum and a count of its carries: room for 2^32 terms), 12 VALU per term
+// against 30 for mul_boundary + add; finish() reduces each sum once and combines
+//     (S00 + (S01 + S10) 2^32 + S11 2^64) 2^-64 = S00 2^-64 + (S01 + S10) 2^-32 + S11.
+template <>
+struct SumOfProducts<Goldilocks> {
+    uint64_t lo[4];
+    uint32_t hi[4];
+    SR_HD void init() {
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            lo[i] = 0;
+            hi[i] = 0;
+        }
+    }
+    SR_HD void term(int i, uint32_t x, uint32_t y) {
+        const uint64_t t = lo[i] + (uint64_t)x * y;
+        hi[i] += t < lo[i];
+        lo[i] = t;
+    }
+    SR_HD void fma(uint64_t a, uint64_t b) {
+        const uint32_t a0 = (uint32_t)a, a1 = (uint32_t)(a >> 32), b0 = (uint32_t)b, b1 = (uint32_t)(b >> 32);
+        term(0, a0, b0);
+        term(1, a0, b1);
+        term(2, a1, b0);
+        term(3, a1, b1);
+    }
+    SR_HD uint64_t finish() const {
+        using G = Goldilocks;
+        const uint64_t s00 = G::reduce128(lo[0], hi[0]), s01 = G::reduce128(lo[1], hi[1]), s10 = G::reduce128(lo[2], hi[2]),
+                       s11 = G::reduce128(lo[3], hi[3]);
+        const uint64_t inv32 = 0xFFFFFFFE00000002ull;  // 2^-32 mod p = p - (2^32 - 1): 2^32 (2^32 - 1) = 2^64 - 2^32 = -1
+        // x 2^-64 = mul_boundary(x, 1); x 2^-32 = mul(x, 2^-32)
+        return G::add(G::add(G::mul_boundary(s00, 1), G::mul(G::add(s01, s10), inv32)), s11);
+    }
+};
+
 // y[r] = sum_c M[r][c] * v[c] over ring elements in CRT/NTT form of a fully split ring (slot-wise Fp products and sums):
 // Matrix<RqNTT>::checked_mul_vec (crates/linear_algebra/src/matrix.rs:168-178), one fused pass over M.
 // Lane = one slot; a workgroup row-block of RB rows shares each v[c] slot it loads.  M is streamed once (HBM-bound).
@@ -228,22 +284,18 @@ __global__ __launch_bounds__(256) void matvec_kernel(typename F::storage *y, con
     const size_t slot = (blockIdx.x % chunks) * (size_t)blockDim.x + threadIdx.x;
     const size_t r0 = (blockIdx.x / chunks) * RB;
     if (slot >= d) return;
-    typename F::elem acc[RB];
+    SumOfProducts<F> acc[RB];
 #pragma unroll
-    for (int r = 0; r < RB; r++) acc[r] = F::zero();
+    for (int r = 0; r < RB; r++) acc[r].init();
     for (size_t c = 0; c < ncols; c++) {
         const typename F::elem x = F::load(v + (c << k) + slot);
 #pragma unroll
         for (int r = 0; r < RB; r++)
-            if (r0 + r < nrows) acc[r] = F::add(acc[r], F::mul_boundary_pre(F::load(m + (((r0 + r) * ncols + c) << k) + slot), x));
-        if (Lazy<F>::value && (c & 3) == 3) {  // lazy fields: the uncarried sum is pulled back in every four terms
-#pragma unroll
-            for (int r = 0; r < RB; r++) acc[r] = Lazy<F>::weak(acc[r]);
-        }
+            if (r0 + r < nrows) acc[r].fma(F::load(m + (((r0 + r) * ncols + c) << k) + slot), x);
     }
 #pragma unroll
     for (int r = 0; r < RB; r++)
-        if (r0 + r < nrows) F::store(y + ((r0 + r) << k) + slot, F::boundary_post(acc[r]));  // sum of pre(), one post()
+        if (r0 + r < nrows) F::store(y + ((r0 + r) << k) + slot, acc[r].finish());
 }
 
 // y[r] = sum over the stored entries (val, col) of row r of val * v[col]: SparseMatrix<RqNTT>::checked_mul_vec
@@ -259,8 +311,8 @@ __global__ __launch_bounds__(256) void spmv_kernel(typename F::storage *y, const
     const size_t slot = (blockIdx.x % chunks) * (size_t)blockDim.x + threadIdx.x;
     const size_t r = blockIdx.x / chunks;
     if (slot >= d) return;
-    typename F::elem acc = F::zero();
-    int since = 0;
+    SumOfProducts<F> acc;
+    acc.init();
     const uint64_t j1 = row_ptr[r + 1];
     for (uint64_t j = row_ptr[r]; j < j1; j++) {
         const uint32_t c = cols[j];
@@ -268,13 +320,9 @@ __global__ __launch_bounds__(256) void spmv_kernel(typename F::storage *y, const
             if (slot == 0) atomicAdd(bad, 1ull);
             continue;
         }
-        acc = F::add(acc, F::mul_boundary_pre(F::load(vals + (j << k) + slot), F::load(v + ((size_t)c << k) + slot)));
-        if (Lazy<F>::value && ++since == 4) {  // counted per term added: skipped entries must not stretch the interval
-            acc = Lazy<F>::weak(acc);
-            since = 0;
-        }
+        acc.fma(F::load(vals + (j << k) + slot), F::load(v + ((size_t)c << k) + slot));
     }
-    F::store(y + (r << k) + slot, F::boundary_post(acc));
+    F::store(y + (r << k) + slot, acc.finish());
 }
 
 // Y (n x p) = A (n x m) * B (m x p), dense row-major matrices of ring elements in CRT/NTT form:
@@ -290,11 +338,11 @@ __global__ __launch_bounds__(256) void matmul_kernel(typename F::storage *y, con
     const size_t tile = blockIdx.x / chunks;
     const size_t r0 = (tile / cblocks) * RB, c0 = (tile % cblocks) * CB;
     if (slot >= d) return;
-    typename F::elem acc[RB][CB];
+    SumOfProducts<F> acc[RB][CB];
 #pragma unroll
     for (int r = 0; r < RB; r++)
 #pragma unroll
-        for (int c = 0; c < CB; c++) acc[r][c] = F::zero();
+        for (int c = 0; c < CB; c++) acc[r][c].init();
     for (size_t t = 0; t < m; t++) {
         typename F::elem av[RB], bv[CB];
 #pragma unroll
@@ -304,19 +352,13 @@ __global__ __launch_bounds__(256) void matmul_kernel(typename F::storage *y, con
 #pragma unroll
         for (int r = 0; r < RB; r++)
 #pragma unroll
-            for (int c = 0; c < CB; c++) acc[r][c] = F::add(acc[r][c], F::mul_boundary_pre(av[r], bv[c]));
-        if (Lazy<F>::value && (t & 3) == 3) {
-#pragma unroll
-            for (int r = 0; r < RB; r++)
-#pragma unroll
-                for (int c = 0; c < CB; c++) acc[r][c] = Lazy<F>::weak(acc[r][c]);
-        }
+            for (int c = 0; c < CB; c++) acc[r][c].fma(av[r], bv[c]);
     }
 #pragma unroll
     for (int r = 0; r < RB; r++)
 #pragma unroll
         for (int c = 0; c < CB; c++)
-            if (r0 + r < n && c0 + c < p) F::store(y + (((r0 + r) * p + c0 + c) << k) + slot, F::boundary_post(acc[r][c]));
+            if (r0 + r < n && c0 + c < p) F::store(y + (((r0 + r) * p + c0 + c) << k) + slot, acc[r][c].finish());
 }
 
 // Cyclotomic::rot (crates/ring/src/traits.rs:54-66): out = X * in for every ring element of the batch.
