@@ -373,12 +373,20 @@ template <class F>
 int matvec_dev(sr_ctx *c, uint64_t *y, const uint64_t *m, const uint64_t *v, size_t nrows, size_t ncols, hipStream_t st) {
     using S = typename F::storage;
     if (nrows == 0) return SR_OK;
-    constexpr int RB = 4;
-    const size_t blocks = ((c->degree + 255) / 256) * ((nrows + RB - 1) / RB);
+    // RB rows share each v[c] slot a lane loads; small problems (few slots x rows) take a smaller RB so that the grid still
+    // covers the chip: the largest RB that leaves at least four workgroups per CU
+    const size_t chunks = (c->degree + 255) / 256;
+    int rb = 4;
+    while (rb > 1 && chunks * ((nrows + rb - 1) / rb) < 4096) rb >>= 1;
+    const size_t blocks = chunks * ((nrows + rb - 1) / rb);
     if (blocks > 0x7FFFFFFFull) return fail(SR_E_INVALID, "matvec: too many rows for one launch");
     ProfScope ps(c, st, K_OTHER);
-    hipLaunchKernelGGL((sr::matvec_kernel<F, RB>), dim3((unsigned)blocks), dim3(256), 0, st, reinterpret_cast<S *>(y),
-                       reinterpret_cast<const S *>(m), reinterpret_cast<const S *>(v), nrows, ncols, c->k);
+    S *py = reinterpret_cast<S *>(y);
+    const S *pm = reinterpret_cast<const S *>(m), *pv = reinterpret_cast<const S *>(v);
+    const dim3 g((unsigned)blocks), b(256);
+    if (rb == 4) hipLaunchKernelGGL((sr::matvec_kernel<F, 4>), g, b, 0, st, py, pm, pv, nrows, ncols, c->k);
+    else if (rb == 2) hipLaunchKernelGGL((sr::matvec_kernel<F, 2>), g, b, 0, st, py, pm, pv, nrows, ncols, c->k);
+    else hipLaunchKernelGGL((sr::matvec_kernel<F, 1>), g, b, 0, st, py, pm, pv, nrows, ncols, c->k);
     HIP_TRY(hipGetLastError());
     return SR_OK;
 }
