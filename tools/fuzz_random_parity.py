@@ -45,7 +45,7 @@ while time.time() < t_end:
         special = [0, 1, p - 1, p - 2, (p - 1) // 2, (1 << 32) % p, ((1 << 32) - 1) % p, ((1 << 64) - 1) % p]
         vals = [special[int(rng.integers(0, len(special)))] for _ in range(d)]
         a[:d * O.LIMBS[F]] = O.to_mont(F, vals)
-    op = ["crt", "icrt", "mul", "ntt_mul", "add", "sub", "reduce", "decompose", "rot"][int(rng.integers(0, 9))]
+    op = ["crt", "icrt", "mul", "ntt_mul", "add", "sub", "reduce", "decompose", "rot", "matvec", "wire"][int(rng.integers(0, 11))]
     ok = True
     if op == "crt":
         ok = np.array_equal(r.elementwise_crt(a.copy()), O.pow2_fwd(F, a, k, batch, 4)) if batch else True
@@ -79,6 +79,27 @@ while time.time() < t_end:
         ok = (not over) and np.array_equal(got, want) and np.array_equal(r.gadget_recompose(got, basis, pad), a)
     elif op == "rot" and batch and d > 1:
         ok = np.array_equal(r.rot(a.copy()), O.rot(F, a, d, False))
+    elif op == "matvec" and batch:
+        ncols = int(rng.integers(1, 12))
+        nrows = max(1, batch // ncols)
+        m = O.fill_uniform(F, seed + 3, 0, nrows * ncols * d)
+        v = O.fill_uniform(F, seed + 4, 0, ncols * d)
+        L = O.LIMBS[F]
+        got = r.matvec_ntt(m, v, nrows, ncols)
+        ms, vs = O.from_mont(F, m), O.from_mont(F, v)
+        want = [sum(ms[(rr * ncols + c) * d + s_] * vs[c * d + s_] for c in range(ncols)) % p for rr in range(nrows) for s_ in range(d)] \
+            if nrows * ncols * d <= 4096 else None
+        if want is not None:
+            ok = O.from_mont(F, got) == want
+        else:   # larger cases: row 0 against slot products from the oracle
+            acc = [0] * d
+            for c in range(ncols):
+                prod = O.from_mont(F, O.pow2_pointwise(F, m[c * d * L:(c + 1) * d * L], v[c * d * L:(c + 1) * d * L]))
+                acc = [(x + y) % p for x, y in zip(acc, prod)]
+            ok = O.from_mont(F, got[:d * L]) == acc
+    elif op == "wire" and batch:
+        wire = r.serialize(a)
+        ok = np.array_equal(wire, O.serialize(F, a)) and np.array_equal(r.deserialize(wire), a)
     n_checks += 1
     by_op[op] = by_op.get(op, 0) + 1
     if not ok:
