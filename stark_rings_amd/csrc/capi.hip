@@ -408,7 +408,19 @@ template <class F>
 int matmul_dev(sr_ctx *c, uint64_t *y, const uint64_t *a, const uint64_t *b, size_t n, size_t m, size_t p, hipStream_t st) {
     using S = typename F::storage;
     if (n == 0 || p == 0) return SR_OK;
-    constexpr int RB = 4, CB = 2;
+    // register block of outputs per lane: RB + CB operand loads feed RB * CB multiply-adds.  BabyBear's accumulators are one
+    // register each (8 x 4); Goldilocks' 96-bit sums and Stark's nine limbs cost 12 and 10 (4 x 2).
+#ifndef SR_MM_BB_RB
+#define SR_MM_BB_RB 8
+#define SR_MM_BB_CB 4
+#endif
+    constexpr bool bb = std::is_same<F, sr::BabyBear>::value;
+#ifndef SR_MM_GL_RB
+#define SR_MM_GL_RB 4
+#define SR_MM_GL_CB 2
+#endif
+    constexpr bool gl = std::is_same<F, sr::Goldilocks>::value;
+    constexpr int RB = bb ? SR_MM_BB_RB : (gl ? SR_MM_GL_RB : 4), CB = bb ? SR_MM_BB_CB : (gl ? SR_MM_GL_CB : 2);
     const size_t blocks = ((c->degree + 255) / 256) * ((n + RB - 1) / RB) * ((p + CB - 1) / CB);
     if (blocks > 0x7FFFFFFFull) return fail(SR_E_INVALID, "matmul: too many rows or columns for one launch");
     ProfScope ps(c, st, K_OTHER);
