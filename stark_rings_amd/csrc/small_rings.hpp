@@ -280,10 +280,11 @@ __device__ __forceinline__ void small_block_store(typename F::elem *lds, uint64_
 
 // STAGED: through LDS as above; otherwise each lane reads and writes its own element directly.  Which one wins was
 // measured per ring and operation over 2^22 elements (tools/bench_small_rings.py): staging gains 25-70 % everywhere
-// except Goldilocks-24 ICRT (-4 %) and its fused ring product (-14 %, 96 data VGPRs plus the exchanges), which stay direct.
+// except Goldilocks-24's fused ring product (-13 %, 96 data VGPRs plus the exchanges), which stays direct (its ICRT was direct
+// too until the block went through LDS in two rounds: staged 4.0 TB/s, direct 3.6-3.8).
 template <class F, int D, int W, int OP>
 constexpr bool small_staged() {
-    return !(D == 24 && (OP == SOP_ICRT || OP == SOP_RINGMUL));
+    return !(D == 24 && OP == SOP_RINGMUL);
 }
 template <class F, int D, bool STAGED>
 __device__ __forceinline__ void small_get(typename F::elem *lds, const uint64_t *src, size_t first, size_t batch,
