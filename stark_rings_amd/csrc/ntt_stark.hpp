@@ -158,7 +158,8 @@ __global__ __launch_bounds__(256, 2) void cols_kernel(S *data, size_t batch, int
 // Pass q = 0 .. LOGT/2 - 1 runs stages 2q, 2q + 1 of the tile on the register layout
 //     e = ((t >> ls) << (ls + 2)) + (j << ls) + (t & (2^ls - 1)),   ls = LOGT - 2q - 2      (legs 2^ls apart, block t >> ls)
 // and an odd LOGT ends with the single stage of half 1 on e = 4 t + j (blocks 2 t, 2 t + 1).  Pass 0's twiddles are uniform.
-// LDS: limb-major rows, pad(e) = e + PM (e >> 5): conflict-free or two-way for every layout (PM = 5 at LOGT = 9, else 3).
+// LDS: limb-major rows, pad(e) = e + PM (e >> 5): conflict-free or two-way for every layout (PM = 5 at LOGT = 9, else 3;
+// tools/stark_lds_padding_search.py).
 // TPW tiles share a workgroup (and an LDS row) when a tile has fewer than 128 lanes: D = 16 .. 256, 256 lanes per workgroup;
 // pad() is additive over tile bases (multiples of 16), so a tile addresses its slice through an offset pointer.
 template <int LOGT, int TPW = 1>
