@@ -76,6 +76,7 @@ struct sr_ctx {
     size_t table_bytes = 0;
     // inverse stage-0 constants (table form): plain inverse, and fused ring-mul (with boundary correction)
     unsigned char inv_scale0[40], inv_scale1[40], mul_scale0[40], mul_scale1[40];
+    bool stark_one_tile = false;  // the ring element is one tile of st::tile_kernel (D <= 2048 unless SR_ST_WHOLE_MAX says otherwise)
     bool stark_tuned = false;  // and k >= 4: the register-tiled kernels of ntt_stark.hpp (SR_STARK_TUNED=0: generic kernels on StarkL)
     bool stark_lazy = false;  // Stark rings: transforms run on StarkL (nine 28-bit limbs, lazy carries; stark_lazy.hpp)
     // staging for host-pointer entry points
@@ -577,9 +578,9 @@ int st_fwd(sr_ctx *c, uint64_t *d, size_t batch, hipStream_t st) {
     auto p = make_params<sr::StarkL>(c, false);
     auto *a = reinterpret_cast<sr::U256Storage *>(d);
     auto hook = [&](bool begin) { begin ? gl_prof_begin(c, 0, st) : gl_prof_end(c, st); };
-    if (sr::st::fwd_cols(a, batch, p, st, hook)) return fail(SR_E_HIP, "stark strided launch failed");
+    if (sr::st::fwd_cols(a, batch, p, c->stark_one_tile, st, hook)) return fail(SR_E_HIP, "stark strided launch failed");
     ProfScope ps(c, st, K_ROWS);
-    if (sr::st::launch_rows<sr::MODE_FWD>(a, nullptr, a, batch, p, st)) return fail(SR_E_HIP, "stark rows launch failed");
+    if (sr::st::launch_rows<sr::MODE_FWD>(a, nullptr, a, batch, p, c->stark_one_tile, st)) return fail(SR_E_HIP, "stark rows launch failed");
     return SR_OK;
 }
 int st_inv(sr_ctx *c, uint64_t *d, size_t batch, hipStream_t st) {
@@ -588,10 +589,10 @@ int st_inv(sr_ctx *c, uint64_t *d, size_t batch, hipStream_t st) {
     auto *a = reinterpret_cast<sr::U256Storage *>(d);
     {
         ProfScope ps(c, st, K_ROWS);
-        if (sr::st::launch_rows<sr::MODE_INV>(a, nullptr, a, batch, p, st)) return fail(SR_E_HIP, "stark rows launch failed");
+        if (sr::st::launch_rows<sr::MODE_INV>(a, nullptr, a, batch, p, c->stark_one_tile, st)) return fail(SR_E_HIP, "stark rows launch failed");
     }
     auto hook = [&](bool begin) { begin ? gl_prof_begin(c, 2, st) : gl_prof_end(c, st); };
-    if (sr::st::inv_cols(a, batch, p, st, hook)) return fail(SR_E_HIP, "stark strided launch failed");
+    if (sr::st::inv_cols(a, batch, p, c->stark_one_tile, st, hook)) return fail(SR_E_HIP, "stark strided launch failed");
     return SR_OK;
 }
 int st_ring_mul(sr_ctx *c, uint64_t *out, const uint64_t *a, uint64_t *b, size_t batch, hipStream_t st) {
@@ -599,20 +600,20 @@ int st_ring_mul(sr_ctx *c, uint64_t *out, const uint64_t *a, uint64_t *b, size_t
     using S = sr::U256Storage;
     auto p = make_params<sr::StarkL>(c, true);
     S *o = reinterpret_cast<S *>(out), *pb = reinterpret_cast<S *>(b);
-    const bool strided = !sr::st::whole(c->k);
+    const bool strided = !c->stark_one_tile;
     if (strided) {  // strided stages of both operands first; a's go to out so that a stays intact
         if (out != a) HIP_TRY(hipMemcpyAsync(out, a, (batch << c->k) * sizeof(S), hipMemcpyDeviceToDevice, st));
         auto hook = [&](bool begin) { begin ? gl_prof_begin(c, 0, st) : gl_prof_end(c, st); };
-        if (sr::st::fwd_cols(o, batch, p, st, hook)) return fail(SR_E_HIP, "stark strided launch failed");
-        if (sr::st::fwd_cols(pb, batch, p, st, hook)) return fail(SR_E_HIP, "stark strided launch failed");
+        if (sr::st::fwd_cols(o, batch, p, false, st, hook)) return fail(SR_E_HIP, "stark strided launch failed");
+        if (sr::st::fwd_cols(pb, batch, p, false, st, hook)) return fail(SR_E_HIP, "stark strided launch failed");
     }
     {
         ProfScope ps(c, st, K_ROWS);
         const S *src = strided ? o : reinterpret_cast<const S *>(a);
-        if (sr::st::launch_rows<sr::MODE_MUL>(const_cast<S *>(src), pb, o, batch, p, st)) return fail(SR_E_HIP, "stark rows launch failed");
+        if (sr::st::launch_rows<sr::MODE_MUL>(const_cast<S *>(src), pb, o, batch, p, c->stark_one_tile, st)) return fail(SR_E_HIP, "stark rows launch failed");
     }
     auto hook = [&](bool begin) { begin ? gl_prof_begin(c, 2, st) : gl_prof_end(c, st); };
-    if (sr::st::inv_cols(o, batch, p, st, hook)) return fail(SR_E_HIP, "stark strided launch failed");
+    if (sr::st::inv_cols(o, batch, p, c->stark_one_tile, st, hook)) return fail(SR_E_HIP, "stark strided launch failed");
     return SR_OK;
 }
 
@@ -891,6 +892,7 @@ int sr_ctx_create(int ring, int log2_degree, int device, sr_ctx **out) {
                 c->stark_lazy = !(env && env[0] == '0') && log2_degree >= 1;
                 const char *tuned = getenv("SR_STARK_TUNED");
                 c->stark_tuned = c->stark_lazy && !(tuned && tuned[0] == '0') && sr::st::supported(log2_degree);
+                c->stark_one_tile = sr::st::whole(log2_degree, sr::st::whole_max());
                 rc = c->stark_lazy ? init_pow2<sr::StarkL>(c) : init_pow2<sr::Stark>(c);
                 break;
             }

@@ -304,13 +304,13 @@ inline bool supported(int k) { return k >= kMinLog && k <= 20; }
 // 512 <= D <= 4096: the tile kernel takes the whole transform; above, the last nine stages after the strided passes
 // Largest log2 D taken as one tile.  Measured over 2^24 coefficients (ring product, ms): D = 1024 one tile 1.96 / strided + 512-tiles
 // 2.48; D = 2048 2.22 / 2.46; D = 4096 2.86 / 2.57 (1024 lanes and 157 KB of LDS leave one workgroup per CU and every transpose
-// stalls all sixteen waves).  SR_ST_WHOLE_MAX overrides (9..12; read per call so that tests can switch it).
+// stalls all sixteen waves).  SR_ST_WHOLE_MAX overrides (9..12); the context reads it once, when it is created.
 inline int whole_max() {
     const char *e = getenv("SR_ST_WHOLE_MAX");
     const int x = e ? atoi(e) : 11;
     return x < 9 ? 9 : (x > 12 ? 12 : x);
 }
-inline bool whole(int k) { return k >= kMinLog && k <= whole_max(); }
+inline bool whole(int k, int wmax) { return k >= kMinLog && k <= wmax; }
 
 template <int DIR>
 inline int launch_cols(S *d, size_t batch, int s0, int m, const P &p, hipStream_t st) {
@@ -333,8 +333,8 @@ inline int launch_cols(S *d, size_t batch, int s0, int m, const P &p, hipStream_
 }
 // the strided stages 0 .. k-10 as passes of (c mod 3), 3, 3, ... stages; begin / end bracket each launch for the profiler
 template <class Hook>
-inline int fwd_cols(S *d, size_t batch, const P &p, hipStream_t st, Hook &&hook) {
-    int c = whole(p.k) ? 0 : p.k - kTileLog, s0 = 0;
+inline int fwd_cols(S *d, size_t batch, const P &p, bool one_tile, hipStream_t st, Hook &&hook) {
+    int c = one_tile ? 0 : p.k - kTileLog, s0 = 0;
     while (c > 0) {
         const int m = c % 3 ? c % 3 : 3;
         hook(true);
@@ -347,8 +347,8 @@ inline int fwd_cols(S *d, size_t batch, const P &p, hipStream_t st, Hook &&hook)
     return 0;
 }
 template <class Hook>
-inline int inv_cols(S *d, size_t batch, const P &p, hipStream_t st, Hook &&hook) {
-    const int c = whole(p.k) ? 0 : p.k - kTileLog;
+inline int inv_cols(S *d, size_t batch, const P &p, bool one_tile, hipStream_t st, Hook &&hook) {
+    const int c = one_tile ? 0 : p.k - kTileLog;
     int s_hi = c;  // stages [0, s_hi) remain
     // mirror of fwd_cols: its passes were (c mod 3 or 3), 3, 3, ...; undo them last to first
     while (s_hi > 0) {
@@ -383,11 +383,11 @@ inline int launch_tile(S *a, const S *b, S *out, size_t tiles, const P &p, hipSt
     return hipGetLastError() != hipSuccess;
 }
 template <int MODE>
-inline int launch_rows(S *a, const S *b, S *out, size_t batch, const P &p, hipStream_t st) {
-    const int logt = whole(p.k) ? p.k : kTileLog;
+inline int launch_rows(S *a, const S *b, S *out, size_t batch, const P &p, bool one_tile, hipStream_t st) {
+    const int logt = one_tile ? p.k : kTileLog;
     const size_t tiles = batch << (p.k - logt);
     if (tiles > 0x7FFFFFFFull) return 1;
-    if (!whole(p.k)) return launch_tile<9, MODE, false>(a, b, out, tiles, p, st);
+    if (!one_tile) return launch_tile<9, MODE, false>(a, b, out, tiles, p, st);
     switch (p.k) {
         case 4: return launch_tile<4, MODE, true>(a, b, out, tiles, p, st);
         case 5: return launch_tile<5, MODE, true>(a, b, out, tiles, p, st);
