@@ -62,6 +62,52 @@ struct Goldilocks {
         bool fix = (s < a) | (s >= P);
         return fix ? s + EPS : s;
     }
+#elif defined(__HIP_DEVICE_COMPILE__) && !defined(SR_GL_NO_EXECMASK)
+    // Round-2 form, 4 VALU (3 for sub): the conditional correction is ONE v_lshl_add_u64 executed under an EXEC mask made from
+    // the carry (s_and / s_andn1_saveexec ... s_mov exec: SALU work, which the scalar unit issues beside the other waves' VALU)
+    // instead of a second carry chain plus two v_cndmask.  t = a + EPS cannot overflow for canonical a; the carry of t + b says
+    // a + b >= p (then t + b - 2^64 = a + b - p is the answer), and the other lanes take the EPS back (+ p mod 2^64).
+    // s_nop 1: the two wait states gfx950 wants between a VALU write of an SGPR carry and the VALU read of it.
+    static __device__ __forceinline__ elem add(elem a, elem b) {
+        uint64_t t, c, sv;
+        uint32_t r0, r1;
+        asm("v_lshl_add_u64 %0, %1, 0, %2" : "=v"(t) : "v"(a), "s"((uint64_t)EPS));
+        asm("v_add_co_u32_e64 %0, %2, %3, %5\n\t"
+            "s_nop 1\n\t"
+            "v_addc_co_u32_e64 %1, %2, %4, %6, %2"
+            : "=&v"(r0), "=&v"(r1), "=&s"(c)
+            : "v"((uint32_t)t), "v"((uint32_t)(t >> 32)), "v"((uint32_t)b), "v"((uint32_t)(b >> 32)));
+        uint64_t r = (uint64_t)r0 | ((uint64_t)r1 << 32);
+        asm("s_andn1_saveexec_b64 %1, %2\n\t"
+            "v_lshl_add_u64 %0, %0, 0, %3\n\t"
+            "s_mov_b64 exec, %1"
+            : "+v"(r), "=&s"(sv)
+            : "s"(c), "s"((uint64_t)P)
+            : "scc");
+        return r;
+    }
+#elif defined(__HIP_DEVICE_COMPILE__) && !defined(SR_ADD6)
+    // 5 VALU: s = a + b on a carry chain, then u = s + EPS (= s - p mod 2^64) as ONE v_mad_u64_u32 (1 * 0xFFFFFFFF + s) whose
+    // carry-out says s >= p; either carry selects u.  (The C++ form below spends an add_co / addc_co pair on u: 6 VALU.)
+    // s_nop 1: the two wait states gfx950 wants between a VALU write of an SGPR carry and the VALU read of it.
+    static __device__ __forceinline__ elem add(elem a, elem b) {
+        uint32_t s0, s1, r0, r1;
+        uint64_t c1, c2, u;
+        asm("v_add_co_u32_e64 %0, %2, %3, %5\n\t"
+            "s_nop 1\n\t"
+            "v_addc_co_u32_e64 %1, %2, %4, %6, %2"
+            : "=&v"(s0), "=&v"(s1), "=&s"(c1)
+            : "v"((uint32_t)a), "v"((uint32_t)(a >> 32)), "v"((uint32_t)b), "v"((uint32_t)(b >> 32)));
+        const uint64_t s = (uint64_t)s0 | ((uint64_t)s1 << 32);
+        asm("v_mad_u64_u32 %0, %1, 1, -1, %2" : "=v"(u), "=s"(c2) : "v"(s));
+        asm("s_or_b64 %2, %2, %7\n\t"
+            "v_cndmask_b32_e64 %0, %3, %5, %2\n\t"
+            "v_cndmask_b32_e64 %1, %4, %6, %2"
+            : "=&v"(r0), "=&v"(r1), "+s"(c2)
+            : "v"(s0), "v"(s1), "v"((uint32_t)u), "v"((uint32_t)(u >> 32)), "s"(c1)
+            : "scc");
+        return (uint64_t)r0 | ((uint64_t)r1 << 32);
+    }
 #else
     SR_HD static elem add(elem a, elem b) {
         uint32_t c, c1, c2;
@@ -79,6 +125,25 @@ struct Goldilocks {
     SR_HD static elem sub(elem a, elem b) {
         uint64_t d = a - b;
         return (a < b) ? d - EPS : d;
+    }
+#elif defined(__HIP_DEVICE_COMPILE__) && !defined(SR_GL_NO_EXECMASK)
+    // 3 VALU: borrow chain, then + p on the lanes that borrowed (EXEC-masked v_lshl_add_u64, see add)
+    static __device__ __forceinline__ elem sub(elem a, elem b) {
+        uint64_t c, sv;
+        uint32_t r0, r1;
+        asm("v_sub_co_u32_e64 %0, %2, %3, %5\n\t"
+            "s_nop 1\n\t"
+            "v_subb_co_u32_e64 %1, %2, %4, %6, %2"
+            : "=&v"(r0), "=&v"(r1), "=&s"(c)
+            : "v"((uint32_t)a), "v"((uint32_t)(a >> 32)), "v"((uint32_t)b), "v"((uint32_t)(b >> 32)));
+        uint64_t r = (uint64_t)r0 | ((uint64_t)r1 << 32);
+        asm("s_and_saveexec_b64 %1, %2\n\t"
+            "v_lshl_add_u64 %0, %0, 0, %3\n\t"
+            "s_mov_b64 exec, %1"
+            : "+v"(r), "=&s"(sv)
+            : "s"(c), "s"((uint64_t)P)
+            : "scc");
+        return r;
     }
 #else
     SR_HD static elem sub(elem a, elem b) {
@@ -107,6 +172,41 @@ struct Goldilocks {
     }
 #else
 #if defined(__HIP_DEVICE_COMPILE__)
+#if !defined(SR_GL_NO_EXECMASK)
+    // a - b for any u64 a and b < 2^32 (+ p on borrow): 3 VALU (see sub)
+    static __device__ __forceinline__ uint64_t sub_small(uint64_t a, uint32_t b) {
+        uint64_t c, sv;
+        uint32_t r0, r1;
+        asm("v_sub_co_u32_e64 %0, %2, %3, %5\n\t"
+            "s_nop 1\n\t"
+            "v_subb_co_u32_e64 %1, %2, %4, 0, %2"
+            : "=&v"(r0), "=&v"(r1), "=&s"(c)
+            : "v"((uint32_t)a), "v"((uint32_t)(a >> 32)), "v"(b));
+        uint64_t r = (uint64_t)r0 | ((uint64_t)r1 << 32);
+        asm("s_and_saveexec_b64 %1, %2\n\t"
+            "v_lshl_add_u64 %0, %0, 0, %3\n\t"
+            "s_mov_b64 exec, %1"
+            : "+v"(r), "=&s"(sv)
+            : "s"(c), "s"((uint64_t)P)
+            : "scc");
+        return r;
+    }
+    // canonical (l2 + hl * EPS) for l2 + hl * EPS < 2^64 + p: 3 VALU.  v_mad_u64_u32 delivers the 65th bit as its carry-out;
+    // that bit or t >= p (one 64-bit compare against p in an SGPR pair) selects the lanes that take + EPS = - p (mod 2^64).
+    static __device__ __forceinline__ elem mad_eps_fix(uint64_t l2, uint32_t hl) {
+        uint64_t t, cy, c2, sv;
+        asm("v_mad_u64_u32 %0, %1, %2, -1, %3" : "=v"(t), "=s"(cy) : "v"(hl), "v"(l2));
+        asm("v_cmp_le_u64_e64 %0, %1, %2" : "=s"(c2) : "s"((uint64_t)P), "v"(t));
+        asm("s_or_b64 %1, %2, %3\n\t"
+            "s_and_saveexec_b64 %1, %1\n\t"
+            "v_lshl_add_u64 %0, %0, 0, %4\n\t"
+            "s_mov_b64 exec, %1"
+            : "+v"(t), "=&s"(sv)
+            : "s"(c2), "s"(cy), "s"((uint64_t)EPS)
+            : "scc");
+        return t;
+    }
+#else
     // a - b for any u64 a and b < 2^32 (+ p on borrow).  The high word of b is an opaque zero register: with a literal 0 the
     // combiner rewrites subcarry(x, 0, c) as x - zext(c) and spends a v_cndmask on materialising c.
     static __device__ __forceinline__ uint64_t sub_small(uint64_t a, uint32_t b) {
@@ -136,7 +236,7 @@ struct Goldilocks {
         bool fix = c1 | (c2 != 0);
         return (uint64_t)(fix ? u0 : t0) | ((uint64_t)(fix ? u1 : t1) << 32);
     }
-#else
+#elif defined(SR_FIX5)  // round-1 form: the conditional + EPS on an add_co / addc_co pair (1 + 4 VALU)
     static __device__ __forceinline__ elem mad_eps_fix(uint64_t l2, uint32_t hl) {
         uint64_t t, cy, tmp;
         uint32_t r0, r1;
@@ -154,7 +254,24 @@ struct Goldilocks {
                        // s_add_u32 / s_addc_u32 address pair, corrupting the carry (a +2^32 address fault)
         return (uint64_t)r0 | ((uint64_t)r1 << 32);
     }
+#else
+    // 1 + 3 VALU: the conditional + EPS is a second v_mad_u64_u32 (1 * 0xFFFFFFFF + t) whose carry-out says t >= p
+    static __device__ __forceinline__ elem mad_eps_fix(uint64_t l2, uint32_t hl) {
+        uint64_t t, u, cy, c2;
+        uint32_t r0, r1;
+        asm("v_mad_u64_u32 %0, %1, %2, -1, %3" : "=v"(t), "=s"(cy) : "v"(hl), "v"(l2));
+        asm("v_mad_u64_u32 %0, %1, 1, -1, %2" : "=v"(u), "=s"(c2) : "v"(t));  // u = t + EPS = t - p (mod 2^64); carry <=> t >= p
+        asm("s_or_b64 %2, %2, %7\n\t"               // or the multiply-add overflowed (then u < p)
+            "v_cndmask_b32_e64 %0, %3, %5, %2\n\t"
+            "v_cndmask_b32_e64 %1, %4, %6, %2"
+            : "=&v"(r0), "=&v"(r1), "+s"(c2)
+            : "v"((uint32_t)t), "v"((uint32_t)(t >> 32)), "v"((uint32_t)u), "v"((uint32_t)(u >> 32)), "s"(cy)
+            : "scc");  // s_or_b64 writes SCC: without the clobber the scheduler may (and did) drop this statement between an
+                       // s_add_u32 / s_addc_u32 address pair, corrupting the carry (a +2^32 address fault)
+        return (uint64_t)r0 | ((uint64_t)r1 << 32);
+    }
 #endif
+#endif  // SR_GL_NO_EXECMASK
     static __device__ __forceinline__ elem reduce128(uint64_t lo, uint64_t hi) {
         return mad_eps_fix(sub_small(lo, (uint32_t)(hi >> 32)), (uint32_t)hi);
     }
