@@ -54,9 +54,10 @@ namespace stark_rings {
 
 class CyclotomicConfig {
 public:
-    CyclotomicConfig(sr_ring ring, int log2_degree = 0, int device = 0) : ring_(ring) {
+    // plan: the kernel plan of the context (sr_plan), nullptr = defaults; fixed for the life of the context
+    CyclotomicConfig(sr_ring ring, int log2_degree = 0, int device = 0, const sr_plan *plan = nullptr) : ring_(ring) {
         sr_ctx *c = nullptr;
-        check(sr_ctx_create(ring, log2_degree, device, &c), "sr_ctx_create");
+        check(sr_ctx_create_ex(ring, log2_degree, device, plan, &c), "sr_ctx_create_ex");
         ctx_.reset(c, [](sr_ctx *p) { sr_ctx_destroy(p); });
         check(sr_ctx_degree(c, &degree_), "sr_ctx_degree");
         check(sr_ctx_limbs(c, &limbs_), "sr_ctx_limbs");

@@ -70,6 +70,34 @@ typedef struct sr_ctx sr_ctx;
  * Device-pointer calls on different streams of one context may overlap on the GPU; the context orders its own shared scratch
  * between streams with an event.  Contexts are independent of each other. */
 int sr_ctx_create(int ring, int log2_degree, int device, sr_ctx **out);
+/* The same with an explicit kernel plan, fixed for the life of the context (the library itself reads no environment
+ * variable: a getenv racing a setenv in another thread of a Send + Sync host would be a data race).  plan == NULL or an
+ * all-zero plan = the measured-fastest defaults, i.e. sr_ctx_create.  The alternative plans compute the same function bit
+ * for bit and exist for differential tests and A/B measurements (tests/test_gpu_parity.py, README.md). */
+enum sr_plan_flags {
+    SR_PLAN_GENERIC_KERNELS = 1u << 0,  /* field-generic radix-2 LDS kernels instead of the tuned / register-tiled paths        */
+    SR_PLAN_GL_NO_COLS256 = 1u << 1,    /* Goldilocks 2^16 <= D <= 2^20: strided register passes + 4096-point rows              */
+    SR_PLAN_RT_NO_COLS256 = 1u << 2,    /* register-tiled path (BabyBear): 4-stage column passes + 12-stage rows                */
+    SR_PLAN_GL_REGTILE = 1u << 3,       /* Goldilocks on the register-tiled path (cross-check of ntt_regtile.hpp)               */
+    SR_PLAN_STARK_NO_LAZY = 1u << 4,    /* Stark transforms and sums on 8 x 32-bit limbs instead of nine 28-bit lazy limbs       */
+    SR_PLAN_STARK_GENERIC_ON_LAZY = 1u << 5 /* Stark: generic LDS kernels on the lazy limbs instead of ntt_stark.hpp             */
+};
+typedef struct sr_plan {
+    uint32_t flags;               /* OR of sr_plan_flags                                                                       */
+    int32_t log_tile;             /* 0 = default; 8..12: LDS tile of the generic kernels                                       */
+    int32_t stark_whole_max;      /* 0 = default (11); 9..12: largest log2 D the Stark kernels keep as one tile per element    */
+    uint32_t chunk_polys;         /* fused ring products above one tile: ring elements per chunk of launches (0 = as many as the
+                                     operand scratch holds)                                                                    */
+    uint64_t scratch_limit_bytes; /* cap of the operand scratch (0 = default 16 GiB); larger batches run in chunks             */
+    uint32_t host_chunk_mb;       /* chunk of the host-pointer pipeline in MiB (0 = default 128)                               */
+    uint32_t reserved;
+} sr_plan;
+int sr_ctx_create_ex(int ring, int log2_degree, int device, const sr_plan *plan, sr_ctx **out);
+/* Pre-sizes the context's operand scratch for fused ring products of up to `batch` elements (capped by the plan's
+ * scratch_limit_bytes).  Device entry points are asynchronous, with ONE exception: a ring product above one LDS tile whose
+ * scratch has to grow first blocks (hipDeviceSynchronize + hipFree + hipMalloc) -- call this once after creating the context
+ * (or accept that the first product of a new size blocks) and no _dev call blocks afterwards. */
+int sr_ctx_reserve_scratch(sr_ctx *ctx, size_t batch);
 int sr_ctx_destroy(sr_ctx *ctx);
 /* D, u64 limbs per coefficient, u64 words per ring element */
 int sr_ctx_degree(const sr_ctx *ctx, size_t *degree);
@@ -168,8 +196,15 @@ int sr_deserialize_batch_dev(sr_ctx *ctx, uint64_t *d_out, const uint8_t *d_wire
 int sr_wire_invalid_count(sr_ctx *ctx, unsigned long long *out, void *stream);
 int sr_serialize_batch(sr_ctx *ctx, uint8_t *wire, const uint64_t *in, size_t batch);
 int sr_deserialize_batch(sr_ctx *ctx, uint64_t *out, const uint8_t *wire, size_t batch);
-/* d_b is used as scratch and holds crt(b) afterwards when D exceeds one LDS tile; d_out may alias d_a. */
-int sr_ring_mul_batch_dev(sr_ctx *ctx, uint64_t *d_out, const uint64_t *d_a, uint64_t *d_b, size_t batch, void *stream);
+/* RqPoly * &RqPoly (coeff_form.rs:250-258): d_a and d_b are only read -- the reference never mutates an operand, so one b can
+ * be multiplied into many a.  d_out may alias d_a; d_b must not alias d_out.  Above one LDS tile the column stages of b go
+ * through the context's operand scratch (sr_ctx_reserve_scratch). */
+int sr_ring_mul_batch_dev(sr_ctx *ctx, uint64_t *d_out, const uint64_t *d_a, const uint64_t *d_b, size_t batch, void *stream);
+/* The constant-operand case: d_b_ntt already holds crt(b) (sr_ntt_fwd_batch_dev), e.g. the rows of a commitment matrix that
+ * stay in NTT form (matrix.rs:168-178) while fresh coefficient-form elements arrive: d_out = icrt(crt(d_a) (.) d_b_ntt),
+ * one of the three transforms saved.  Every ring id (rings without a fused kernel run forward transform, slot product and
+ * inverse transform one after the other on d_out).  d_out may alias d_a; d_b_ntt is only read and must not alias d_out. */
+int sr_ring_mul_ntt_rhs_batch_dev(sr_ctx *ctx, uint64_t *d_out, const uint64_t *d_a, const uint64_t *d_b_ntt, size_t batch, void *stream);
 int sr_reduce_batch_dev(sr_ctx *ctx, const uint64_t *d_in, size_t in_len_per_elem, uint64_t *d_out, size_t batch, void *stream);
 /* Synthetic coefficients, uniform in [0,p), counter-based (same definition as the oracle's
  * sro_fill_uniform): fills n_coeffs coefficients starting at flat coefficient index first_coeff. */

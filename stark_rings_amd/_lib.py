@@ -15,6 +15,8 @@ _c = ctypes
 # every symbol include/stark_rings_hip.h declares: name -> (restype, argtypes)
 SYMBOLS = {
     "sr_ctx_create": (_c.c_int, [_c.c_int, _c.c_int, _c.c_int, _c.POINTER(_c.c_void_p)]),
+    "sr_ctx_create_ex": (_c.c_int, [_c.c_int, _c.c_int, _c.c_int, _c.c_void_p, _c.POINTER(_c.c_void_p)]),
+    "sr_ctx_reserve_scratch": (_c.c_int, [_c.c_void_p, _c.c_size_t]),
     "sr_ctx_destroy": (_c.c_int, [_c.c_void_p]),
     "sr_ctx_degree": (_c.c_int, [_c.c_void_p, _c.POINTER(_c.c_size_t)]),
     "sr_ctx_limbs": (_c.c_int, [_c.c_void_p, _c.POINTER(_c.c_int)]),
@@ -53,6 +55,7 @@ SYMBOLS = {
     "sr_rot_batch_dev": (_c.c_int, [_c.c_void_p] * 3 + [_c.c_size_t, _c.c_void_p]),
     "sr_rot_batch": (_c.c_int, [_c.c_void_p, u64p, _c.c_size_t]),
     "sr_ring_mul_batch_dev": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_size_t, _c.c_void_p]),
+    "sr_ring_mul_ntt_rhs_batch_dev": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_size_t, _c.c_void_p]),
     "sr_reduce_batch_dev": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_size_t, _c.c_void_p, _c.c_size_t, _c.c_void_p]),
     "sr_fill_uniform_dev": (_c.c_int, [_c.c_void_p, _c.c_uint64, _c.c_uint64, _c.c_size_t, _c.c_void_p, _c.c_void_p]),
     "sr_count_noncanonical_dev": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_size_t, _c.POINTER(_c.c_uint64), _c.c_void_p]),
@@ -62,6 +65,45 @@ SYMBOLS = {
     "sr_last_error_string": (_c.c_char_p, []),
     "sr_version": (_c.c_char_p, []),
 }
+
+
+
+class Plan(ctypes.Structure):
+    """sr_plan of include/stark_rings_hip.h: the kernel plan of a context, fixed when it is created."""
+    _fields_ = [("flags", _c.c_uint32), ("log_tile", _c.c_int32), ("stark_whole_max", _c.c_int32), ("chunk_polys", _c.c_uint32),
+                ("scratch_limit_bytes", _c.c_uint64), ("host_chunk_mb", _c.c_uint32), ("reserved", _c.c_uint32)]
+
+
+PLAN_GENERIC_KERNELS, PLAN_GL_NO_COLS256, PLAN_RT_NO_COLS256 = 1, 2, 4
+PLAN_GL_REGTILE, PLAN_STARK_NO_LAZY, PLAN_STARK_GENERIC_ON_LAZY = 8, 16, 32
+
+
+def plan_from_env(ring=None):
+    """Test / A-B helper: the SR_* switches of earlier rounds, parsed HERE (the library itself reads no environment variable).
+    ring: ring id, so that SR_GOLDILOCKS_GENERIC only affects Goldilocks contexts and so on."""
+    e = os.environ
+    f = 0
+    if (ring in (None, 0) and e.get("SR_GOLDILOCKS_GENERIC") == "1") or (ring in (None, 1) and e.get("SR_BABYBEAR_GENERIC") == "1"):
+        f |= PLAN_GENERIC_KERNELS
+    if e.get("SR_GL_COLS256") == "0":
+        f |= PLAN_GL_NO_COLS256
+    if e.get("SR_RT_COLS256") == "0":
+        f |= PLAN_RT_NO_COLS256
+    if e.get("SR_GOLDILOCKS_REGTILE") == "1":
+        f |= PLAN_GL_REGTILE
+    if e.get("SR_STARK_LAZY") == "0":
+        f |= PLAN_STARK_NO_LAZY
+    if e.get("SR_STARK_TUNED") == "0":
+        f |= PLAN_STARK_GENERIC_ON_LAZY
+    p = Plan()
+    p.flags = f
+    p.log_tile = int(e.get("SR_LOG_TILE", "0") or 0)
+    p.stark_whole_max = int(e.get("SR_ST_WHOLE_MAX", "0") or 0)
+    p.chunk_polys = int(e.get("SR_CHUNK_POLYS", "0") or 0)
+    p.scratch_limit_bytes = int(e.get("SR_SCRATCH_LIMIT_MB", "0") or 0) << 20
+    p.host_chunk_mb = int(e.get("SR_HOST_CHUNK_MB", "0") or 0)
+    return p
+
 
 _lib = None
 

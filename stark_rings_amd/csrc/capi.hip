@@ -66,7 +66,9 @@ struct sr_ctx {
     bool fast_goldilocks = true;
     bool regtile = false;   // BabyBear (and, for cross-checks, Goldilocks with SR_GOLDILOCKS_REGTILE=1): ntt_regtile.hpp
     sr::rt::Hooks rt_hooks{};
-    void *rt_scratch[2] = {nullptr, nullptr};   // packed intermediates of the register-tiled path
+    sr_plan plan{};         // fixed at creation (sr_ctx_create_ex); the library reads no environment variable
+    void *rt_scratch[2] = {nullptr, nullptr};   // operand scratch: [0] column-stage image of b in a fused ring product (every
+                                                // path); [0], [1] packed intermediates of the register-tiled path
     size_t rt_scratch_bytes[2] = {0, 0};
     // the scratch is shared by every call on this context: a call on another stream first waits for the previous user
     hipEvent_t rt_scratch_free = nullptr;
@@ -220,10 +222,7 @@ int init_pow2(sr_ctx *c) {
     const int k = c->k;
     if (k > F::kTwoAdicity - 1) return fail(SR_E_INVALID, "log2_degree exceeds the field's 2-adicity");
     c->log_tile = default_log_tile<F>();
-    if (const char *lt = getenv("SR_LOG_TILE")) {  // tuning knob: LDS tile of the generic kernels (8..12)
-        const int v = atoi(lt);
-        if (v >= 8 && v <= 12) c->log_tile = v;
-    }
+    if (c->plan.log_tile >= 8 && c->plan.log_tile <= 12) c->log_tile = c->plan.log_tile;  // tuning knob of the generic kernels
     if (k > 2 * c->log_tile && !c->stark_tuned) return fail(SR_E_INVALID, "log2_degree too large for the two-level kernels");
     const size_t d = c->degree;
     size_t extra = 0;
@@ -274,7 +273,7 @@ int init_pow2(sr_ctx *c) {
         // tuned-path tables live right behind [tw | itw] so one broadcast of the block ships everything
         if (sr::gl_fast_init(c->gl_fast, k, (const uint64_t *)tw, (const uint64_t *)itw, (uint64_t *)(itw + d),
                              (const uint64_t *)pows.data(), (const uint64_t *)ipows.data(), (uint64_t)dinv,
-                             (uint64_t)fused, c->stream))
+                             (uint64_t)fused, !(c->plan.flags & SR_PLAN_GL_NO_COLS256), c->plan.chunk_polys, c->stream))
             return fail(SR_E_HIP, "goldilocks fast-path table build failed");
     }
     return SR_OK;
@@ -313,13 +312,13 @@ int launch_rows(sr_ctx *c, typename F::storage *a, const typename F::storage *b,
     return SR_OK;
 }
 template <class F, int MODE>
-int launch_cols(sr_ctx *c, typename F::storage *a, size_t batch, bool fused_scale, hipStream_t st) {
+int launch_cols(sr_ctx *c, typename F::storage *a, const typename F::storage *src, size_t batch, bool fused_scale, hipStream_t st) {
     const size_t blocks = batch << (c->k - c->log_tile);
     if (blocks > 0x7FFFFFFFull) return fail(SR_E_INVALID, "batch too large for one launch");
     auto p = make_params<F>(c, fused_scale);
     ProfScope ps(c, st, MODE == sr::MODE_FWD ? K_FWD_COLS : K_INV_COLS);
     hipLaunchKernelGGL((sr::cols_kernel<F, MODE>), dim3((unsigned)blocks), dim3(sr::kThreads), lds_bytes<F>(c, false),
-                       st, a, batch, p);
+                       st, a, src, batch, p);
     HIP_TRY(hipGetLastError());
     return SR_OK;
 }
@@ -329,7 +328,7 @@ int fwd_dev(sr_ctx *c, uint64_t *d, size_t batch, hipStream_t st) {
     auto *a = reinterpret_cast<typename F::storage *>(d);
     if (c->k == 0 || batch == 0) return SR_OK;
     if (c->k > c->log_tile) {
-        int rc = launch_cols<F, sr::MODE_FWD>(c, a, batch, false, st);
+        int rc = launch_cols<F, sr::MODE_FWD>(c, a, a, batch, false, st);
         if (rc) return rc;
     }
     return launch_rows<F, sr::MODE_FWD>(c, a, nullptr, a, batch, false, st);
@@ -340,7 +339,7 @@ int inv_dev(sr_ctx *c, uint64_t *d, size_t batch, hipStream_t st) {
     if (c->k == 0 || batch == 0) return SR_OK;
     int rc = launch_rows<F, sr::MODE_INV>(c, a, nullptr, a, batch, false, st);
     if (rc) return rc;
-    if (c->k > c->log_tile) return launch_cols<F, sr::MODE_INV>(c, a, batch, false, st);
+    if (c->k > c->log_tile) return launch_cols<F, sr::MODE_INV>(c, a, a, batch, false, st);
     return SR_OK;
 }
 template <class F>
@@ -431,8 +430,20 @@ int matmul_dev(sr_ctx *c, uint64_t *y, const uint64_t *a, const uint64_t *b, siz
     HIP_TRY(hipGetLastError());
     return SR_OK;
 }
+// operand scratch (defined below): grow-only device buffers owned by the context, ordered between streams by an event
+int ensure_scratch(sr_ctx *c, int n_buffers, size_t bytes);
+int rt_scratch_acquire(sr_ctx *c, hipStream_t st);
+int rt_scratch_release(sr_ctx *c, hipStream_t st);
+// ring elements of elem_bytes each the operand scratch may hold for a batch (plan cap; at least one element)
+size_t scratch_polys(const sr_ctx *c, size_t batch, size_t elem_bytes) {
+    const size_t cap = c->plan.scratch_limit_bytes ? (size_t)c->plan.scratch_limit_bytes : ((size_t)16 << 30);
+    size_t n = cap / elem_bytes;
+    if (n == 0) n = 1;
+    if (c->plan.chunk_polys && n > c->plan.chunk_polys) n = c->plan.chunk_polys;
+    return n < batch ? n : batch;
+}
 template <class F>
-int ring_mul_dev(sr_ctx *c, uint64_t *out, const uint64_t *a, uint64_t *b, size_t batch, hipStream_t st) {
+int ring_mul_dev(sr_ctx *c, uint64_t *out, const uint64_t *a, const uint64_t *b, size_t batch, hipStream_t st) {
     using S = typename F::storage;
     if (batch == 0) return SR_OK;
     if constexpr (!sr::Lazy<F>::value) {  // (a lazy field is never selected for D = 1)
@@ -442,16 +453,26 @@ int ring_mul_dev(sr_ctx *c, uint64_t *out, const uint64_t *a, uint64_t *b, size_
         }
     }
     if (c->k > c->log_tile) {
-        // first (strided) forward stages of both operands; a's go to out so that a stays intact
-        if (out != a) HIP_TRY(hipMemcpyAsync(out, a, (batch << c->k) * sizeof(S), hipMemcpyDeviceToDevice, st));
-        int rc = launch_cols<F, sr::MODE_FWD>(c, reinterpret_cast<S *>(out), batch, true, st);
-        if (rc) return rc;
-        rc = launch_cols<F, sr::MODE_FWD>(c, reinterpret_cast<S *>(b), batch, true, st);
-        if (rc) return rc;
-        rc = launch_rows<F, sr::MODE_MUL>(c, reinterpret_cast<S *>(out), reinterpret_cast<const S *>(b),
-                                          reinterpret_cast<S *>(out), batch, true, st);
-        if (rc) return rc;
-        return launch_cols<F, sr::MODE_INV>(c, reinterpret_cast<S *>(out), batch, true, st);
+        // first (strided) forward stages of both operands: a's go straight to out, b's into the operand scratch, so that
+        // neither operand is written (coeff_form.rs:250-258); batches beyond the scratch cap run in chunks
+        const size_t elem = sizeof(S) << c->k;
+        const size_t chunk = scratch_polys(c, batch, elem);
+        if (int rc = ensure_scratch(c, 1, chunk * elem)) return rc;
+        if (int rc = rt_scratch_acquire(c, st)) return rc;
+        S *sb = reinterpret_cast<S *>(c->rt_scratch[0]);
+        for (size_t e = 0; e < batch; e += chunk) {
+            const size_t n = batch - e < chunk ? batch - e : chunk;
+            S *o = reinterpret_cast<S *>(out) + (e << c->k);
+            int rc = launch_cols<F, sr::MODE_FWD>(c, o, reinterpret_cast<const S *>(a) + (e << c->k), n, true, st);
+            if (rc) return rc;
+            rc = launch_cols<F, sr::MODE_FWD>(c, sb, reinterpret_cast<const S *>(b) + (e << c->k), n, true, st);
+            if (rc) return rc;
+            rc = launch_rows<F, sr::MODE_MUL>(c, o, sb, o, n, true, st);
+            if (rc) return rc;
+            rc = launch_cols<F, sr::MODE_INV>(c, o, o, n, true, st);
+            if (rc) return rc;
+        }
+        return rt_scratch_release(c, st);
     }
     return launch_rows<F, sr::MODE_MUL>(c, reinterpret_cast<S *>(const_cast<uint64_t *>(a)),
                                         reinterpret_cast<const S *>(b), reinterpret_cast<S *>(out), batch, true, st);
@@ -507,12 +528,12 @@ sr::rt::Params<F> make_rt_params(const sr_ctx *c, bool fused) {
     p.itw = p.tw + c->degree;
     memcpy(&p.scale0, fused ? c->mul_scale0 : c->inv_scale0, sizeof(E));
     memcpy(&p.scale1, fused ? c->mul_scale1 : c->inv_scale1, sizeof(E));
+    p.no_cols256 = (c->plan.flags & SR_PLAN_RT_NO_COLS256) != 0;
     return p;
 }
 // grow-only scratch for packed intermediates (allocated on first use; a hipMalloc here is why the very first
 // call of a given size is not graph-capturable)
-int rt_ensure_scratch(sr_ctx *c, int n_buffers, size_t bytes) {
-    if (c->k <= 12) return SR_OK;
+int ensure_scratch(sr_ctx *c, int n_buffers, size_t bytes) {
     for (int i = 0; i < n_buffers; i++) {
         if (c->rt_scratch_bytes[i] >= bytes) continue;
         HIP_TRY(hipDeviceSynchronize());
@@ -526,14 +547,17 @@ int rt_ensure_scratch(sr_ctx *c, int n_buffers, size_t bytes) {
     return SR_OK;
 }
 // stream ordering of the shared scratch (callers hold the context's mutex, so the bookkeeping itself is serialised)
-int rt_scratch_acquire(sr_ctx *c, hipStream_t st) {
+int rt_ensure_scratch(sr_ctx *c, int n_buffers, size_t bytes) {
     if (c->k <= 12) return SR_OK;
+    return ensure_scratch(c, n_buffers, bytes);
+}
+int rt_scratch_acquire(sr_ctx *c, hipStream_t st) {
     if (!c->rt_scratch_free) HIP_TRY(hipEventCreateWithFlags(&c->rt_scratch_free, hipEventDisableTiming));
     if (c->rt_scratch_used && c->rt_scratch_stream != st) HIP_TRY(hipStreamWaitEvent(st, c->rt_scratch_free, 0));
     return SR_OK;
 }
 int rt_scratch_release(sr_ctx *c, hipStream_t st) {
-    if (c->k <= 12) return SR_OK;
+    if (!c->rt_scratch_free) HIP_TRY(hipEventCreateWithFlags(&c->rt_scratch_free, hipEventDisableTiming));
     HIP_TRY(hipEventRecord(c->rt_scratch_free, st));
     c->rt_scratch_stream = st;
     c->rt_scratch_used = true;
@@ -560,7 +584,7 @@ int rt_inv(sr_ctx *c, uint64_t *d, size_t batch, hipStream_t st) {
     return rt_scratch_release(c, st);
 }
 template <class F>
-int rt_ring_mul(sr_ctx *c, uint64_t *out, const uint64_t *a, uint64_t *b, size_t batch, hipStream_t st) {
+int rt_ring_mul(sr_ctx *c, uint64_t *out, const uint64_t *a, const uint64_t *b, size_t batch, hipStream_t st) {
     using S = typename F::storage;
     using E = typename F::elem;
     if (int rc = rt_ensure_scratch(c, 2, (batch << c->k) * sizeof(E))) return rc;
@@ -578,7 +602,7 @@ int st_fwd(sr_ctx *c, uint64_t *d, size_t batch, hipStream_t st) {
     auto p = make_params<sr::StarkL>(c, false);
     auto *a = reinterpret_cast<sr::U256Storage *>(d);
     auto hook = [&](bool begin) { begin ? gl_prof_begin(c, 0, st) : gl_prof_end(c, st); };
-    if (sr::st::fwd_cols(a, batch, p, c->stark_one_tile, st, hook)) return fail(SR_E_HIP, "stark strided launch failed");
+    if (sr::st::fwd_cols(a, a, batch, p, c->stark_one_tile, st, hook)) return fail(SR_E_HIP, "stark strided launch failed");
     ProfScope ps(c, st, K_ROWS);
     if (sr::st::launch_rows<sr::MODE_FWD>(a, nullptr, a, batch, p, c->stark_one_tile, st)) return fail(SR_E_HIP, "stark rows launch failed");
     return SR_OK;
@@ -595,26 +619,37 @@ int st_inv(sr_ctx *c, uint64_t *d, size_t batch, hipStream_t st) {
     if (sr::st::inv_cols(a, batch, p, c->stark_one_tile, st, hook)) return fail(SR_E_HIP, "stark strided launch failed");
     return SR_OK;
 }
-int st_ring_mul(sr_ctx *c, uint64_t *out, const uint64_t *a, uint64_t *b, size_t batch, hipStream_t st) {
+int st_ring_mul(sr_ctx *c, uint64_t *out, const uint64_t *a, const uint64_t *b, size_t batch, hipStream_t st) {
     if (batch == 0) return SR_OK;
     using S = sr::U256Storage;
     auto p = make_params<sr::StarkL>(c, true);
-    S *o = reinterpret_cast<S *>(out), *pb = reinterpret_cast<S *>(b);
-    const bool strided = !c->stark_one_tile;
-    if (strided) {  // strided stages of both operands first; a's go to out so that a stays intact
-        if (out != a) HIP_TRY(hipMemcpyAsync(out, a, (batch << c->k) * sizeof(S), hipMemcpyDeviceToDevice, st));
-        auto hook = [&](bool begin) { begin ? gl_prof_begin(c, 0, st) : gl_prof_end(c, st); };
-        if (sr::st::fwd_cols(o, batch, p, false, st, hook)) return fail(SR_E_HIP, "stark strided launch failed");
-        if (sr::st::fwd_cols(pb, batch, p, false, st, hook)) return fail(SR_E_HIP, "stark strided launch failed");
-    }
-    {
+    if (c->stark_one_tile) {  // the ring element is one tile: one launch, a and b only read
         ProfScope ps(c, st, K_ROWS);
-        const S *src = strided ? o : reinterpret_cast<const S *>(a);
-        if (sr::st::launch_rows<sr::MODE_MUL>(const_cast<S *>(src), pb, o, batch, p, c->stark_one_tile, st)) return fail(SR_E_HIP, "stark rows launch failed");
+        if (sr::st::launch_rows<sr::MODE_MUL>(reinterpret_cast<S *>(const_cast<uint64_t *>(a)), reinterpret_cast<const S *>(b),
+                                              reinterpret_cast<S *>(out), batch, p, true, st))
+            return fail(SR_E_HIP, "stark rows launch failed");
+        return SR_OK;
     }
-    auto hook = [&](bool begin) { begin ? gl_prof_begin(c, 2, st) : gl_prof_end(c, st); };
-    if (sr::st::inv_cols(o, batch, p, c->stark_one_tile, st, hook)) return fail(SR_E_HIP, "stark strided launch failed");
-    return SR_OK;
+    // strided stages of both operands first: a's go straight to out, b's into the operand scratch (neither is written)
+    const size_t elem = sizeof(S) << c->k;
+    const size_t chunk = scratch_polys(c, batch, elem);
+    if (int rc = ensure_scratch(c, 1, chunk * elem)) return rc;
+    if (int rc = rt_scratch_acquire(c, st)) return rc;
+    S *sb = reinterpret_cast<S *>(c->rt_scratch[0]);
+    auto hook_f = [&](bool begin) { begin ? gl_prof_begin(c, 0, st) : gl_prof_end(c, st); };
+    auto hook_i = [&](bool begin) { begin ? gl_prof_begin(c, 2, st) : gl_prof_end(c, st); };
+    for (size_t e = 0; e < batch; e += chunk) {
+        const size_t n = batch - e < chunk ? batch - e : chunk;
+        S *o = reinterpret_cast<S *>(out) + (e << c->k);
+        if (sr::st::fwd_cols(o, reinterpret_cast<const S *>(a) + (e << c->k), n, p, false, st, hook_f)) return fail(SR_E_HIP, "stark strided launch failed");
+        if (sr::st::fwd_cols(sb, reinterpret_cast<const S *>(b) + (e << c->k), n, p, false, st, hook_f)) return fail(SR_E_HIP, "stark strided launch failed");
+        {
+            ProfScope ps(c, st, K_ROWS);
+            if (sr::st::launch_rows<sr::MODE_MUL>(o, sb, o, n, p, false, st)) return fail(SR_E_HIP, "stark rows launch failed");
+        }
+        if (sr::st::inv_cols(o, n, p, false, st, hook_i)) return fail(SR_E_HIP, "stark strided launch failed");
+    }
+    return rt_scratch_release(c, st);
 }
 
 bool is_pow2_ring(int ring) { return ring >= SR_RING_GOLDILOCKS_POW2 && ring <= SR_RING_STARK_POW2; }
@@ -817,7 +852,7 @@ int dev_matvec(sr_ctx *c, uint64_t *y, const uint64_t *m, const uint64_t *v, siz
     if (c->stark_lazy) return matvec_dev<sr::StarkL>(c, y, m, v, nrows, ncols, st);  // sums of products on 28-bit lazy limbs (stark_lazy.hpp)
     DISPATCH_POW2(c, (matvec_dev<F>(c, y, m, v, nrows, ncols, st)));
 }
-int dev_ring_mul(sr_ctx *c, uint64_t *out, const uint64_t *a, uint64_t *b, size_t batch, hipStream_t st) {
+int dev_ring_mul(sr_ctx *c, uint64_t *out, const uint64_t *a, const uint64_t *b, size_t batch, hipStream_t st) {
     if (c->ring == SR_RING_FROG_16) return sr::frog_launch(c->frog, sr::FROG_RINGMUL, a, b, 0, out, batch, st) ? fail(SR_E_HIP, "frog-ring launch failed") : SR_OK;
     if (c->ring == SR_RING_GOLDILOCKS_24) return sr::small_launch(c->small, sr::SMALL_G24_RINGMUL, a, b, 0, out, batch, st) ? fail(SR_E_HIP, "small-ring launch failed") : SR_OK;
     if (c->ring == SR_RING_BABYBEAR_72) return sr::small_launch(c->small, sr::SMALL_B72_RINGMUL, a, b, 0, out, batch, st) ? fail(SR_E_HIP, "small-ring launch failed") : SR_OK;
@@ -826,11 +861,32 @@ int dev_ring_mul(sr_ctx *c, uint64_t *out, const uint64_t *a, uint64_t *b, size_
         return rt_ring_mul<sr::Goldilocks>(c, out, a, b, batch, st);
     }
     if (c->ring == SR_RING_GOLDILOCKS_POW2 && c->fast_goldilocks && sr::gl_fast_supported(c->gl_fast)) {
-        return sr::gl_fast_ring_mul(c->gl_fast, out, a, b, batch, st) ? fail(SR_E_HIP, "goldilocks fast-path launch failed") : SR_OK;
+        uint64_t *scratch = nullptr;
+        size_t chunk = 0;
+        if (c->k > 12 && batch) {  // b's column stages go through the operand scratch
+            const size_t elem = (size_t)8 << c->k;
+            chunk = scratch_polys(c, batch, elem);
+            if (int rc = ensure_scratch(c, 1, chunk * elem)) return rc;
+            if (int rc = rt_scratch_acquire(c, st)) return rc;
+            scratch = reinterpret_cast<uint64_t *>(c->rt_scratch[0]);
+        }
+        if (sr::gl_fast_ring_mul(c->gl_fast, out, a, b, scratch, chunk, batch, st)) return fail(SR_E_HIP, "goldilocks fast-path launch failed");
+        return scratch ? rt_scratch_release(c, st) : SR_OK;
     }
     if (c->stark_tuned) return st_ring_mul(c, out, a, b, batch, st);
     if (c->stark_lazy) return ring_mul_dev<sr::StarkL>(c, out, a, b, batch, st);
     DISPATCH_POW2(c, (ring_mul_dev<F>(c, out, a, b, batch, st)));
+}
+// out = icrt(crt(a) (.) b_ntt): forward transform, slot product and inverse transform on out, one after the other (the
+// Goldilocks tuned path fuses them: gl_fast_ring_mul_rhs)
+int dev_ring_mul_ntt_rhs(sr_ctx *c, uint64_t *out, const uint64_t *a, const uint64_t *b_ntt, size_t batch, hipStream_t st) {
+    if (batch == 0) return SR_OK;
+    if (c->ring == SR_RING_GOLDILOCKS_POW2 && !c->regtile && c->fast_goldilocks && sr::gl_fast_supported(c->gl_fast) && c->k >= 8)
+        return sr::gl_fast_ring_mul_rhs(c->gl_fast, out, a, b_ntt, batch, st) ? fail(SR_E_HIP, "goldilocks fast-path launch failed") : SR_OK;
+    if (out != a) HIP_TRY(hipMemcpyAsync(out, a, batch * c->degree * c->limbs * 8, hipMemcpyDeviceToDevice, st));
+    if (int rc = dev_fwd(c, out, batch, st)) return rc;
+    if (int rc = dev_pointwise(c, out, b_ntt, batch, st)) return rc;
+    return dev_inv(c, out, batch, st);
 }
 int dev_reduce(sr_ctx *c, const uint64_t *in, size_t in_len, uint64_t *out, size_t batch, hipStream_t st) {
     if (c->ring == SR_RING_FROG_16) {
@@ -854,8 +910,17 @@ const char *sr_last_error_string(void) { return g_err.c_str(); }
 const char *sr_version(void) { return "stark-rings-amd 0.1 (gfx950)"; }
 
 int sr_ctx_create(int ring, int log2_degree, int device, sr_ctx **out) {
+    return sr_ctx_create_ex(ring, log2_degree, device, nullptr, out);
+}
+int sr_ctx_create_ex(int ring, int log2_degree, int device, const sr_plan *plan, sr_ctx **out) {
     if (!out) return fail(SR_E_INVALID, "null out pointer");
     *out = nullptr;
+    if (plan) {
+        if (plan->flags >> 6) return fail(SR_E_INVALID, "sr_plan: unknown flag bits");
+        if (plan->log_tile && (plan->log_tile < 8 || plan->log_tile > 12)) return fail(SR_E_INVALID, "sr_plan: log_tile must be 0 or 8..12");
+        if (plan->stark_whole_max && (plan->stark_whole_max < 9 || plan->stark_whole_max > 12))
+            return fail(SR_E_INVALID, "sr_plan: stark_whole_max must be 0 or 9..12");
+    }
     if (ring < SR_RING_GOLDILOCKS_POW2 || ring > SR_RING_FROG_16) return fail(SR_E_INVALID, "unknown ring id");
     if (is_pow2_ring(ring) && (log2_degree < 0 || log2_degree > 24)) return fail(SR_E_INVALID, "log2_degree out of range");
     int ndev = 0;
@@ -867,6 +932,8 @@ int sr_ctx_create(int ring, int log2_degree, int device, sr_ctx **out) {
     sr_ctx *c = new sr_ctx();
     c->ring = ring;
     c->device = device;
+    if (plan) c->plan = *plan;
+    const uint32_t pf = c->plan.flags;
     int rc = SR_OK;
     auto bail = [&](int code) {
         sr_ctx_destroy(c);
@@ -887,29 +954,24 @@ int sr_ctx_create(int ring, int log2_degree, int device, sr_ctx **out) {
             case SR_RING_GOLDILOCKS_POW2: rc = init_pow2<sr::Goldilocks>(c); break;
             case SR_RING_BABYBEAR_POW2: rc = init_pow2<sr::BabyBear>(c); break;
             default: {
-                // SR_STARK_LAZY=0 keeps the transforms on the 8 x 32-bit-limb arithmetic (differential tests); D = 1 has none
-                const char *env = getenv("SR_STARK_LAZY");
-                c->stark_lazy = !(env && env[0] == '0') && log2_degree >= 1;
-                const char *tuned = getenv("SR_STARK_TUNED");
-                c->stark_tuned = c->stark_lazy && !(tuned && tuned[0] == '0') && sr::st::supported(log2_degree);
-                c->stark_one_tile = sr::st::whole(log2_degree, sr::st::whole_max());
+                // SR_PLAN_STARK_NO_LAZY keeps the transforms on the 8 x 32-bit-limb arithmetic (differential tests); D = 1 has none
+                c->stark_lazy = !(pf & SR_PLAN_STARK_NO_LAZY) && log2_degree >= 1;
+                c->stark_tuned = c->stark_lazy && !(pf & (SR_PLAN_STARK_GENERIC_ON_LAZY | SR_PLAN_GENERIC_KERNELS)) && sr::st::supported(log2_degree);
+                c->stark_one_tile = sr::st::whole(log2_degree, sr::st::whole_max(c->plan.stark_whole_max));
                 rc = c->stark_lazy ? init_pow2<sr::StarkL>(c) : init_pow2<sr::Stark>(c);
                 break;
             }
         }
         if (rc) return bail(rc);
         if (ring == SR_RING_GOLDILOCKS_POW2) {
-            const char *env = getenv("SR_GOLDILOCKS_GENERIC");
-            c->fast_goldilocks = !(env && env[0] == '1');
+            c->fast_goldilocks = !(pf & SR_PLAN_GENERIC_KERNELS);
             c->gl_fast.prof_user = c;
             c->gl_fast.prof_begin = gl_prof_begin;
             c->gl_fast.prof_end = gl_prof_end;
-            const char *rt = getenv("SR_GOLDILOCKS_REGTILE");
-            c->regtile = rt && rt[0] == '1' && c->k >= 12 && c->k <= 24;
+            c->regtile = (pf & SR_PLAN_GL_REGTILE) && c->k >= 12 && c->k <= 24;
         }
         if (ring == SR_RING_BABYBEAR_POW2) {
-            const char *env = getenv("SR_BABYBEAR_GENERIC");
-            c->regtile = !(env && env[0] == '1') && c->k >= 12 && c->k <= 24;
+            c->regtile = !(pf & SR_PLAN_GENERIC_KERNELS) && c->k >= 12 && c->k <= 24;
         }
         c->rt_hooks.user = c;
         c->rt_hooks.begin = gl_prof_begin;
@@ -1289,13 +1351,38 @@ int sr_recompose_batch(sr_ctx *c, uint64_t *out, const uint64_t *in, uint64_t ba
     HIP_TRY(hipStreamSynchronize(c->stream));
     return SR_OK;
 }
-int sr_ring_mul_batch_dev(sr_ctx *c, uint64_t *out, const uint64_t *a, uint64_t *b, size_t batch, void *stream) {
+int sr_ring_mul_batch_dev(sr_ctx *c, uint64_t *out, const uint64_t *a, const uint64_t *b, size_t batch, void *stream) {
     if (int rc = check(c, out, a, b)) return rc;
     if (int rc = check_count(c, batch)) return rc;
-    if ((const uint64_t *)b == a || b == out) return fail(SR_E_INVALID, "ring_mul: b must not alias a or out");
+    if (b == out) return fail(SR_E_INVALID, "ring_mul: b must not alias out");
     std::lock_guard<std::mutex> lk(c->mu);
     DeviceGuard g(c->device);
     return dev_ring_mul(c, out, a, b, batch, (hipStream_t)stream);
+}
+int sr_ring_mul_ntt_rhs_batch_dev(sr_ctx *c, uint64_t *out, const uint64_t *a, const uint64_t *b_ntt, size_t batch, void *stream) {
+    if (int rc = check(c, out, a, b_ntt)) return rc;
+    if (int rc = check_count(c, batch)) return rc;
+    if (b_ntt == out) return fail(SR_E_INVALID, "ring_mul_ntt_rhs: b_ntt must not alias out");
+    std::lock_guard<std::mutex> lk(c->mu);
+    DeviceGuard g(c->device);
+    return dev_ring_mul_ntt_rhs(c, out, a, b_ntt, batch, (hipStream_t)stream);
+}
+int sr_ctx_reserve_scratch(sr_ctx *c, size_t batch) {
+    if (!c) return fail(SR_E_INVALID, "null context");
+    if (int rc = check_count(c, batch)) return rc;
+    std::lock_guard<std::mutex> lk(c->mu);
+    DeviceGuard g(c->device);
+    if (!is_pow2_ring(c->ring) || batch == 0) return SR_OK;  // the small rings need no scratch
+    const size_t elem = c->degree * c->limbs * 8;
+    if (c->regtile) {
+        const size_t w = c->ring == SR_RING_BABYBEAR_POW2 ? 4 : 8;
+        return rt_ensure_scratch(c, 2, (batch << c->k) * w);
+    }
+    const bool one_launch = c->ring == SR_RING_GOLDILOCKS_POW2 && c->fast_goldilocks && sr::gl_fast_supported(c->gl_fast)
+                                ? c->k <= 12
+                                : (c->stark_tuned ? c->stark_one_tile : c->k <= c->log_tile);
+    if (one_launch) return SR_OK;
+    return ensure_scratch(c, 1, scratch_polys(c, batch, elem) * elem);
 }
 int sr_reduce_batch_dev(sr_ctx *c, const uint64_t *in, size_t in_len, uint64_t *out, size_t batch, void *stream) {
     if (int rc = check(c, in, out)) return rc;
@@ -1345,11 +1432,7 @@ static int host_pipeline(sr_ctx *c, uint64_t *out, const uint64_t *a, const uint
     const size_t elem_bytes = c->degree * c->limbs * 8;
     const size_t bytes = batch * elem_bytes;
     if (bytes == 0) return SR_OK;
-    size_t chunk_mb = 128;
-    if (const char *e = getenv("SR_HOST_CHUNK_MB")) {
-        const long v = atol(e);
-        if (v > 0) chunk_mb = (size_t)v;
-    }
+    const size_t chunk_mb = c->plan.host_chunk_mb ? c->plan.host_chunk_mb : 128;
     size_t chunk = (chunk_mb << 20) / elem_bytes;
     if (chunk == 0) chunk = 1;
     if (batch <= 2 * chunk) {  // one shot

@@ -131,7 +131,8 @@ __global__ __launch_bounds__(kThreads) void rows_kernel(typename F::storage *a, 
 // Stages [0, s_rows): C = 2^s_rows rows of length Tr = D / C; a workgroup owns W = TILE / C
 // consecutive columns of one ring element.  grid.x = batch * (Tr / W) = batch * D / TILE.
 template <class F, int MODE>
-__global__ __launch_bounds__(kThreads) void cols_kernel(typename F::storage *a, size_t batch, NttParams<F> p) {
+__global__ __launch_bounds__(kThreads) void cols_kernel(typename F::storage *a, const typename F::storage *src, size_t batch,
+                                                        NttParams<F> p) {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     const int n_tile = 1 << p.log_tile;
     const int lc = p.s_rows;              // log2 C
@@ -143,10 +144,11 @@ __global__ __launch_bounds__(kThreads) void cols_kernel(typename F::storage *a, 
     const size_t chunk = blockIdx.x % chunks;
     if (poly >= batch) return;
     typename F::storage *base = a + (poly << p.k) + (chunk << lw);
+    const typename F::storage *sbase = src + (poly << p.k) + (chunk << lw);  // src == a: in place; otherwise src is only read
 
     for (int idx = threadIdx.x; idx < n_tile; idx += kThreads) {
         int c = idx >> lw, w = idx & (W - 1);
-        F::lds_put(smem, idx, n_tile, F::load(base + ((size_t)c << ltr) + w));
+        F::lds_put(smem, idx, n_tile, F::load(sbase + ((size_t)c << ltr) + w));
     }
     __syncthreads();
 

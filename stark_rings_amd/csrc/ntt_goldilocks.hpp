@@ -187,7 +187,7 @@ struct Tables {
 // its butterflies, INV before (TWIST only on the pass adjacent to the rows kernel, where S = 4096).
 // ------------------------------------------------------------------------------------------------
 template <int M, int DIR, bool TWIST>
-__global__ __launch_bounds__(256) void strided_kernel(u64 *data, int k, int s_lo, const u64 *tw, const u64 *twist) {
+__global__ __launch_bounds__(256) void strided_kernel(u64 *data, const u64 *src, int k, int s_lo, const u64 *tw, const u64 *twist) {
     constexpr int R = 1 << M;
     const int ls = k - s_lo - M;  // log2 S
     const size_t S = (size_t)1 << ls;
@@ -197,11 +197,13 @@ __global__ __launch_bounds__(256) void strided_kernel(u64 *data, int k, int s_lo
     const unsigned h = rest & ((1u << s_lo) - 1u);
     const size_t poly = rest >> s_lo;
     const unsigned i = ci * 256u + threadIdx.x;
-    u64 *base = data + (poly << k) + ((size_t)h << (k - s_lo)) + i;
+    const size_t off = (poly << k) + ((size_t)h << (k - s_lo)) + i;
+    u64 *base = data + off;
+    const u64 *sbase = src + off;  // src == data: in place; otherwise the pass reads src and leaves it intact
 
     u64 x[R];
 #pragma unroll
-    for (int j = 0; j < R; j++) x[j] = base[(size_t)j << ls];
+    for (int j = 0; j < R; j++) x[j] = sbase[(size_t)j << ls];
 
     if (DIR == 0) {
 #pragma unroll
@@ -254,7 +256,7 @@ __global__ __launch_bounds__(256) void strided_kernel(u64 *data, int k, int s_lo
 __device__ __forceinline__ int pad(int pos);  // defined with the rows kernel below
 
 template <int DIR, bool TWIST>
-__global__ __launch_bounds__(256, 4) void strided256_kernel(u64 *data, int k, int s_lo, const u64 *tw, const u64 *twist) {
+__global__ __launch_bounds__(256, 4) void strided256_kernel(u64 *data, const u64 *src, int k, int s_lo, const u64 *tw, const u64 *twist) {
     __shared__ u64 lds[kLdsElems];
     const int t = threadIdx.x;
     const int ls = k - s_lo - 8;  // log2 S
@@ -265,13 +267,15 @@ __global__ __launch_bounds__(256, 4) void strided256_kernel(u64 *data, int k, in
     const size_t poly = rest >> s_lo;
     const int col = t & 15, rg = t >> 4;
     const unsigned i = ci * 16u + (unsigned)col;  // position inside the leg
-    u64 *base = data + (poly << k) + ((size_t)h << (k - s_lo)) + i;
+    const size_t off = (poly << k) + ((size_t)h << (k - s_lo)) + i;
+    u64 *base = data + off;
+    const u64 *sbase = src + off;
     const int base2 = rg * 256 + col;
     u64 x[16];
 
     if (DIR == 0) {
 #pragma unroll
-        for (int jj = 0; jj < 16; jj++) x[jj] = base[(size_t)(rg + 16 * jj) << ls];
+        for (int jj = 0; jj < 16; jj++) x[jj] = sbase[(size_t)(rg + 16 * jj) << ls];
 #pragma unroll
         for (int u = 0; u < 4; u++) {
             const int half = 8 >> u;
@@ -310,7 +314,7 @@ __global__ __launch_bounds__(256, 4) void strided256_kernel(u64 *data, int k, in
     } else {
 #pragma unroll
         for (int jj = 0; jj < 16; jj++) {
-            u64 v = base[(size_t)(16 * rg + jj) << ls];
+            u64 v = sbase[(size_t)(16 * rg + jj) << ls];
             if (TWIST) v = G::mul(v, twist[((size_t)((h << 8) + (unsigned)(16 * rg + jj)) << 12) + i]);
             x[jj] = v;
         }
@@ -387,73 +391,89 @@ SR_HD void cols_stage_inv(u64 *x, std::integer_sequence<int, Js...>) {
     (cols_bf_inv<U, Js>(x), ...);
 }
 
-template <int DIR>
-// -DSR_COLS_WAVES=5 builds the unpadded five-workgroups-per-CU variant: measured equal (8.15 vs 8.08 ms for the two forward
-// launches), the kernel is bound by instruction issue, not by latency
+// LC = log2 of the columns a workgroup owns: 16 << LC lanes, 256 legs x 2^LC consecutive columns (2^LC x 8-byte segments).
+// Wider segments stream better (tools/ubench/strided_pattern.hip: 4.7 / 5.1 / 6.1 TB/s for 16 / 32 / 64 columns) at the price of
+// fewer, larger workgroups.  LC = 4 pads the LDS tile (a 32-lane LDS group spans two legs); LC >= 5 needs no padding: every
+// 32-lane group reads or writes 32 consecutive 8-byte words.
+template <int LC>
+struct ColsTile {
+    static constexpr int C = 1 << LC;
+    static constexpr int kLanes = 16 * C;
+    static constexpr int kElems = LC == 4 ? kLdsElems : 256 * C;
+    static __device__ __forceinline__ int idx(int leg, int col) {
+        const int pos = leg * C + col;
+        return LC == 4 ? pos + (pos >> 4) : pos;
+    }
+};
 #ifndef SR_COLS_WAVES
 #define SR_COLS_WAVES 4
 #endif
-__global__ __launch_bounds__(256, SR_COLS_WAVES) void cols256_kernel(u64 *data, int k, const u64 *__restrict__ wc,
-                                                         const u64 *__restrict__ twist) {
-#if SR_COLS_WAVES >= 5
-    __shared__ u64 lds[kTile];  // unpadded: five workgroups per CU fit the 160 KiB of LDS
-#define SR_CPAD(x) (x)
-#else
-    __shared__ u64 lds[kLdsElems];
-#define SR_CPAD(x) pad(x)
-#endif
+template <int DIR, int LC>
+__global__ __launch_bounds__(16 << LC, LC == 4 ? SR_COLS_WAVES : 4) void cols256_kernel(u64 *data, const u64 *src, int k,
+                                                                                       const u64 *__restrict__ wc,
+                                                                                       const u64 *__restrict__ twist) {
+    using CT = ColsTile<LC>;
+    constexpr int C = CT::C;
+    __shared__ u64 lds[CT::kElems];
     const int t = threadIdx.x;
     const int ls = k - 8;  // log2 N2
-    const unsigned ci = blockIdx.x & ((1u << (ls - 4)) - 1u);
-    const size_t poly = blockIdx.x >> (ls - 4);
-    const int col = t & 15, rg = t >> 4;
-    const unsigned i = ci * 16u + (unsigned)col;  // column = position inside a leg
+    const unsigned ci = blockIdx.x & ((1u << (ls - LC)) - 1u);
+    const size_t poly = blockIdx.x >> (ls - LC);
+    const int col = t & (C - 1), rg = t >> LC;
+    const unsigned i = ci * (unsigned)C + (unsigned)col;  // column = position inside a leg
     // wave-uniform base + 32-bit byte offsets (a ring element is at most 8 MiB): one v_add_u32 per access
     char *pb = reinterpret_cast<char *>(data + (poly << k));
+    const char *ps = reinterpret_cast<const char *>(src + (poly << k));  // src == data: in place; otherwise src is only read
     const char *tb = reinterpret_cast<const char *>(twist);
     const unsigned leg = 8u << ls;                                      // bytes between consecutive legs
     const unsigned offA = (((unsigned)rg << ls) + i) * 8u;              // leg rg (+ 16 jj)
     const unsigned offB = (((unsigned)rg << (ls + 4)) + i) * 8u;        // leg 16 rg (+ sigma) = final block b
-    const int base2 = rg * 256 + col;
     using seq16 = std::make_integer_sequence<int, 16>;
     u64 x[16];
 
     if (DIR == 0) {
 #pragma unroll
-        for (int jj = 0; jj < 16; jj++) x[jj] = *reinterpret_cast<const u64 *>(pb + (offA + (unsigned)jj * 16u * leg));
+        for (int jj = 0; jj < 16; jj++) x[jj] = *reinterpret_cast<const u64 *>(ps + (offA + (unsigned)jj * 16u * leg));
+#ifndef SR_DIAG_COLS_NOCOMPUTE
         cols_stage_fwd<0>(x, seq16{});
         cols_stage_fwd<1>(x, seq16{});
         cols_stage_fwd<2>(x, seq16{});
         cols_stage_fwd<3>(x, seq16{});
 #pragma unroll
         for (int h = 0; h < 16; h++) x[h] = G::mul(x[h], wc[h * 16 + rg]);
+#endif
 #pragma unroll
-        for (int h = 0; h < 16; h++) lds[SR_CPAD(h * 256 + t)] = x[h];  // leg 16 h + rg, column col
+        for (int h = 0; h < 16; h++) lds[CT::idx(16 * h + rg, col)] = x[h];  // leg 16 h + rg, column col
         __syncthreads();
         u64 tw[16];
 #pragma unroll
         for (int sg = 0; sg < 16; sg++) tw[sg] = *reinterpret_cast<const u64 *>(tb + (offB + (unsigned)sg * leg));
 #pragma unroll
-        for (int j = 0; j < 16; j++) x[j] = lds[SR_CPAD(base2 + j * 16)];  // block rg, leg j
+        for (int j = 0; j < 16; j++) x[j] = lds[CT::idx(16 * rg + j, col)];  // block rg, leg j
+#ifndef SR_DIAG_COLS_NOCOMPUTE
         dft16_fwd(x);
 #pragma unroll
         for (int sg = 0; sg < 16; sg++)
             *reinterpret_cast<u64 *>(pb + (offB + (unsigned)sg * leg)) = G::mul(x[sg], tw[sg]);
+#else
+#pragma unroll
+        for (int sg = 0; sg < 16; sg++) *reinterpret_cast<u64 *>(pb + (offB + (unsigned)sg * leg)) = x[sg] ^ tw[sg];
+#endif
     } else {
         u64 tw[16];
 #pragma unroll
         for (int sg = 0; sg < 16; sg++) {
-            x[sg] = *reinterpret_cast<const u64 *>(pb + (offB + (unsigned)sg * leg));
+            x[sg] = *reinterpret_cast<const u64 *>(ps + (offB + (unsigned)sg * leg));
             tw[sg] = *reinterpret_cast<const u64 *>(tb + (offB + (unsigned)sg * leg));
         }
 #pragma unroll
         for (int sg = 0; sg < 16; sg++) x[sg] = G::mul(x[sg], tw[sg]);
         dft16_inv(x);
 #pragma unroll
-        for (int j = 0; j < 16; j++) lds[SR_CPAD(base2 + j * 16)] = x[j];
+        for (int j = 0; j < 16; j++) lds[CT::idx(16 * rg + j, col)] = x[j];
         __syncthreads();
 #pragma unroll
-        for (int h = 0; h < 16; h++) x[h] = lds[SR_CPAD(h * 256 + t)];
+        for (int h = 0; h < 16; h++) x[h] = lds[CT::idx(16 * h + rg, col)];
 #pragma unroll
         for (int h = 0; h < 16; h++) x[h] = G::mul(x[h], wc[h * 16 + rg]);
         cols_stage_inv<3>(x, seq16{});
@@ -463,7 +483,6 @@ __global__ __launch_bounds__(256, SR_COLS_WAVES) void cols256_kernel(u64 *data, 
 #pragma unroll
         for (int jj = 0; jj < 16; jj++) *reinterpret_cast<u64 *>(pb + (offA + (unsigned)jj * 16u * leg)) = x[jj];
     }
-#undef SR_CPAD
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -537,7 +556,8 @@ __device__ __forceinline__ void tile_inv(u64 *x, u64 *lds, const int t, const Ta
     }
 }
 
-// MODE 0: a -> crt(a) in place; 1: a -> icrt(a) in place; 2: out = icrt(crt(a) (.) crt(b)) tile by tile.
+// MODE 0: a -> crt(a) in place; 1: a -> icrt(a) in place; 2: out = icrt(crt(a) (.) crt(b)) tile by tile;
+// 3: out = icrt(crt(a) (.) b) with b already in CRT/NTT form (the constant-operand product: one transform fewer).
 // n_total = flat coefficient count of the batch (only consulted when TW: ragged last tile).
 #ifndef SR_ROWS_WAVES
 #define SR_ROWS_WAVES 4
@@ -580,7 +600,18 @@ __global__ __launch_bounds__(256, TW ? SR_ROWS_WAVES_TW : SR_ROWS_WAVES) void ro
         }
         u64 B[16];
         __syncthreads();  // everyone has read its pass-3 slots of a before b's pass-1 writes land
-        tile_fwd<Q, TW>(b + base, lds, t, T, B, nvalid);
+        if (MODE == 3) {  // b is in NTT order already: lane-contiguous load, one exchange into 16 consecutive slots per lane
+#pragma unroll
+            for (int j = 0; j < 16; j++) {
+                const int pos = j * 256 + t;
+                lds[pad(pos)] = b[base + ((!TW || pos < nvalid) ? pos : nvalid - 1)];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < 16; j++) B[j] = lds[17 * t + j];
+        } else {
+            tile_fwd<Q, TW>(b + base, lds, t, T, B, nvalid);
+        }
 #pragma unroll
         for (int j = 0; j < 16; j++) A[j] = G::mul(A[j], B[j]);
         // no barrier: tile_inv first writes the lane's own slots 17 t + j, which only this lane has just read
@@ -647,7 +678,15 @@ __global__ __launch_bounds__(256, 4) void rows256_kernel(u64 *a, const u64 *b, u
         }
         u64 B[16];
         __syncthreads();  // every lane has read a's exchange before b's lands
-        tile256_fwd(b + base, lds, t, T, B);
+        if (MODE == 3) {  // b already in NTT order (see rows_kernel)
+#pragma unroll
+            for (int j = 0; j < 16; j++) lds[pad(j * 256 + t)] = b[base + j * 256 + t];
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < 16; j++) B[j] = lds[17 * t + j];
+        } else {
+            tile256_fwd(b + base, lds, t, T, B);
+        }
 #pragma unroll
         for (int j = 0; j < 16; j++) A[j] = G::mul(A[j], B[j]);
     }
@@ -714,12 +753,7 @@ struct GoldilocksFastTables {
     bool cols256 = false;    // c == 8 in one cols256 launch (2^16 <= D <= 2^20)
     bool ready = false;
     gl::Tables t{};
-    size_t chunk_polys = 0;  // 0 = whole batch per launch
-    // optional 2-lane pipelining of chunks so that the memory-bound strided passes of one chunk overlap the
-    // VALU-bound rows kernel of another (lanes are internal streams forked from / joined to the caller's)
-    int n_lanes = 1;
-    hipStream_t lane[2] = {nullptr, nullptr};
-    hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr};
+    size_t chunk_polys = 0;  // ring products: elements per chunk of launches (0 = as many as the scratch holds)
     // optional per-launch timing hooks (set by capi.hip): tag 0 strided fwd, 1 rows, 2 strided inv
     void (*prof_begin)(void *user, int tag, hipStream_t st) = nullptr;
     void (*prof_end)(void *user, hipStream_t st) = nullptr;
@@ -745,7 +779,7 @@ inline size_t gl_fast_extra_bytes(int k) {
 // twiddle block so that one broadcast ships everything.
 inline int gl_fast_init(GoldilocksFastTables &f, int k, const uint64_t *tw, const uint64_t *itw, uint64_t *extra,
                         const uint64_t *host_pows, const uint64_t *host_ipows, uint64_t dinv, uint64_t dinv_mul,
-                        hipStream_t st) {
+                        bool allow_cols256, size_t chunk_polys, hipStream_t st) {
     f.k = k;
     f.ready = false;
     if (gl_fast_extra_bytes(k) == 0) return 0;
@@ -762,9 +796,10 @@ inline int gl_fast_init(GoldilocksFastTables &f, int k, const uint64_t *tw, cons
     uint64_t *wcf = p;                p += 256;
     uint64_t *wci = p;
     // plan: 2^16 <= D <= 2^20 runs all its column stages (8) in one shift-only cols256 launch and leaves D / 256-point
-    // rows; otherwise the rows are 4096 points (or whole ring elements, D <= 4096).  SR_GL_COLS256=0: the older plan.
-    const char *env256 = getenv("SR_GL_COLS256");
-    f.cols256 = k >= 16 && k <= 20 && !(env256 && atoi(env256) == 0);
+    // rows; otherwise the rows are 4096 points (or whole ring elements, D <= 4096).  allow_cols256 = false (sr_plan flag
+    // SR_PLAN_GL_NO_COLS256): the older plan.
+    f.cols256 = k >= 16 && k <= 20 && allow_cols256;
+    f.chunk_polys = chunk_polys;
     f.c = f.cols256 ? 8 : (k > 12 ? k - 12 : 0);
     uint64_t *d_pows = nullptr;
     if (hipMalloc(&d_pows, 2 * (k + 1) * sizeof(uint64_t)) != hipSuccess) return 1;
@@ -778,59 +813,38 @@ inline int gl_fast_init(GoldilocksFastTables &f, int k, const uint64_t *tw, cons
     if (hipStreamSynchronize(st) != hipSuccess) return 1;
     (void)hipFree(d_pows);
     f.t = gl::Tables{tw, itw, twist_f, twist_ip, twist_im, w1f, w1i, w1im, w2f, w2i, wcf, wci};
-    const char *env = getenv("SR_CHUNK_POLYS");
-    f.chunk_polys = env ? (size_t)strtoull(env, nullptr, 10) : 0;
-    env = getenv("SR_LANES");
-    f.n_lanes = env ? atoi(env) : 1;
-    if (f.n_lanes < 1 || f.n_lanes > 2) f.n_lanes = 1;
-    if (f.n_lanes > 1) {
-        for (int i = 0; i < 2; i++) {
-            if (hipStreamCreateWithFlags(&f.lane[i], hipStreamNonBlocking) != hipSuccess) return 1;
-            if (hipEventCreateWithFlags(&f.ev_join[i], hipEventDisableTiming) != hipSuccess) return 1;
-        }
-        if (hipEventCreateWithFlags(&f.ev_fork, hipEventDisableTiming) != hipSuccess) return 1;
-    }
     f.ready = true;
     return 0;
 }
-inline void gl_fast_destroy(GoldilocksFastTables &f) {
-    f.ready = false;
-    for (int i = 0; i < 2; i++) {
-        if (f.lane[i]) (void)hipStreamDestroy(f.lane[i]);
-        if (f.ev_join[i]) (void)hipEventDestroy(f.ev_join[i]);
-        f.lane[i] = nullptr;
-        f.ev_join[i] = nullptr;
-    }
-    if (f.ev_fork) (void)hipEventDestroy(f.ev_fork);
-    f.ev_fork = nullptr;
-}
+inline void gl_fast_destroy(GoldilocksFastTables &f) { f.ready = false; }
 
 template <int DIR, bool TWIST>
-inline int gl_launch_strided(const GoldilocksFastTables &f, int M, uint64_t *data, int k, int s_lo, size_t npoly,
-                             const uint64_t *tw, const uint64_t *twist, hipStream_t st) {
+inline int gl_launch_strided(const GoldilocksFastTables &f, int M, uint64_t *data, const uint64_t *src, int k, int s_lo,
+                             size_t npoly, const uint64_t *tw, const uint64_t *twist, hipStream_t st) {
     GlProfScope ps(f, DIR == 0 ? 0 : 2, st);
     const size_t S = (size_t)1 << (k - s_lo - M);
     const size_t blocks = npoly * ((size_t)1 << s_lo) * (S >> 8);
     if (blocks == 0 || blocks > 0x7FFFFFFFull) return 1;
     dim3 g((unsigned)blocks), b(256);
     switch (M) {
-        case 0: hipLaunchKernelGGL((gl::strided_kernel<0, DIR, TWIST>), g, b, 0, st, data, k, s_lo, tw, twist); break;
-        case 1: hipLaunchKernelGGL((gl::strided_kernel<1, DIR, TWIST>), g, b, 0, st, data, k, s_lo, tw, twist); break;
-        case 2: hipLaunchKernelGGL((gl::strided_kernel<2, DIR, TWIST>), g, b, 0, st, data, k, s_lo, tw, twist); break;
-        case 3: hipLaunchKernelGGL((gl::strided_kernel<3, DIR, TWIST>), g, b, 0, st, data, k, s_lo, tw, twist); break;
-        case 4: hipLaunchKernelGGL((gl::strided_kernel<4, DIR, TWIST>), g, b, 0, st, data, k, s_lo, tw, twist); break;
+        case 0: hipLaunchKernelGGL((gl::strided_kernel<0, DIR, TWIST>), g, b, 0, st, data, src, k, s_lo, tw, twist); break;
+        case 1: hipLaunchKernelGGL((gl::strided_kernel<1, DIR, TWIST>), g, b, 0, st, data, src, k, s_lo, tw, twist); break;
+        case 2: hipLaunchKernelGGL((gl::strided_kernel<2, DIR, TWIST>), g, b, 0, st, data, src, k, s_lo, tw, twist); break;
+        case 3: hipLaunchKernelGGL((gl::strided_kernel<3, DIR, TWIST>), g, b, 0, st, data, src, k, s_lo, tw, twist); break;
+        case 4: hipLaunchKernelGGL((gl::strided_kernel<4, DIR, TWIST>), g, b, 0, st, data, src, k, s_lo, tw, twist); break;
         default: return 1;
     }
     return hipGetLastError() != hipSuccess;
 }
 template <int DIR, bool TWIST>
-inline int gl_launch_strided256(const GoldilocksFastTables &f, uint64_t *data, int k, int s_lo, size_t npoly,
+inline int gl_launch_strided256(const GoldilocksFastTables &f, uint64_t *data, const uint64_t *src, int k, int s_lo, size_t npoly,
                                 const uint64_t *tw, const uint64_t *twist, hipStream_t st) {
     GlProfScope ps(f, DIR == 0 ? 0 : 2, st);
     const size_t S = (size_t)1 << (k - s_lo - 8);
     const size_t blocks = npoly * ((size_t)1 << s_lo) * (S >> 4);
     if (blocks == 0 || blocks > 0x7FFFFFFFull) return 1;
-    hipLaunchKernelGGL((gl::strided256_kernel<DIR, TWIST>), dim3((unsigned)blocks), dim3(256), 0, st, data, k, s_lo, tw, twist);
+    hipLaunchKernelGGL((gl::strided256_kernel<DIR, TWIST>), dim3((unsigned)blocks), dim3(256), 0, st, data, src, k, s_lo, tw,
+                       twist);
     return hipGetLastError() != hipSuccess;
 }
 // split the c = k - 12 strided stages into passes: 8 = one 256-leg pass through LDS (D >= 2^20), otherwise
@@ -847,29 +861,41 @@ inline int gl_plan(int c, int *ms) {
     if (big) ms[n++] = 8;
     return n;  // 0 passes for D <= 4096: the rows kernel applies the twist itself
 }
+// columns per workgroup (2^LC): measured at D = 2^16, batch 2^14 (tools/ubench/gl_bench.hip): forward 3.86 / 3.75 / 4.38 ms and
+// inverse 4.26 / 4.39 / 5.07 ms for LC = 4 / 5 / 6 -- wider segments stream better (strided_pattern.hip) but one or two big
+// workgroups per CU overlap their load, exchange and store phases worse than four small ones
+#ifndef SR_COLS_LC_FWD
+#define SR_COLS_LC_FWD 5
+#endif
+#ifndef SR_COLS_LC_INV
+#define SR_COLS_LC_INV 4
+#endif
 template <int DIR>
-inline int gl_launch_cols256(const GoldilocksFastTables &f, uint64_t *data, size_t npoly, const uint64_t *wc,
-                             const uint64_t *twist, hipStream_t st) {
+inline int gl_launch_cols256(const GoldilocksFastTables &f, uint64_t *data, const uint64_t *src, size_t npoly,
+                             const uint64_t *wc, const uint64_t *twist, hipStream_t st) {
     GlProfScope ps(f, DIR == 0 ? 0 : 2, st);
-    const size_t blocks = npoly << (f.k - 12);  // N2 / 16 per ring element
+    constexpr int LC = DIR == 0 ? SR_COLS_LC_FWD : SR_COLS_LC_INV;
+    const size_t blocks = npoly << (f.k - 8 - LC);  // N2 / 2^LC per ring element
     if (blocks == 0 || blocks > 0x7FFFFFFFull) return 1;
-    hipLaunchKernelGGL((gl::cols256_kernel<DIR>), dim3((unsigned)blocks), dim3(256), 0, st, data, f.k, wc, twist);
+    hipLaunchKernelGGL((gl::cols256_kernel<DIR, LC>), dim3((unsigned)blocks), dim3(16 << LC), 0, st, data, src, f.k, wc, twist);
     return hipGetLastError() != hipSuccess;
 }
-inline int gl_strided_fwd(const GoldilocksFastTables &f, uint64_t *d, size_t npoly, hipStream_t st) {
-    if (f.cols256) return gl_launch_cols256<0>(f, d, npoly, f.t.wcf, f.t.twist_f, st);
+// forward column stages of npoly ring elements: src -> d (src == d: in place).  Only the first pass reads src.
+inline int gl_strided_fwd(const GoldilocksFastTables &f, uint64_t *d, const uint64_t *src, size_t npoly, hipStream_t st) {
+    if (f.cols256) return gl_launch_cols256<0>(f, d, src, npoly, f.t.wcf, f.t.twist_f, st);
     int ms[8];
     const int n = gl_plan(f.k > 12 ? f.k - 12 : 0, ms);
     int s_lo = 0;
     for (int p = 0; p < n; p++) {
         const bool last = p == n - 1;
+        const uint64_t *from = p == 0 ? src : d;
         int rc;
         if (ms[p] == 8)
-            rc = last ? gl_launch_strided256<0, true>(f, d, f.k, s_lo, npoly, f.t.tw, f.t.twist_f, st)
-                      : gl_launch_strided256<0, false>(f, d, f.k, s_lo, npoly, f.t.tw, nullptr, st);
+            rc = last ? gl_launch_strided256<0, true>(f, d, from, f.k, s_lo, npoly, f.t.tw, f.t.twist_f, st)
+                      : gl_launch_strided256<0, false>(f, d, from, f.k, s_lo, npoly, f.t.tw, nullptr, st);
         else
-            rc = last ? gl_launch_strided<0, true>(f, ms[p], d, f.k, s_lo, npoly, f.t.tw, f.t.twist_f, st)
-                      : gl_launch_strided<0, false>(f, ms[p], d, f.k, s_lo, npoly, f.t.tw, nullptr, st);
+            rc = last ? gl_launch_strided<0, true>(f, ms[p], d, from, f.k, s_lo, npoly, f.t.tw, f.t.twist_f, st)
+                      : gl_launch_strided<0, false>(f, ms[p], d, from, f.k, s_lo, npoly, f.t.tw, nullptr, st);
         if (rc) return rc;
         s_lo += ms[p];
     }
@@ -877,7 +903,7 @@ inline int gl_strided_fwd(const GoldilocksFastTables &f, uint64_t *d, size_t npo
 }
 inline int gl_strided_inv(const GoldilocksFastTables &f, uint64_t *d, size_t npoly, bool fused, hipStream_t st) {
     const uint64_t *tw_i = fused ? f.t.twist_i_mul : f.t.twist_i_plain;
-    if (f.cols256) return gl_launch_cols256<1>(f, d, npoly, f.t.wci, tw_i, st);
+    if (f.cols256) return gl_launch_cols256<1>(f, d, d, npoly, f.t.wci, tw_i, st);
     int ms[8];
     const int n = gl_plan(f.k > 12 ? f.k - 12 : 0, ms);
     int s_lo = f.k > 12 ? f.k - 12 : 0;
@@ -886,11 +912,11 @@ inline int gl_strided_inv(const GoldilocksFastTables &f, uint64_t *d, size_t npo
         const bool first = p == n - 1;
         int rc;
         if (ms[p] == 8)
-            rc = first ? gl_launch_strided256<1, true>(f, d, f.k, s_lo, npoly, f.t.itw, tw_i, st)
-                       : gl_launch_strided256<1, false>(f, d, f.k, s_lo, npoly, f.t.itw, nullptr, st);
+            rc = first ? gl_launch_strided256<1, true>(f, d, d, f.k, s_lo, npoly, f.t.itw, tw_i, st)
+                       : gl_launch_strided256<1, false>(f, d, d, f.k, s_lo, npoly, f.t.itw, nullptr, st);
         else
-            rc = first ? gl_launch_strided<1, true>(f, ms[p], d, f.k, s_lo, npoly, f.t.itw, tw_i, st)
-                       : gl_launch_strided<1, false>(f, ms[p], d, f.k, s_lo, npoly, f.t.itw, nullptr, st);
+            rc = first ? gl_launch_strided<1, true>(f, ms[p], d, d, f.k, s_lo, npoly, f.t.itw, tw_i, st)
+                       : gl_launch_strided<1, false>(f, ms[p], d, d, f.k, s_lo, npoly, f.t.itw, nullptr, st);
         if (rc) return rc;
     }
     return 0;
@@ -921,7 +947,7 @@ inline int gl_launch_rows(const GoldilocksFastTables &f, uint64_t *a, const uint
 }
 inline int gl_fast_fwd(const GoldilocksFastTables &f, uint64_t *d, size_t batch, hipStream_t st) {
     if (batch == 0) return 0;
-    if (gl_strided_fwd(f, d, batch, st)) return 1;
+    if (gl_strided_fwd(f, d, d, batch, st)) return 1;
     return gl_launch_rows<0>(f, d, nullptr, d, batch, false, st);
 }
 inline int gl_fast_inv(const GoldilocksFastTables &f, uint64_t *d, size_t batch, hipStream_t st) {
@@ -929,39 +955,38 @@ inline int gl_fast_inv(const GoldilocksFastTables &f, uint64_t *d, size_t batch,
     if (gl_launch_rows<1>(f, d, nullptr, d, batch, false, st)) return 1;
     return gl_strided_inv(f, d, batch, false, st);
 }
-// out = a * b (ring product on in-memory images); b is overwritten with its strided-pass image.
-inline int gl_fast_ring_mul(const GoldilocksFastTables &f, uint64_t *out, const uint64_t *a, uint64_t *b, size_t batch,
-                            hipStream_t st) {
+// out = a * b (ring product on in-memory images); a and b are only read (coeff_form.rs:250-258 never mutates an operand):
+// a's column stages go straight to out, b's into scratch (scratch_polys ring elements, caller-owned; the batch is cut into
+// chunks of that many elements).  out may alias a; b must not alias out.
+inline int gl_fast_ring_mul(const GoldilocksFastTables &f, uint64_t *out, const uint64_t *a, const uint64_t *b, uint64_t *scratch,
+                            size_t scratch_polys, size_t batch, hipStream_t st) {
     if (batch == 0) return 0;
     if (f.k <= 12)  // whole ring elements per tile: one fused launch, a and b only read
         return gl_launch_rows<2>(f, const_cast<uint64_t *>(a), b, out, batch, true, st);
-    const size_t chunk = f.chunk_polys ? f.chunk_polys : batch;
+    if (scratch_polys == 0) return 1;
+    size_t chunk = f.chunk_polys ? f.chunk_polys : batch;
+    if (chunk > scratch_polys) chunk = scratch_polys;
     const size_t stride = (size_t)1 << f.k;
-    const bool lanes = f.n_lanes > 1 && chunk < batch;
-    if (lanes) {
-        if (hipEventRecord(f.ev_fork, st) != hipSuccess) return 1;
-        for (int i = 0; i < 2; i++)
-            if (hipStreamWaitEvent(f.lane[i], f.ev_fork, 0) != hipSuccess) return 1;
-    }
-    size_t ci = 0;
-    for (size_t e = 0; e < batch; e += chunk, ci++) {
+    for (size_t e = 0; e < batch; e += chunk) {
         const size_t n = batch - e < chunk ? batch - e : chunk;
-        hipStream_t s = lanes ? f.lane[ci & 1] : st;
-        uint64_t *o = out + e * stride, *bb = b + e * stride;
-        const uint64_t *aa = a + e * stride;
-        if (o != aa && hipMemcpyAsync(o, aa, n * stride * 8, hipMemcpyDeviceToDevice, s) != hipSuccess) return 1;
-        if (gl_strided_fwd(f, o, n, s)) return 1;
-        if (gl_strided_fwd(f, bb, n, s)) return 1;
-        if (gl_launch_rows<2>(f, o, bb, o, n, true, s)) return 1;
-        if (gl_strided_inv(f, o, n, true, s)) return 1;
-    }
-    if (lanes) {
-        for (int i = 0; i < 2; i++) {
-            if (hipEventRecord(f.ev_join[i], f.lane[i]) != hipSuccess) return 1;
-            if (hipStreamWaitEvent(st, f.ev_join[i], 0) != hipSuccess) return 1;
-        }
+        uint64_t *o = out + e * stride;
+        if (gl_strided_fwd(f, o, a + e * stride, n, st)) return 1;
+        if (gl_strided_fwd(f, scratch, b + e * stride, n, st)) return 1;
+        if (gl_launch_rows<2>(f, o, scratch, o, n, true, st)) return 1;
+        if (gl_strided_inv(f, o, n, true, st)) return 1;
     }
     return 0;
+}
+
+// out = icrt(crt(a) (.) b_ntt), b_ntt = crt(b) as sr_ntt_fwd leaves it: a's column stages go straight to out, the rows kernel
+// transforms a's tile only and reads b's slots in NTT order, the inverse column stages finish in place.  No scratch.
+inline int gl_fast_ring_mul_rhs(const GoldilocksFastTables &f, uint64_t *out, const uint64_t *a, const uint64_t *b_ntt, size_t batch,
+                                hipStream_t st) {
+    if (batch == 0) return 0;
+    if (f.k <= 12) return gl_launch_rows<3>(f, const_cast<uint64_t *>(a), b_ntt, out, batch, true, st);
+    if (gl_strided_fwd(f, out, a, batch, st)) return 1;
+    if (gl_launch_rows<3>(f, out, b_ntt, out, batch, true, st)) return 1;
+    return gl_strided_inv(f, out, batch, true, st);
 }
 
 }  // namespace sr

@@ -30,6 +30,7 @@ struct Params {
     int c;   // k - 12
     const typename F::elem *tw, *itw;
     typename F::elem scale0, scale1;  // inverse stage 0: sum leg, diff leg (table form)
+    bool no_cols256 = false;          // plan: 4-stage column passes + 12-stage rows instead of the 8 + 8 split
 };
 
 __device__ __forceinline__ int pad(int pos) { return pos + (pos >> 4); }
@@ -488,8 +489,7 @@ inline int launch_strided(const Hooks &hk, int M, const typename View<F, VI>::T 
 // 2^16 and 2^20 run stages 0..7 as one cols256 launch (SR_RT_COLS256=0: the 4-stage register passes, kept for A/B tests)
 template <class F>
 inline bool use_cols256(const Params<F> &p) {
-    const char *e = getenv("SR_RT_COLS256");  // read per call: tests flip it between contexts
-    return !(e && atoi(e) == 0) && (p.k == 16 || p.k == 20);
+    return !p.no_cols256 && (p.k == 16 || p.k == 20);  // no_cols256: sr_plan flag SR_PLAN_RT_NO_COLS256, fixed per context
 }
 template <class F, int DIR, class VI, class VO>
 inline int launch_cols256(const Hooks &hk, const typename View<F, VI>::T *src, typename View<F, VO>::T *dst, size_t npoly,

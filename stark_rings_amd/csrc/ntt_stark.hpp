@@ -19,6 +19,7 @@
 // rows stage keeps every limb below 2^31; an inverse group reduces its sum legs weakly at its end (a three-stage group also
 // relaxes its twice-summed legs before the third stage).  Loads take canonical memory images, stores canonicalise.
 #pragma once
+#include <atomic>
 #include <cstdlib>
 
 #include "ntt_generic.hpp"
@@ -130,7 +131,7 @@ __device__ __forceinline__ void inv_group(E *x, const P &p, uint32_t t0) {
 // one lane per (element, block of stage s0, offset inside the leg): grid.x * 256 >= batch << (k - M)
 // LAST (inverse only): the pass ends with stage 0 of the transform (s0 == 0)
 template <int M, int DIR, bool LAST>
-__global__ __launch_bounds__(256, 2) void cols_kernel(S *data, size_t batch, int s0, P p) {
+__global__ __launch_bounds__(256, 2) void cols_kernel(S *data, const S *src, size_t batch, int s0, P p) {
     const size_t gid = blockIdx.x * (size_t)256 + threadIdx.x;
     const int lq = p.k - M;                // log2 lanes per element
     if (gid >= (batch << lq)) return;
@@ -138,10 +139,12 @@ __global__ __launch_bounds__(256, 2) void cols_kernel(S *data, size_t batch, int
     const uint32_t q = (uint32_t)(gid & (((size_t)1 << lq) - 1));
     const int ls = p.k - s0 - M;           // log2 leg stride
     const uint32_t blk = q >> ls, r = q & ((1u << ls) - 1u);
-    S *base = data + (poly << p.k) + ((size_t)blk << (ls + M)) + r;
+    const size_t off = (poly << p.k) + ((size_t)blk << (ls + M)) + r;
+    S *base = data + off;
+    const S *sbase = src + off;  // src == data: in place; otherwise the pass reads src and leaves it intact
     E x[1 << M];
 #pragma unroll
-    for (int j = 0; j < (1 << M); j++) x[j] = F::load(base + ((size_t)j << ls));
+    for (int j = 0; j < (1 << M); j++) x[j] = F::load(sbase + ((size_t)j << ls));
     const uint32_t t0 = (1u << s0) + blk;
     if constexpr (DIR == MODE_FWD) {
         fwd_group<M>(x, p.tw, t0);
@@ -305,40 +308,39 @@ inline bool supported(int k) { return k >= kMinLog && k <= 20; }
 // Largest log2 D taken as one tile.  Measured over 2^24 coefficients (ring product, ms): D = 1024 one tile 1.96 / strided + 512-tiles
 // 2.48; D = 2048 2.22 / 2.46; D = 4096 2.86 / 2.57 (1024 lanes and 157 KB of LDS leave one workgroup per CU and every transpose
 // stalls all sixteen waves).  SR_ST_WHOLE_MAX overrides (9..12); the context reads it once, when it is created.
-inline int whole_max() {
-    const char *e = getenv("SR_ST_WHOLE_MAX");
-    const int x = e ? atoi(e) : 11;
+inline int whole_max(int requested) {  // sr_plan.stark_whole_max: 0 = default
+    const int x = requested ? requested : 11;
     return x < 9 ? 9 : (x > 12 ? 12 : x);
 }
 inline bool whole(int k, int wmax) { return k >= kMinLog && k <= wmax; }
 
 template <int DIR>
-inline int launch_cols(S *d, size_t batch, int s0, int m, const P &p, hipStream_t st) {
+inline int launch_cols(S *d, const S *src, size_t batch, int s0, int m, const P &p, hipStream_t st) {
     const size_t lanes = batch << (p.k - m);
     const size_t blocks = (lanes + 255) / 256;
     if (blocks > 0x7FFFFFFFull) return 1;
     const dim3 g((unsigned)blocks), b(256);
     const bool last = DIR == MODE_INV && s0 == 0;
     if (m == 3) {
-        if (last) hipLaunchKernelGGL((cols_kernel<3, DIR, true>), g, b, 0, st, d, batch, s0, p);
-        else hipLaunchKernelGGL((cols_kernel<3, DIR, false>), g, b, 0, st, d, batch, s0, p);
+        if (last) hipLaunchKernelGGL((cols_kernel<3, DIR, true>), g, b, 0, st, d, src, batch, s0, p);
+        else hipLaunchKernelGGL((cols_kernel<3, DIR, false>), g, b, 0, st, d, src, batch, s0, p);
     } else if (m == 2) {
-        if (last) hipLaunchKernelGGL((cols_kernel<2, DIR, true>), g, b, 0, st, d, batch, s0, p);
-        else hipLaunchKernelGGL((cols_kernel<2, DIR, false>), g, b, 0, st, d, batch, s0, p);
+        if (last) hipLaunchKernelGGL((cols_kernel<2, DIR, true>), g, b, 0, st, d, src, batch, s0, p);
+        else hipLaunchKernelGGL((cols_kernel<2, DIR, false>), g, b, 0, st, d, src, batch, s0, p);
     } else {
-        if (last) hipLaunchKernelGGL((cols_kernel<1, DIR, true>), g, b, 0, st, d, batch, s0, p);
-        else hipLaunchKernelGGL((cols_kernel<1, DIR, false>), g, b, 0, st, d, batch, s0, p);
+        if (last) hipLaunchKernelGGL((cols_kernel<1, DIR, true>), g, b, 0, st, d, src, batch, s0, p);
+        else hipLaunchKernelGGL((cols_kernel<1, DIR, false>), g, b, 0, st, d, src, batch, s0, p);
     }
     return hipGetLastError() != hipSuccess;
 }
 // the strided stages 0 .. k-10 as passes of (c mod 3), 3, 3, ... stages; begin / end bracket each launch for the profiler
 template <class Hook>
-inline int fwd_cols(S *d, size_t batch, const P &p, bool one_tile, hipStream_t st, Hook &&hook) {
+inline int fwd_cols(S *d, const S *src, size_t batch, const P &p, bool one_tile, hipStream_t st, Hook &&hook) {
     int c = one_tile ? 0 : p.k - kTileLog, s0 = 0;
     while (c > 0) {
         const int m = c % 3 ? c % 3 : 3;
         hook(true);
-        const int rc = launch_cols<MODE_FWD>(d, batch, s0, m, p, st);
+        const int rc = launch_cols<MODE_FWD>(d, s0 == 0 ? src : d, batch, s0, m, p, st);  // only the first pass reads src
         hook(false);
         if (rc) return rc;
         s0 += m;
@@ -355,7 +357,7 @@ inline int inv_cols(S *d, size_t batch, const P &p, bool one_tile, hipStream_t s
         const int first = c % 3 ? c % 3 : 3;
         const int m = s_hi > first ? 3 : first;
         hook(true);
-        const int rc = launch_cols<MODE_INV>(d, batch, s_hi - m, m, p, st);
+        const int rc = launch_cols<MODE_INV>(d, d, batch, s_hi - m, m, p, st);
         hook(false);
         if (rc) return rc;
         s_hi -= m;
@@ -368,14 +370,14 @@ inline int launch_tile(S *a, const S *b, S *out, size_t tiles, const P &p, hipSt
     constexpr size_t bytes = (size_t)T::kWords * 4;
     const size_t wgs = (tiles + tiles_per_wg(LOGT) - 1) / tiles_per_wg(LOGT);
     if constexpr (bytes > 65536) {  // more than 64 KB of dynamic LDS has to be allowed once per kernel and device
-        static bool attr_done[64] = {};
+        static std::atomic<bool> attr_done[64];  // per kernel instantiation; contexts on several threads may race here
         int dev = 0;
         if (hipGetDevice(&dev) != hipSuccess) return 1;
-        if (dev < 0 || dev >= 64 || !attr_done[dev]) {
+        if (dev < 0 || dev >= 64 || !attr_done[dev].load(std::memory_order_acquire)) {
             if (hipFuncSetAttribute((const void *)tile_kernel<LOGT, MODE, WHOLE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) !=
                 hipSuccess)
-                return 1;
-            if (dev >= 0 && dev < 64) attr_done[dev] = true;
+                return 1;  // setting it twice from two threads is harmless; the flag only saves the repeated call
+            if (dev >= 0 && dev < 64) attr_done[dev].store(true, std::memory_order_release);
         }
     }
     hipLaunchKernelGGL((tile_kernel<LOGT, MODE, WHOLE>), dim3((unsigned)wgs), dim3(T::kLanes * tiles_per_wg(LOGT)), bytes, st, a, b, out,

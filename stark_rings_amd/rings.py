@@ -57,15 +57,20 @@ def _np_ptr(a):
 class CyclotomicRing:
     """One ring configuration bound to one HIP device (the analogue of a `CyclotomicConfig` impl)."""
 
-    def __init__(self, ring, log2_degree=0, device=0):
+    def __init__(self, ring, log2_degree=0, device=0, plan=None):
+        """plan: a _lib.Plan (sr_plan); None = the SR_* switches of the environment as parsed by _lib.plan_from_env (all unset =
+        the library defaults).  The library itself never reads the environment."""
         if isinstance(ring, str):
             ring = _RING_NAMES[ring]
         self._lib = _lib.load()
         self._ctx = ctypes.c_void_p()
-        rc = self._lib.sr_ctx_create(int(ring), int(log2_degree), int(device), ctypes.byref(self._ctx))
+        if plan is None:
+            plan = _lib.plan_from_env(int(ring))
+        self.plan = plan
+        rc = self._lib.sr_ctx_create_ex(int(ring), int(log2_degree), int(device), ctypes.byref(plan), ctypes.byref(self._ctx))
         if rc != 0:
             self._ctx = None
-            raise RingError("sr_ctx_create failed (%d): %s" % (rc, _lib.last_error()))
+            raise RingError("sr_ctx_create_ex failed (%d): %s" % (rc, _lib.last_error()))
         self.ring = int(ring)
         self.device = int(device)
         d = ctypes.c_size_t()
@@ -263,20 +268,24 @@ class CyclotomicRing:
         return out
 
     # -- device-resident API (torch CUDA tensors of 8-byte integers) --------------------------
-    @staticmethod
-    def _dev(t):
-        import torch
-
+    def _dev(self, t):
         if not (t.is_cuda and t.is_contiguous() and t.element_size() == 8):
             raise RingError("expected a contiguous CUDA tensor of 8-byte integers")
+        if t.device.index != self.device:
+            raise RingError("tensor lives on cuda:%d, this context on cuda:%d" % (t.device.index, self.device))
         return ctypes.c_void_p(t.data_ptr()), t.numel()
 
-    @staticmethod
-    def _stream(stream):
+    def _stream(self, stream):
         import torch
 
-        s = stream if stream is not None else torch.cuda.current_stream()
+        s = stream if stream is not None else torch.cuda.current_stream(self.device)
+        if s.device.index != self.device:
+            raise RingError("stream belongs to cuda:%d, this context to cuda:%d" % (s.device.index, self.device))
         return ctypes.c_void_p(s.cuda_stream)
+
+    def reserve_scratch(self, batch):
+        """sr_ctx_reserve_scratch: pre-size the operand scratch so that no later mul_dev of up to `batch` elements blocks."""
+        self._check(self._lib.sr_ctx_reserve_scratch(self._ctx, int(batch)))
 
     def elementwise_crt_dev(self, t, stream=None):
         p, n = self._dev(t)
@@ -435,8 +444,19 @@ class CyclotomicRing:
         self._check(self._lib.sr_wire_invalid_count(self._ctx, ctypes.byref(n), self._stream(stream)))
         return int(n.value)
 
+    def mul_ntt_rhs_dev(self, out, a, b_ntt, stream=None):
+        """out = icrt(crt(a) (.) b_ntt) for b_ntt = crt(b) already in CRT/NTT form (the constant-operand product); a and b_ntt
+        are only read; out may be a."""
+        po, n = self._dev(out)
+        pa, m = self._dev(a)
+        pb, q = self._dev(b_ntt)
+        if not (n == m == q):
+            raise RingError("operand lengths differ")
+        self._check(self._lib.sr_ring_mul_ntt_rhs_batch_dev(self._ctx, po, pa, pb, self._batch_of(n), self._stream(stream)))
+        return out
+
     def mul_dev(self, out, a, b, stream=None):
-        """out = a * b; b is clobbered (holds crt(b)) when D exceeds one LDS tile; out may be a."""
+        """out = a * b (RqPoly * &RqPoly, coeff_form.rs:250-258); a and b are only read; out may be a."""
         po, n = self._dev(out)
         pa, m = self._dev(a)
         pb, q = self._dev(b)

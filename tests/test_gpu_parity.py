@@ -1134,3 +1134,130 @@ def test_long_sums_of_extreme_products(torch_cuda, name, k):
             finally:
                 del os.environ["SR_STARK_LAZY"]
     assert rinv  # (Montgomery images cancel: products of images are taken by the kernels' own boundary product)
+
+
+# ----------------------------------------------------------------------------- round 2: operands are never written; constant-operand product
+def _plan(**kw):
+    from stark_rings_amd import _lib
+
+    p = _lib.Plan()
+    for key, val in kw.items():
+        setattr(p, key, val)
+    return p
+
+
+_PLANS_INTACT = [
+    ("goldilocks", 13, {}), ("goldilocks", 16, {}), ("goldilocks", 17, {}), ("goldilocks", 16, {"flags": 2}),   # 2 = SR_PLAN_GL_NO_COLS256
+    ("goldilocks", 14, {"flags": 1}), ("goldilocks", 16, {"flags": 8}),                                         # generic kernels; register-tiled
+    ("babybear", 16, {}), ("babybear", 14, {}), ("babybear", 13, {"flags": 1}), ("babybear", 16, {"flags": 4}),
+    ("stark", 12, {}), ("stark", 13, {}), ("stark", 12, {"flags": 32}), ("stark", 11, {"flags": 16}), ("stark", 12, {"stark_whole_max": 12}),
+]
+
+
+@pytest.mark.parametrize("name,k,plan", _PLANS_INTACT)
+def test_ring_mul_leaves_both_operands_intact(torch_cuda, name, k, plan):
+    """coeff_form.rs:250-258: `a * &b` never mutates an operand.  Every prime, D above one tile, every kernel plan: a and b are
+    bit-identical after the call, and ONE b multiplied into several a gives the oracle's products each time."""
+    torch = torch_cuda
+    from stark_rings_amd import CyclotomicRing
+
+    F = O.FIELD_ID[name]
+    ring = CyclotomicRing(name, k, device=0, plan=_plan(**plan))
+    batch = 3
+    n = batch << k
+    b = O.fill_uniform(F, 77, 0, n)
+    tb = torch.from_numpy(b.view(np.int64)).cuda()
+    for seed in (5, 6):
+        a = O.fill_uniform(F, seed, 0, n)
+        ta = torch.from_numpy(a.view(np.int64)).cuda()
+        out = torch.empty_like(ta)
+        ring.mul_dev(out, ta, tb)
+        torch.cuda.synchronize()
+        assert np.array_equal(tb.cpu().numpy().view(np.uint64), b), "b was written"
+        assert np.array_equal(ta.cpu().numpy().view(np.uint64), a), "a was written"
+        assert np.array_equal(out.cpu().numpy().view(np.uint64), O.pow2_ring_mul(F, a, b, k, batch, 4))
+    # host form, same contract
+    a = O.fill_uniform(F, 9, 0, n)
+    a0, b0 = a.copy(), b.copy()
+    got = ring.mul(a, b)
+    assert np.array_equal(a, a0) and np.array_equal(b, b0)
+    assert np.array_equal(got, O.pow2_ring_mul(F, a, b, k, batch, 4))
+    ring.close()
+
+
+@pytest.mark.parametrize("name,k", [("goldilocks", 16), ("goldilocks", 13), ("stark", 12), ("babybear", 13)])
+def test_ring_mul_in_chunks_of_the_operand_scratch(torch_cuda, name, k):
+    """A scratch cap below the batch (sr_plan.scratch_limit_bytes / chunk_polys) cuts the product into chunks: same results,
+    ragged last chunk included; sr_ctx_reserve_scratch pre-sizes the scratch."""
+    torch = torch_cuda
+    from stark_rings_amd import CyclotomicRing
+
+    F = O.FIELD_ID[name]
+    L = O.LIMBS[F]
+    batch = 7
+    elem_bytes = (8 * L) << k
+    flags = 1 if name == "babybear" else 0   # BabyBear's register-tiled path owns packed scratch of its own: test the generic path here
+    for plan in (_plan(flags=flags, scratch_limit_bytes=3 * elem_bytes), _plan(flags=flags, chunk_polys=2)):
+        ring = CyclotomicRing(name, k, device=0, plan=plan)
+        ring.reserve_scratch(batch)
+        n = batch << k
+        a = O.fill_uniform(F, 21, 0, n)
+        b = O.fill_uniform(F, 22, 0, n)
+        ta = torch.from_numpy(a.view(np.int64)).cuda()
+        tb = torch.from_numpy(b.view(np.int64)).cuda()
+        out = torch.empty_like(ta)
+        ring.mul_dev(out, ta, tb)
+        torch.cuda.synchronize()
+        assert np.array_equal(out.cpu().numpy().view(np.uint64), O.pow2_ring_mul(F, a, b, k, batch, 4))
+        assert np.array_equal(tb.cpu().numpy().view(np.uint64), b)
+        ring.close()
+
+
+_RHS_CASES = [("goldilocks", k) for k in (4, 8, 10, 12, 13, 16, 17)] + [("babybear", 10), ("babybear", 16), ("stark", 4), ("stark", 12),
+                                                                       ("goldilocks24", 0), ("babybear72", 0), ("frog16", 0)]
+
+
+@pytest.mark.parametrize("name,k", _RHS_CASES)
+def test_ring_mul_with_ntt_form_rhs(torch_cuda, name, k):
+    """sr_ring_mul_ntt_rhs_batch_dev: out = icrt(crt(a) (.) b_ntt) == a * b for b_ntt = crt(b) -- the constant-operand product
+    (one transform fewer); fused on the tuned Goldilocks path, composed elsewhere.  a and b_ntt are only read; ragged batch."""
+    torch = torch_cuda
+    ring = ring_for(name, k)
+    w = ring.words_per_elem
+    batch = 5
+    base = {"goldilocks24": "goldilocks", "babybear72": "babybear", "frog16": "frog"}.get(name, name)
+    F = O.FIELD_ID[base]
+    a = O.fill_uniform(F, 31, 0, batch * ring.degree)
+    b = O.fill_uniform(F, 32, 0, batch * ring.degree)
+    ta = torch.from_numpy(a.view(np.int64)).cuda()
+    tb = torch.from_numpy(b.view(np.int64)).cuda()
+    want = torch.empty_like(ta)
+    ring.mul_dev(want, ta, tb)
+    tbn = tb.clone()
+    ring.elementwise_crt_dev(tbn)
+    keep = tbn.clone()
+    out = torch.empty_like(ta)
+    ring.mul_ntt_rhs_dev(out, ta, tbn)
+    torch.cuda.synchronize()
+    assert torch.equal(out, want)
+    assert torch.equal(tbn, keep), "b_ntt was written"
+    assert np.array_equal(ta.cpu().numpy().view(np.uint64), a), "a was written"
+    # in place on a
+    ring.mul_ntt_rhs_dev(ta, ta, tbn)
+    assert torch.equal(ta, want)
+    assert w * batch == ta.numel()
+
+
+def test_plan_struct_is_validated_and_env_free(torch_cuda):
+    """sr_ctx_create_ex refuses malformed plans; the library exports no behaviour switch through the environment."""
+    from stark_rings_amd import CyclotomicRing, RingError
+
+    for bad in (_plan(flags=1 << 6), _plan(log_tile=7), _plan(log_tile=13), _plan(stark_whole_max=8)):
+        with pytest.raises(RingError):
+            CyclotomicRing("goldilocks", 10, device=0, plan=bad)
+    import glob
+    import os
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for path in glob.glob(os.path.join(root, "stark_rings_amd", "csrc", "*")):
+        assert "getenv" not in open(path).read(), path
