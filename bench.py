@@ -1,8 +1,11 @@
 #!/usr/bin/env python3
 """Headline benchmark: batched ring multiplications c = a * b in Fp[X]/(X^D+1) on MI355X.
 
-  python bench.py --gpus N --steps K --warmup W            (N = 1)
-  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...   (N > 1)
+  python bench.py --gpus N --steps K --warmup W
+      N = 1 runs in this process.  N > 1 without a torchrun environment starts N ranks itself (a child
+      `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ...` of this very script, started
+      BEFORE this process touches HIP) and exits with the child's status.
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...   (what the driver runs; same thing)
 
 One "step" = one pass of the hot path (forward NTT x2, slot product, inverse NTT) over one batch of
 synthetic coefficient vectors already resident in HBM.  Default workload = BASELINE.json configs[1]:
@@ -60,6 +63,38 @@ def usable_cores():
     return int(env) if env else n
 
 
+def source_hash():
+    """sha256 over the kernel sources and the C header: the identity of what the .so was built from.  PMC-derived numbers
+    committed under profiles/ carry the hash they were measured at and are dropped when it differs."""
+    import hashlib
+
+    h = hashlib.sha256()
+    src = os.path.join(ROOT, "stark_rings_amd", "csrc")
+    for name in sorted(os.listdir(src)) + ["../../include/stark_rings_hip.h"]:
+        path = os.path.join(src, name)
+        if os.path.isfile(path):
+            h.update(name.encode())
+            h.update(open(path, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def self_launch(args):
+    """--gpus N > 1 outside torchrun: start the ranks as a child process tree.  Nothing in this process has initialised HIP
+    (no torch.cuda call, no library load), so no exec-after-GPU-init can happen; the child is a plain subprocess."""
+    import socket
+    import subprocess
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -70,7 +105,11 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo for rehearsals)")
+    ap.add_argument("--parity-sample", type=int, default=-1,
+                    help="elements per rank checked bit for bit against the oracle (default: 64 for the D = 2^20 shard, 3 otherwise)")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))
 
     import numpy as np
     import torch
@@ -102,10 +141,16 @@ def main():
     words = batch * ring.words_per_elem
 
     # ---- shared twiddles: rank 0's tables broadcast once over RCCL/xGMI, adopted by every rank ----
+    bcast_bytes = bcast_ms = ranks_seen = None
     if world > 1:
         from stark_rings_amd.sharding import share_twiddles
 
-        share_twiddles(ring, dev)  # non-zero ranks zero their block first: the tables really come from rank 0
+        t_b = time.perf_counter()
+        bcast_bytes = share_twiddles(ring, dev)  # non-zero ranks zero their block first: the tables really come from rank 0
+        bcast_ms = (time.perf_counter() - t_b) * 1e3
+        seen = torch.ones(1, dtype=torch.int64, device=dev if args.backend == "nccl" else "cpu")
+        dist.all_reduce(seen)  # every rank counted once: the process group really spans `world` ranks
+        ranks_seen = int(seen.item())
 
     # ---- synthetic inputs generated on device (counter-based PRNG; rank-disjoint coefficient ranges) ----
     a = torch.empty(words, dtype=torch.int64, device=dev)
@@ -121,7 +166,9 @@ def main():
     ring.mul_dev(a, a, b)
     torch.cuda.synchronize()
     assert ring.count_noncanonical_dev(a) == 0, "non-canonical outputs"
-    sample = sorted({0, batch // 3, batch - 1})
+    n_sample = args.parity_sample if args.parity_sample >= 0 else (64 if k >= 20 else 3)
+    n_sample = min(n_sample, batch)
+    sample = sorted({(i * (batch - 1)) // max(n_sample - 1, 1) for i in range(n_sample)}) if n_sample else []
     sample_out = {e: a[e * wpe:(e + 1) * wpe].cpu().numpy().view(np.uint64).copy() for e in sample}
     rt = a[:min(batch, 8) * wpe].clone()
     ring.elementwise_crt_dev(rt)
@@ -179,6 +226,29 @@ def main():
         copy_kind = max(rates, key=rates.get)
         copy_gbs = rates[copy_kind]
 
+    # ---- parity of this rank's sample against the oracle (CHECKER only, outside every timed region; every rank checks its own
+    #      shard: SURVEY.md 8d asks for >= 64 sampled elements per GPU at D = 2^20) ----
+    parity = None
+    if not args.no_cpu_baseline and sample:
+        import oracle_lib as O  # test infrastructure: used as the checker here and as the timed CPU baseline below, never as product
+
+        F = O.FIELD_ID[ring_name]
+        threads = max(1, usable_cores() // world)
+        ea = np.concatenate([O.fill_uniform(F, 0x5EED0001, first + e * d, d) for e in sample])
+        eb = np.concatenate([O.fill_uniform(F, 0x5EED0002, first + e * d, d) for e in sample])
+        want = O.pow2_ring_mul(F, ea, eb, k, len(sample), threads)
+        bad = [e for i, e in enumerate(sample) if not np.array_equal(sample_out[e], want[i * wpe:(i + 1) * wpe])]
+        ok = torch.tensor([0 if bad else 1], dtype=torch.int64, device=dev if (world > 1 and args.backend == "nccl") else "cpu")
+        if world > 1:
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if bad:
+            print("PARITY FAILURE rank %d: elements %s differ from the oracle" % (rank, bad[:8]), file=sys.stderr)
+        if int(ok.item()) != 1:
+            raise SystemExit("PARITY FAILURE: GPU result differs from the oracle on at least one rank")
+        parity = ("bit-exact vs oracle on %d sampled elements per rank (%d ranks) of the first step; all outputs canonical; "
+                  "icrt(crt(c)) == c" % (len(sample), world))
+        del ea, eb, want
+
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
@@ -194,41 +264,56 @@ def main():
     dom = kern[dom_tag]
     launches_per_step = dom["launches"] / args.steps
     dom_avg_ms = dom["ms"] / dom["launches"]
-    # algorithmic bytes one launch of the dominant kernel is responsible for: the whole batch's 3*D*w,
-    # split over the launches of that kernel in one step
-    alg_bytes_per_launch = bytes_per_mul * batch / launches_per_step
+    # algorithmic bytes of ONE LAUNCH of the dominant kernel = what that kernel itself has to move per ring element (DESIGN.md
+    # section 5): the fused rows kernel reads a, b and writes c (3 D w'); a column pass reads and writes one operand (2 D w').
+    # w' = bytes per coefficient of the buffers THAT kernel touches: 8 (Goldilocks), 32 (Stark), and 4 for BabyBear, whose
+    # kernels between the boundary passes work on the library's packed 32-bit scratch (the 8-byte boundary words appear only
+    # in the column passes: read 8, write 4 forward; read 4, write 8 inverse).
+    wk = {"goldilocks": 8, "babybear": 4, "stark": 32}[ring_name]
+    if dom_tag == "rows":
+        kernel_bytes_per_elem = 3 * d * wk
+    elif ring_name == "babybear":
+        kernel_bytes_per_elem = d * (coeff_bytes + wk)
+    else:
+        kernel_bytes_per_elem = 2 * d * wk
+    if k <= 12 and ring_name != "stark" or launches_per_step == 0:
+        kernel_bytes_per_elem = bytes_per_mul  # one fused launch at the boundary layout
+    alg_bytes_per_launch = kernel_bytes_per_elem * batch / max(launches_per_step, 1e-9) * (2 if dom_tag == "fwd_cols" else 1)
     achieved_gbs = alg_bytes_per_launch / (dom_avg_ms * 1e-3) / 1e9
     step_gbs = bytes_per_mul * batch * world / (elapsed / args.steps) / 1e9 / world
 
-    # HBM traffic of the dominant kernel per launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE /
-    # WRITE_SIZE in their own runs, FETCH_SIZE doubled per MI355X_MICROARCH.md): profiles/<round>/traffic.json
-    traffic = None
-    step_traffic = None  # measured HBM bytes of one whole step (every launch), for the achieved-bandwidth figure
+    # HBM traffic (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in their own passes, FETCH_SIZE doubled per MI355X_MICROARCH.md) and
+    # dynamic VALU instructions per wave (SQ counter pass) are NOT measured in this run: they are replayed from
+    # profiles/<round>/pmc_<workload>.json, which records the source hash of the build it was collected on.  A different
+    # hash (any kernel edit since) drops them instead of presenting stale numbers as current.
+    traffic = step_traffic = valu = None
+    traffic_source = "none: no profiles/*/pmc_%s.json" % args.workload
     try:
         rounds = sorted(r for r in os.listdir(os.path.join(ROOT, "profiles")) if r.startswith("r"))
-        tj = json.load(open(os.path.join(ROOT, "profiles", rounds[-1], "traffic.json")))
-        if tj.get("workload") == args.workload and batch == tj.get("batch"):
-            traffic = tj["bytes_per_launch"].get(dom_tag)
-            if all(t in tj["bytes_per_launch"] for t in kern):
-                step_traffic = sum(tj["bytes_per_launch"][t] * kern[t]["launches"] / args.steps for t in kern)
-    except (OSError, ValueError, KeyError, IndexError):
-        pass
-
-    # integer-VALU issue roofline of the same kernel: dynamic VALU instructions per wave (SQ counter pass committed
-    # under profiles/) x waves per launch / measured duration, against one wave-instruction per 4 cycles per SIMD
-    valu = None
-    try:
-        vpath = os.path.join(ROOT, "profiles", rounds[-1], "valu_%s.json" % args.workload)
-        if not os.path.exists(vpath):
-            vpath = os.path.join(ROOT, "profiles", rounds[-1], "valu.json")
-        vj = json.load(open(vpath))
-        if vj.get("workload") == args.workload and batch == vj.get("batch") and dom_tag in vj["kernels"]:
-            kv = vj["kernels"][dom_tag]
-            rate = kv["waves_per_launch"] * kv["valu_per_wave"] / (dom_avg_ms * 1e-3)
-            peak = 256 * 4 * 2.4e9 / 4
-            valu = {"bound": "valu-issue", "achieved": rate, "peak": peak, "unit": "wave-instructions/s", "frac": rate / peak,
-                    "valu_instructions_per_wave": kv["valu_per_wave"], "waves_per_launch": kv["waves_per_launch"],
-                    "note": "supplementary: the path is integer-VALU-bound, see DESIGN.md section 6"}
+        for rnd in reversed(rounds):
+            pj_path = os.path.join(ROOT, "profiles", rnd, "pmc_%s.json" % args.workload)
+            if os.path.exists(pj_path):
+                break
+        pj = json.load(open(pj_path))
+        here = source_hash()
+        if pj.get("batch") != batch:
+            traffic_source = "dropped: %s was collected at batch %s" % (os.path.relpath(pj_path, ROOT), pj.get("batch"))
+        elif pj.get("source_sha256") != here:
+            traffic_source = "dropped (stale): %s was collected at source hash %s, this build is %s" % (
+                os.path.relpath(pj_path, ROOT), pj.get("source_sha256"), here)
+        else:
+            traffic_source = "replayed from %s (source hash %s, commit %s); not measured in this run" % (
+                os.path.relpath(pj_path, ROOT), here, pj.get("commit"))
+            traffic = pj["bytes_per_launch"].get(dom_tag)
+            if all(t in pj["bytes_per_launch"] for t in kern):
+                step_traffic = sum(pj["bytes_per_launch"][t] * kern[t]["launches"] / args.steps for t in kern)
+            if dom_tag in pj.get("valu", {}):
+                kv = pj["valu"][dom_tag]
+                rate = kv["waves_per_launch"] * kv["valu_per_wave"] / (dom_avg_ms * 1e-3)
+                peak = 256 * 4 * 2.4e9 / 4
+                valu = {"bound": "valu-issue", "achieved": rate, "peak": peak, "unit": "wave-instructions/s", "frac": rate / peak,
+                        "valu_instructions_per_wave": kv["valu_per_wave"], "waves_per_launch": kv["waves_per_launch"],
+                        "note": "supplementary, replayed like roofline.traffic: one wave-instruction per 4 cycles per SIMD as the peak"}
     except (OSError, ValueError, KeyError, IndexError, NameError):
         pass
 
@@ -250,11 +335,12 @@ def main():
                    "global_batch": batch * world, "layout": "ark-ff Montgomery u64 limbs, in place (a *= b)",
                    "parallelism": "batch-sharded x%d, twiddle broadcast only" % world},
         "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic,
+                     "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                      "copy_measured": copy_gbs, "copy_measured_kind": copy_kind,
                      "frac_of_copy_measured": achieved_gbs / copy_gbs if copy_gbs else None,
                      "kernel": dom_tag, "kernel_avg_ms": dom_avg_ms, "launches_per_step": launches_per_step,
                      "algorithmic_bytes_per_ring_mul": bytes_per_mul,
+                     "dominant_kernel_bytes_per_ring_mul": kernel_bytes_per_elem,
                      "whole_step_achieved_per_gpu": step_gbs, "whole_step_frac": step_gbs / HBM_PEAK_GBS,
                      # measured HBM traffic of the whole step (PMC passes under profiles/) over the step time: the bandwidth the
                      # step actually draws, as opposed to the algorithmic 3*D*w figure above
@@ -266,17 +352,17 @@ def main():
 
     if valu is not None:
         out["integer_valu"] = valu
+    if parity:
+        out["parity"] = parity
+    if world > 1:
+        out["multi_gpu"] = {"backend": args.backend + (" (RCCL)" if args.backend == "nccl" else ""), "ranks_seen": ranks_seen,
+                            "devices_visible": ndev, "twiddle_broadcast_bytes": bcast_bytes, "twiddle_broadcast_ms": bcast_ms,
+                            "data_path_collectives": 0}
 
     if world == 1 and not args.no_cpu_baseline:
-        import oracle_lib as O  # test infrastructure; used here as CHECKER of the sampled GPU outputs and as the timed CPU baseline
+        import oracle_lib as O  # the timed CPU baseline (the parity check above used it as the checker)
 
         F = O.FIELD_ID[ring_name]
-        for e in sample:
-            ea = O.fill_uniform(F, 0x5EED0001, first + e * d, d)
-            eb = O.fill_uniform(F, 0x5EED0002, first + e * d, d)
-            if not np.array_equal(sample_out[e], O.pow2_ring_mul(F, ea, eb, k)):
-                raise SystemExit("PARITY FAILURE element %d: GPU result differs from the oracle" % e)
-        out["parity"] = "bit-exact vs oracle on elements %s of the first step; all outputs canonical; icrt(crt(c)) == c" % sample
         cores = usable_cores()
         n0 = max(cores, 8)
         ea = O.fill_uniform(F, 1, 0, n0 * d)

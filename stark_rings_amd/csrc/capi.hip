@@ -21,6 +21,7 @@
 #include "ntt_goldilocks.hpp"
 #include "ntt_regtile.hpp"
 #include "small_rings.hpp"
+#include "small_linalg.hpp"
 #include "decompose.hpp"
 #include "wire.hpp"
 #include "frog_ring.hpp"
@@ -345,8 +346,7 @@ int inv_dev(sr_ctx *c, uint64_t *d, size_t batch, hipStream_t st) {
 template <class F>
 int pointwise_dev(sr_ctx *c, uint64_t *lhs, const uint64_t *rhs, size_t n_coeffs, hipStream_t st) {
     if (n_coeffs == 0) return SR_OK;
-    size_t blocks = (n_coeffs + 255) / 256;
-    if (blocks > 8192) blocks = 8192;
+    const unsigned blocks = sr::stream_blocks<F>(n_coeffs);
     ProfScope ps(c, st, K_POINTWISE);
     hipLaunchKernelGGL(sr::pointwise_kernel<F>, dim3((unsigned)blocks), dim3(256), 0, st,
                        reinterpret_cast<typename F::storage *>(lhs),
@@ -357,8 +357,7 @@ int pointwise_dev(sr_ctx *c, uint64_t *lhs, const uint64_t *rhs, size_t n_coeffs
 template <class F>
 int addsub_dev(sr_ctx *c, uint64_t *lhs, const uint64_t *rhs, size_t n_coeffs, bool sub, hipStream_t st) {
     if (n_coeffs == 0) return SR_OK;
-    size_t blocks = (n_coeffs + 255) / 256;
-    if (blocks > 8192) blocks = 8192;
+    const unsigned blocks = sr::stream_blocks<F>(n_coeffs);
     ProfScope ps(c, st, K_POINTWISE);
     auto *l = reinterpret_cast<typename F::storage *>(lhs);
     auto *r = reinterpret_cast<const typename F::storage *>(rhs);
@@ -482,8 +481,7 @@ int reduce_dev(sr_ctx *c, const uint64_t *in, size_t in_len, uint64_t *out, size
     if (in_len > 2 * c->degree) return fail(SR_E_INVALID, "reduce: in_len_per_elem > 2D");
     if (batch == 0) return SR_OK;
     size_t n = batch << c->k;
-    size_t blocks = (n + 255) / 256;
-    if (blocks > 8192) blocks = 8192;
+    const unsigned blocks = sr::stream_blocks<F>(n);
     ProfScope ps(c, st, K_OTHER);
     hipLaunchKernelGGL(sr::reduce_pow2_kernel<F>, dim3((unsigned)blocks), dim3(256), 0, st,
                        reinterpret_cast<const typename F::storage *>(in), in_len,
@@ -839,16 +837,35 @@ int dev_addsub(sr_ctx *c, uint64_t *l, const uint64_t *r, size_t batch, bool sub
         default: return addsub_dev<sr::Stark>(c, l, r, n, sub, st);
     }
 }
+// the three reference-native rings: one slot (Fq3 / Fq9 / Fq4) per lane, small_linalg.hpp
+#define DISPATCH_SLOT(c, CALL)                                                                                   \
+    switch ((c)->ring) {                                                                                         \
+        case SR_RING_GOLDILOCKS_24: { using SL = sr::SlotG24; const auto &K = (c)->small; return (CALL) ? fail(SR_E_HIP, "small-ring launch failed") : SR_OK; } \
+        case SR_RING_BABYBEAR_72: { using SL = sr::SlotB72; const auto &K = (c)->small; return (CALL) ? fail(SR_E_HIP, "small-ring launch failed") : SR_OK; }   \
+        default: { using SL = sr::SlotFrog; const auto &K = (c)->frog; return (CALL) ? fail(SR_E_HIP, "frog-ring launch failed") : SR_OK; }                       \
+    }
 int dev_spmv(sr_ctx *c, uint64_t *y, const uint64_t *vals, const uint32_t *cols, const uint64_t *row_ptr, const uint64_t *v,
              size_t nrows, size_t ncols, hipStream_t st) {
+    if (!is_pow2_ring(c->ring)) {
+        ProfScope ps(c, st, K_OTHER);
+        DISPATCH_SLOT(c, (sr::slot_spmv<SL>(K, y, vals, cols, row_ptr, v, nrows, ncols, c->d_counter + 1, st)));
+    }
     if (c->stark_lazy) return spmv_dev<sr::StarkL>(c, y, vals, cols, row_ptr, v, nrows, ncols, st);  // sums of products on 28-bit lazy limbs (stark_lazy.hpp)
     DISPATCH_POW2(c, (spmv_dev<F>(c, y, vals, cols, row_ptr, v, nrows, ncols, st)));
 }
 int dev_matmul(sr_ctx *c, uint64_t *y, const uint64_t *a, const uint64_t *b, size_t n, size_t m, size_t p, hipStream_t st) {
+    if (!is_pow2_ring(c->ring)) {
+        ProfScope ps(c, st, K_OTHER);
+        DISPATCH_SLOT(c, (sr::slot_matmul<SL>(K, y, a, b, n, m, p, st)));
+    }
     if (c->stark_lazy) return matmul_dev<sr::StarkL>(c, y, a, b, n, m, p, st);  // sums of products on 28-bit lazy limbs (stark_lazy.hpp)
     DISPATCH_POW2(c, (matmul_dev<F>(c, y, a, b, n, m, p, st)));
 }
 int dev_matvec(sr_ctx *c, uint64_t *y, const uint64_t *m, const uint64_t *v, size_t nrows, size_t ncols, hipStream_t st) {
+    if (!is_pow2_ring(c->ring)) {
+        ProfScope ps(c, st, K_OTHER);
+        DISPATCH_SLOT(c, (sr::slot_matvec<SL>(K, y, m, v, nrows, ncols, st)));
+    }
     if (c->stark_lazy) return matvec_dev<sr::StarkL>(c, y, m, v, nrows, ncols, st);  // sums of products on 28-bit lazy limbs (stark_lazy.hpp)
     DISPATCH_POW2(c, (matvec_dev<F>(c, y, m, v, nrows, ncols, st)));
 }

@@ -202,21 +202,53 @@ __global__ __launch_bounds__(kThreads) void cols_kernel(typename F::storage *a, 
 }
 
 // ---- element-wise kernels ----------------------------------------------------------------
+// Streaming kernels move 16 bytes per lane per access (MI355X_MICROARCH.md: 6.3 TB/s for a float4 copy against ~5 TB/s at
+// 8 B per lane): two coefficients of the one-limb fields as one ulonglong2; a Stark coefficient is two such accesses already.
+// Unaligned buffers and an odd tail fall back to one coefficient per lane.
+template <class F, class Op>
+__device__ __forceinline__ void elementwise2(typename F::storage *lhs, const typename F::storage *rhs, size_t n, Op op) {
+    const size_t gid = blockIdx.x * (size_t)blockDim.x + threadIdx.x, stride = (size_t)gridDim.x * blockDim.x;
+    size_t done = 0;
+    if constexpr (sizeof(typename F::storage) == 8) {
+        if ((((uintptr_t)lhs | (uintptr_t)rhs) & 15u) == 0) {
+            const size_t pairs = n >> 1;
+            ulonglong2 *l2 = reinterpret_cast<ulonglong2 *>(lhs);
+            const ulonglong2 *r2 = reinterpret_cast<const ulonglong2 *>(rhs);
+            for (size_t i = gid; i < pairs; i += stride) {
+                ulonglong2 x = l2[i];
+                const ulonglong2 y = r2[i];
+                typename F::storage xs[2] = {x.x, x.y}, ys[2] = {y.x, y.y};
+                F::store(&xs[0], op(F::load(&xs[0]), F::load(&ys[0])));
+                F::store(&xs[1], op(F::load(&xs[1]), F::load(&ys[1])));
+                x.x = xs[0];
+                x.y = xs[1];
+                l2[i] = x;
+            }
+            done = pairs << 1;
+        }
+    }
+    for (size_t i = done + gid; i < n; i += stride) F::store(lhs + i, op(F::load(lhs + i), F::load(rhs + i)));
+}
 // lhs[i] = lhs[i] * rhs[i] on the in-memory images (ntt_form.rs:177-189)
 template <class F>
-__global__ void pointwise_kernel(typename F::storage *lhs, const typename F::storage *rhs, size_t n) {
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
-        F::store(lhs + i, F::mul_boundary(F::load(lhs + i), F::load(rhs + i)));
+__global__ __launch_bounds__(256) void pointwise_kernel(typename F::storage *lhs, const typename F::storage *rhs, size_t n) {
+    elementwise2<F>(lhs, rhs, n, [](const typename F::elem &a, const typename F::elem &b) { return F::mul_boundary(a, b); });
 }
 
 // lhs[i] = lhs[i] +- rhs[i] coefficient-wise: RqNTT / RqPoly Add and Sub (ntt_form.rs:227-285, 588-638; coeff_form.rs
 // operator impls) -- the same in either form and for every ring, the slots being Fp-vector spaces
 template <class F, bool SUB>
-__global__ void addsub_kernel(typename F::storage *lhs, const typename F::storage *rhs, size_t n) {
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-        typename F::elem a = F::load(lhs + i), b = F::load(rhs + i);
-        F::store(lhs + i, SUB ? F::sub(a, b) : F::add(a, b));
-    }
+__global__ __launch_bounds__(256) void addsub_kernel(typename F::storage *lhs, const typename F::storage *rhs, size_t n) {
+    elementwise2<F>(lhs, rhs, n, [](const typename F::elem &a, const typename F::elem &b) { return SUB ? F::sub(a, b) : F::add(a, b); });
+}
+// workgroups for a streaming kernel over n coefficients: one 16-byte access per lane where the field allows it, a grid-stride
+// loop beyond 2^20 workgroups
+template <class F>
+inline unsigned stream_blocks(size_t n) {
+    const size_t per_lane = sizeof(typename F::storage) == 8 ? 2 : 1;
+    size_t blocks = ((n + per_lane - 1) / per_lane + 255) / 256;
+    if (blocks > ((size_t)1 << 20)) blocks = (size_t)1 << 20;
+    return (unsigned)(blocks ? blocks : 1);
 }
 
 // sum_i a_i b_i on memory images (== sum_i mul_boundary(a_i, b_i)) for the linear-algebra kernels below.
@@ -378,13 +410,45 @@ __global__ void rot_kernel(typename F::storage *out, const typename F::storage *
     }
 }
 
-// out[e][i] = in[e][i] - in[e][D + i]   (stark_prime/mod.rs:40-47); in_len <= 2D per element
+// out[e][i] = in[e][i] - in[e][D + i]   (stark_prime/mod.rs:40-47); in_len <= 2D per element.  Two coefficients (16 bytes) per
+// lane for the one-limb fields when every row of `in` and `out` is 16-byte aligned (even in_len, D >= 2).
 template <class F>
-__global__ void reduce_pow2_kernel(const typename F::storage *in, size_t in_len, typename F::storage *out, int k,
-                                   size_t batch) {
+__global__ __launch_bounds__(256) void reduce_pow2_kernel(const typename F::storage *in, size_t in_len, typename F::storage *out,
+                                                          int k, size_t batch) {
     const size_t d = (size_t)1 << k;
     const size_t n = batch << k;
-    for (size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x; t < n; t += (size_t)gridDim.x * blockDim.x) {
+    const size_t gid = blockIdx.x * (size_t)blockDim.x + threadIdx.x, stride = (size_t)gridDim.x * blockDim.x;
+    if constexpr (sizeof(typename F::storage) == 8) {
+        if (k >= 1 && (in_len & 1) == 0 && ((((uintptr_t)in | (uintptr_t)out) & 15u) == 0)) {
+            for (size_t t2 = gid; t2 < (n >> 1); t2 += stride) {
+                const size_t t = t2 << 1, e = t >> k, i = t & (d - 1);
+                const typename F::storage *src = in + e * in_len;
+                typename F::storage lo[2] = {0, 0}, hi[2] = {0, 0};
+                if (i < in_len) {
+                    const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(src + i);
+                    lo[0] = v.x;
+                    lo[1] = v.y;
+                }
+                typename F::elem r0 = i < in_len ? F::load(&lo[0]) : F::zero(), r1 = i < in_len ? F::load(&lo[1]) : F::zero();
+                if (d + i < in_len) {
+                    const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(src + d + i);
+                    hi[0] = v.x;
+                    hi[1] = v.y;
+                    r0 = F::sub(r0, F::load(&hi[0]));
+                    r1 = F::sub(r1, F::load(&hi[1]));
+                }
+                typename F::storage o[2];
+                F::store(&o[0], r0);
+                F::store(&o[1], r1);
+                ulonglong2 w;
+                w.x = o[0];
+                w.y = o[1];
+                *reinterpret_cast<ulonglong2 *>(out + t) = w;
+            }
+            return;
+        }
+    }
+    for (size_t t = gid; t < n; t += stride) {
         size_t e = t >> k, i = t & (d - 1);
         const typename F::storage *src = in + e * in_len;
         typename F::elem lo = i < in_len ? F::load(src + i) : F::zero();

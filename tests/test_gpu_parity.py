@@ -1261,3 +1261,77 @@ def test_plan_struct_is_validated_and_env_free(torch_cuda):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     for path in glob.glob(os.path.join(root, "stark_rings_amd", "csrc", "*")):
         assert "getenv" not in open(path).read(), path
+
+
+# ----------------------------------------------------------------------------- round 2: linear algebra over the reference's own RqNTT types
+_SMALL_LA = [("goldilocks24", "goldilocks", "sro_g24_ntt_mul"), ("babybear72", "babybear", "sro_bb72_ntt_mul"), ("frog16", "frog", "sro_frog16_ntt_mul")]
+
+
+def _oracle_slot_dot(fn, F, p, rows_m, vec, d):
+    """sum_c M[c] * v[c] for ring elements in NTT form: oracle slot products (Fq3 / Fq9 / Fq4), coefficient-wise integer sums."""
+    acc = [0] * d
+    for mc, vc in zip(rows_m, vec):
+        prod = O.from_mont(F, O.small(fn, mc, vc))
+        acc = [(x + y) % p for x, y in zip(acc, prod)]
+    return acc
+
+
+@pytest.mark.parametrize("name,base,fn", _SMALL_LA)
+def test_linear_algebra_over_the_reference_rings(torch_cuda, name, base, fn):
+    """Matrix<R>::checked_mul_vec / checked_mul_mat (matrix.rs:148-178) and SparseMatrix<R>::checked_mul_vec
+    (sparse_matrix.rs:201-212) for R = the RqNTT types the reference actually ships (Fq3 / Fq9 / Fq4 slots): every output is the
+    oracle's slot products summed as integers.  Inner dimension 41 with every coefficient p - 1, then random."""
+    torch = torch_cuda
+    F = O.FIELD_ID[base]
+    p = P.PRIMES[base][0]
+    ring = ring_for(name, 0)
+    d = ring.degree
+    nrows, ncols = 3, 41
+    for case in range(2):
+        if case == 0:
+            m = O.to_mont(F, [p - 1] * (nrows * ncols * d))
+            v = O.to_mont(F, [p - 1] * (ncols * d))
+        else:
+            m = O.fill_uniform(F, 0x51, 0, nrows * ncols * d)
+            v = O.fill_uniform(F, 0x52, 0, ncols * d)
+        el = lambda buf, i: buf[i * d:(i + 1) * d]
+        want = []
+        for r in range(nrows):
+            want += _oracle_slot_dot(fn, F, p, [el(m, r * ncols + c) for c in range(ncols)], [el(v, c) for c in range(ncols)], d)
+        got = ring.matvec_ntt(m, v, nrows, ncols)
+        assert O.from_mont(F, got) == want, (name, case)
+        assert np.array_equal(ring.matmul_ntt(m, v, nrows, ncols, 1), got)
+        # (2 x 41) (41 x 3): B's columns are v, 2v (= v + v) and v again
+        v2 = ring.add(v.copy(), v)
+        b = np.concatenate([np.concatenate([el(v, c), el(v2, c), el(v, c)]) for c in range(ncols)])
+        y = ring.matmul_ntt(m[:2 * ncols * d], b, 2, ncols, 3)
+        for i in range(2):
+            row = O.from_mont(F, got[i * d:(i + 1) * d])
+            assert O.from_mont(F, el(y, i * 3 + 0)) == row and O.from_mont(F, el(y, i * 3 + 2)) == row
+            assert O.from_mont(F, el(y, i * 3 + 1)) == [(2 * x) % p for x in row]
+        # sparse: row 0 = dense row 0 with bad columns mixed in (skipped + counted), row 1 empty, row 2 = two entries
+        tv = torch.from_numpy(v.view(np.int64)).cuda()
+        cols = list(range(ncols))
+        vals = [el(m, c) for c in range(ncols)]
+        for at in (2, 17):
+            cols.insert(at, ncols + 1)
+            vals.insert(at, el(m, 0))
+        cols += [5, 40]
+        vals += [el(m, 7), el(m, 9)]
+        tvals = torch.from_numpy(np.concatenate(vals).view(np.int64)).cuda()
+        tcols = torch.tensor(cols, dtype=torch.int32, device="cuda")
+        tptr = torch.tensor([0, ncols + 2, ncols + 2, ncols + 4], dtype=torch.int64, device="cuda")
+        ty = torch.empty(3 * d, dtype=torch.int64, device="cuda")
+        ring.spmv_ntt_dev(ty, tvals, tcols, tptr, tv, 3, ncols)
+        assert ring.spmv_bad_index_count() == 2
+        sy = ty.cpu().numpy().view(np.uint64)
+        assert np.array_equal(sy[:d], got[:d])
+        assert not sy[d:2 * d].any()
+        assert O.from_mont(F, sy[2 * d:]) == _oracle_slot_dot(fn, F, p, [el(m, 7), el(m, 9)], [el(v, 5), el(v, 40)], d)
+    # host sparse form refuses an out-of-range column (the reference panics on v[col]); empty shapes
+    from stark_rings_amd import RingError
+    with pytest.raises(RingError):
+        ring.spmv_ntt([[(el(m, 0), ncols)]], v, ncols)
+    assert ring.matvec_ntt(np.zeros(0, dtype=np.uint64), np.zeros(0, dtype=np.uint64), 0, 0).size == 0
+    z = ring.matvec_ntt(np.zeros(0, dtype=np.uint64), np.zeros(0, dtype=np.uint64), 2, 0)
+    assert z.size == 2 * d and not z.any()

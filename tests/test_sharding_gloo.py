@@ -76,3 +76,26 @@ def test_two_rank_shards_reassemble_to_the_unsharded_result(tmp_path, world, bat
     a = O.fill_uniform(F, 0x5EED0001, 0, batch << k)
     b = O.fill_uniform(F, 0x5EED0002, 0, batch << k)
     assert np.array_equal(got, O.pow2_ring_mul(F, a, b, k, batch, 2))
+
+
+@pytest.mark.gpu
+def test_bench_launches_its_own_ranks_and_checks_every_shard():
+    """`python bench.py --gpus 2` with no torchrun environment: bench.py starts the two ranks itself (a child torch.distributed.run,
+    before the parent touches HIP), both ranks share the one GPU of the test box over gloo, each checks a sample of ITS shard
+    against the oracle, and rank 0 prints one JSON line for the whole job."""
+    import json
+    import subprocess
+
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--batch", "6", "--steps", "2",
+           "--warmup", "1", "--parity-sample", "6", "--cpu-seconds", "0.5"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 12
+    assert d["multi_gpu"]["ranks_seen"] == 2 and d["multi_gpu"]["data_path_collectives"] == 0
+    assert d["multi_gpu"]["twiddle_broadcast_bytes"] > 0
+    assert "6 sampled elements per rank (2 ranks)" in d["parity"]
+    assert d["value"] > 0

@@ -1,0 +1,154 @@
+#!/usr/bin/env python3
+"""rocprofv3 passes for one bench.py workload, and their summary.
+
+  on the GPU box (counters in their own passes, as MI355X_MICROARCH.md prescribes; the program after `--` is python3 itself):
+      python3 tools/profile_workload.py collect <workload> gpurun_out/prof_<workload> [--steps 3]
+  anywhere (reads the CSVs the collect step left, writes profiles/<round>/pmc_<workload>.json + kernel_stats + a markdown section):
+      python3 tools/profile_workload.py summarize gpurun_out/prof_<workload> <workload> profiles/r02
+
+pmc_<workload>.json carries the source hash of the build it was collected on (bench.py:source_hash); bench.py replays its
+numbers only while the hash matches.
+"""
+import collections
+import csv
+import glob
+import json
+import os
+import re
+import shutil
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+PASSES = {
+    "trace": ["--kernel-trace", "--stats"],
+    "pmc_FETCH_SIZE": ["--pmc", "FETCH_SIZE"],
+    "pmc_WRITE_SIZE": ["--pmc", "WRITE_SIZE"],
+    "pmc_SQ": ["--pmc", "SQ_WAVES", "SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAIT_INST_ANY",
+               "SQ_ACTIVE_INST_ANY", "SQ_INSTS_LDS"],
+}
+
+
+def collect(workload, outdir, steps):
+    os.makedirs(outdir, exist_ok=True)
+    env = dict(os.environ, TMPDIR="/tmp")
+    for name, flags in PASSES.items():
+        d = os.path.join(outdir, name)
+        shutil.rmtree(d, ignore_errors=True)
+        cmd = ["rocprofv3"] + flags + ["--output-format", "csv", "-d", d, "-o", "p", "--", "python3", os.path.join(ROOT, "bench.py"),
+               "--workload", workload, "--steps", str(steps if name == "trace" else 2), "--warmup", "1", "--no-cpu-baseline"]
+        print("+", " ".join(cmd), flush=True)
+        with open(os.path.join(outdir, name + ".bench.json"), "w") as fo, open(os.path.join(outdir, name + ".err"), "w") as fe:
+            rc = subprocess.call(cmd, env=env, stdout=fo, stderr=fe, cwd="/tmp")
+        if rc:
+            print("pass %s failed (rc %d), see %s" % (name, rc, os.path.join(outdir, name + ".err")))
+            return rc
+        for f in glob.glob(os.path.join(d, "**", "*.csv"), recursive=True):
+            base = os.path.basename(f)
+            kind = "kernel_stats" if "kernel_stats" in base else ("kernel_trace" if "kernel_trace" in base else
+                                                                   ("counters" if "counter_collection" in base else None))
+            if kind:
+                shutil.copy(f, os.path.join(outdir, "%s.%s.csv" % (name, kind)))
+        shutil.rmtree(d, ignore_errors=True)
+    return 0
+
+
+def tag_of(kernel):
+    """bench.py's profile tag of a kernel name (the library brackets the same launches with the same tags)."""
+    k = kernel.replace("void ", "")
+    if "build" in k or "fill_uniform" in k or "count_noncanonical" in k or "addsub" in k or "__amd" in k:
+        return None
+    m = re.match(r"sr::gl::cols256_kernel<(\d)", k) or re.match(r"sr::gl::strided\w*_kernel<(?:\d+, )?(\d)", k)
+    if m:
+        return "fwd_cols" if m.group(1) == "0" else "inv_cols"
+    m = re.match(r"sr::rt::(?:cols256|strided)_kernel<sr::\w+, (?:\d+, )?(\d)", k)
+    if m:
+        return "fwd_cols" if m.group(1) == "0" else "inv_cols"
+    m = re.match(r"sr::st::cols_kernel<\d+, (?:\(sr::\w+\))?(\d)", k)
+    if m:
+        return "fwd_cols" if m.group(1) == "0" else "inv_cols"
+    m = re.match(r"sr::cols_kernel<sr::\w+, (?:\(sr::\w+\))?(\d)", k)
+    if m:
+        return "fwd_cols" if m.group(1) == "0" else "inv_cols"
+    if re.match(r"sr::(gl::rows|rt::rows|st::tile_kernel|rows_kernel)", k):
+        return "rows"
+    return None
+
+
+def full_batch(rows, grid_key):
+    """keep the full-batch launches only (bench.py's property gate also runs a few tiny ones)."""
+    full = collections.defaultdict(int)
+    for r in rows:
+        full[r["Kernel_Name"]] = max(full[r["Kernel_Name"]], int(r[grid_key]))
+    return [r for r in rows if int(r[grid_key]) == full[r["Kernel_Name"]]]
+
+
+def summarize(indir, workload, outdir):
+    import bench
+
+    os.makedirs(outdir, exist_ok=True)
+    batch = bench.WORKLOADS[workload][2]
+    md = ["## %s\n" % workload]
+    # kernel durations (trace pass)
+    shutil.copy(os.path.join(indir, "trace.kernel_stats.csv"), os.path.join(outdir, "kernel_stats_%s.csv" % workload))
+    trace = list(csv.DictReader(open(os.path.join(indir, "trace.kernel_trace.csv"))))
+    gk = "Grid_Size_X" if "Grid_Size_X" in trace[0] else "Grid_Size"
+    dur = collections.defaultdict(list)
+    for r in full_batch(trace, gk):
+        dur[r["Kernel_Name"]].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+    md.append("| kernel | tag | full-batch launches | avg ms |\n|---|---|---|---|")
+    for kname, v in sorted(dur.items(), key=lambda kv: -sum(kv[1])):
+        if tag_of(kname) or "addsub" in kname:
+            md.append("| `%s` | %s | %d | %.3f |" % (kname.split("(")[0].replace("void ", ""), tag_of(kname), len(v), sum(v) / len(v) / 1e6))
+    # counters
+    agg = {}
+    for cn in ("FETCH_SIZE", "WRITE_SIZE"):
+        rows = list(csv.DictReader(open(os.path.join(indir, "pmc_%s.counters.csv" % cn))))
+        dd = collections.defaultdict(list)
+        for r in full_batch(rows, "Grid_Size"):
+            if r["Counter_Name"] == cn:
+                dd[r["Kernel_Name"]].append(float(r["Counter_Value"]))
+        agg[cn] = {k: sum(v) / len(v) for k, v in dd.items()}
+        shutil.copy(os.path.join(indir, "pmc_%s.counters.csv" % cn), os.path.join(outdir, "pmc_%s_%s.csv" % (cn, workload)))
+    sq = collections.defaultdict(lambda: collections.defaultdict(list))
+    rows = list(csv.DictReader(open(os.path.join(indir, "pmc_SQ.counters.csv"))))
+    for r in full_batch(rows, "Grid_Size"):
+        sq[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    shutil.copy(os.path.join(indir, "pmc_SQ.counters.csv"), os.path.join(outdir, "pmc_SQ_%s.csv" % workload))
+    bytes_per_launch, valu = {}, {}
+    md.append("\n| kernel | tag | 2 x FETCH_SIZE (GiB) | WRITE_SIZE (GiB) | waves | VALU / wave | SALU / wave |\n|---|---|---|---|---|---|---|")
+    for kname in sorted(agg["FETCH_SIZE"]):
+        t = tag_of(kname)
+        if not t:
+            continue
+        f, w = 2 * agg["FETCH_SIZE"][kname] * 1024, agg["WRITE_SIZE"].get(kname, 0) * 1024  # the CSVs are in KiB
+        bytes_per_launch.setdefault(t, []).append(f + w)
+        c = sq.get(kname, {})
+        waves = sum(c.get("SQ_WAVES", [0])) / max(1, len(c.get("SQ_WAVES", [0])))
+        vpw = sum(c.get("SQ_INSTS_VALU", [0])) / max(1, len(c.get("SQ_INSTS_VALU", [0]))) / max(waves, 1)
+        spw = sum(c.get("SQ_INSTS_SALU", [0])) / max(1, len(c.get("SQ_INSTS_SALU", [0]))) / max(waves, 1)
+        if waves:
+            valu.setdefault(t, []).append((waves, vpw))
+        md.append("| `%s` | %s | %.2f | %.2f | %d | %.0f | %.0f |" % (kname.split("(")[0].replace("void ", ""), t, f / 2**30, w / 2**30, waves, vpw, spw))
+    commit = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
+    pj = {"workload": workload, "batch": batch, "source_sha256": bench.source_hash(), "commit": commit,
+          "unit": "bytes of HBM traffic per launch, 2 * FETCH_SIZE + WRITE_SIZE (MI355X_MICROARCH.md: FETCH_SIZE counts half of a streaming read on gfx950); a tag with several passes per transform sums them",
+          "bytes_per_launch": {t: int(sum(v)) if t != "rows" and len(v) > 1 else int(sum(v) / len(v)) for t, v in bytes_per_launch.items()},
+          "valu": {t: {"waves_per_launch": int(sum(w for w, _ in v) / len(v)), "valu_per_wave": round(sum(x for _, x in v) / len(v), 1)}
+                   for t, v in valu.items()}}
+    json.dump(pj, open(os.path.join(outdir, "pmc_%s.json" % workload), "w"), indent=1)
+    for name in ("trace", "pmc_SQ"):
+        src = os.path.join(indir, name + ".bench.json")
+        if os.path.exists(src) and os.path.getsize(src):
+            shutil.copy(src, os.path.join(outdir, "bench_under_%s_%s.json" % (name, workload)))
+    open(os.path.join(outdir, "summary_%s.md" % workload), "w").write("\n".join(md) + "\n")
+    print("\n".join(md))
+
+
+if __name__ == "__main__":
+    if sys.argv[1] == "collect":
+        steps = int(sys.argv[sys.argv.index("--steps") + 1]) if "--steps" in sys.argv else 3
+        sys.exit(collect(sys.argv[2], sys.argv[3], steps))
+    summarize(sys.argv[2], sys.argv[3], sys.argv[4])
