@@ -162,8 +162,9 @@ int sr_rot_batch(sr_ctx *ctx, uint64_t *data, size_t batch);
  * form: digit j of element e is ring element e * padding_size + j of d_out (batch * padding_size elements) --
  * GadgetDecompose for &[R] (crates/ring/src/balanced_decomposition/mod.rs:163-175) over Decompose for the ring
  * (cyclotomic_ring/coeff_form.rs:587-605) over decompose_balanced_in_place (mod.rs:62-117; signed representative
- * fq_convertible.rs:21-35, stark_prime/decomposition.rs:41-53).  basis: even, 2 <= basis <= 2^32 (the reference takes u128 and
- * panics on 0, 1 and odd values: SR_E_INVALID here).  Every ring id; digits are field elements in the same Montgomery
+ * fq_convertible.rs:21-35, stark_prime/decomposition.rs:41-53).  basis: any even value in [2, 2^64) (the reference takes a u128
+ * and panics on 0, 1 and odd values: SR_E_INVALID here; a basis of 2^64 or more, which only the 252-bit prime could use, is the
+ * one remaining narrowing).  Every ring id; digits are field elements in the same Montgomery
  * layout.  A coefficient that needs more than padding_size digits makes the reference panic (out[i] out of bounds): the
  * device form writes the first padding_size digits and counts it (sr_decompose_overflow_count reads and clears the count,
  * synchronising the stream); the host form returns SR_E_INVALID. */

@@ -755,7 +755,6 @@ int dev_rot(sr_ctx *c, uint64_t *out, const uint64_t *in, size_t batch, hipStrea
 int check_basis(uint64_t b) {
     if (b < 2) return fail(SR_E_INVALID, "cannot decompose in basis 0 or 1");              // mod.rs:63-66
     if (b & 1) return fail(SR_E_INVALID, "decomposition basis must be even");              // mod.rs:69
-    if (b > (1ull << 32)) return fail(SR_E_INVALID, "decomposition basis above 2^32 is not supported");
     return SR_OK;
 }
 int dev_decompose(sr_ctx *c, uint64_t *out, const uint64_t *in, uint64_t b, size_t k, size_t batch, hipStream_t st) {
@@ -1202,7 +1201,6 @@ int sr_recompose_batch_dev(sr_ctx *c, uint64_t *out, const uint64_t *in, uint64_
                            void *stream) {
     if (int rc = check(c, out, in)) return rc;
     if (int rc = check_count(c, batch_out, padding_size)) return rc;
-    if (basis > (1ull << 32)) return fail(SR_E_INVALID, "recomposition basis above 2^32 is not supported");
     if (out == in) return fail(SR_E_INVALID, "recompose: out must not alias in");
     std::lock_guard<std::mutex> lk(c->mu);
     DeviceGuard g(c->device);
@@ -1354,7 +1352,6 @@ int sr_deserialize_batch(sr_ctx *c, uint64_t *out, const uint8_t *wire, size_t b
 int sr_recompose_batch(sr_ctx *c, uint64_t *out, const uint64_t *in, uint64_t basis, size_t padding_size, size_t batch_out) {
     if (int rc = check(c, out, in)) return rc;
     if (int rc = check_count(c, batch_out, padding_size)) return rc;
-    if (basis > (1ull << 32)) return fail(SR_E_INVALID, "recomposition basis above 2^32 is not supported");
     std::lock_guard<std::mutex> lk(c->mu);
     DeviceGuard g(c->device);
     const size_t w = c->degree * c->limbs * 8;

@@ -11,8 +11,10 @@
 // otherwise the digit is -(sign)(b - rem) and the quotient moves one away from zero.  Digits go back to Montgomery form
 // (d * R = mul_boundary(d, R^2)) and are written digit-major: digit j of element e is ring element e * k + j of `out`, so the
 // stores of a wave are contiguous.  Memory-bound: D w bytes in, k D w bytes out per element.
-// Basis: even, 2 <= b <= 2^32 (the reference takes a u128; gadget bases in its tests are 2 .. 2^16).  A power of two is
-// a shift and a mask; any other even basis pays an integer division per digit (per 32-bit limb for Stark).
+// Basis: any even b in [2, 2^64) (the reference takes a u128; its gadget bases are 2 .. 2^16; a basis of 2^64 or more is the one
+// remaining narrowing, and only the 252-bit Stark prime could use it).  A power of two is a shift and a mask; any other even
+// basis pays an integer division per digit (Stark: per 32-bit limb, a 64 / 32-bit division while b <= 2^32 and a restoring
+// 96 / 64-bit division above).
 #pragma once
 #include <type_traits>
 
@@ -115,20 +117,20 @@ struct Mag<Stark> {
     }
     SR_HD uint64_t divrem(uint64_t b, int log2b) {
         uint64_t rem;
-        if (log2b >= 0 && log2b <= 32) {
-            rem = log2b == 32 ? (uint64_t)m.l[0] : (uint64_t)(m.l[0] & (uint32_t)(b - 1));
-            if (log2b == 32) {
+        if (log2b >= 0) {  // power of two, 2^1 .. 2^63: a mask and a shift over the limbs
+            rem = ((uint64_t)m.l[0] | ((uint64_t)m.l[1] << 32)) & (b - 1);
+            const int ws = log2b >> 5, bs = log2b & 31;
+            uint32_t t[10];
 #pragma unroll
-                for (int i = 0; i < 7; i++) m.l[i] = m.l[i + 1];
-                m.l[7] = 0;
-            } else {
+            for (int i = 0; i < 8; i++) t[i] = m.l[i];
+            t[8] = t[9] = 0;
 #pragma unroll
-                for (int i = 0; i < 8; i++) {
-                    const uint32_t hi = i < 7 ? m.l[i + 1] : 0u;
-                    m.l[i] = (uint32_t)((((uint64_t)hi << 32) | m.l[i]) >> log2b);
-                }
+            for (int i = 0; i < 8; i++) {
+                // limb i of (m >> log2b): bits of limbs i + ws and i + ws + 1 (ws is 0 or 1)
+                const uint32_t lo = ws ? t[i + 1] : t[i], hi = ws ? t[i + 2] : t[i + 1];
+                m.l[i] = bs ? (uint32_t)((((uint64_t)hi << 32) | lo) >> bs) : lo;
             }
-        } else {
+        } else if (b <= (1ull << 32)) {
             uint64_t r = 0;  // < b <= 2^32: (r << 32 | limb) fits 64 bits
 #pragma unroll
             for (int i = 7; i >= 0; i--) {
@@ -136,6 +138,26 @@ struct Mag<Stark> {
                 const uint64_t q = cur / b;
                 m.l[i] = (uint32_t)q;
                 r = cur - q * b;
+            }
+            rem = r;
+        } else {
+            // b above 2^32: (r 2^32 + limb) / b with r < b < 2^64 is a 96-by-64-bit division whose quotient fits 32 bits;
+            // restoring division, one quotient bit per step (device code has no 128-bit divide)
+            uint64_t r = 0;
+#pragma unroll 1
+            for (int i = 7; i >= 0; i--) {
+                uint32_t q = 0;
+                const uint32_t limb = m.l[i];
+#pragma unroll 4
+                for (int bit = 31; bit >= 0; bit--) {
+                    const bool carry = (r >> 63) != 0;
+                    r = (r << 1) | ((limb >> bit) & 1u);
+                    if (carry || r >= b) {
+                        r -= b;
+                        q |= 1u << bit;
+                    }
+                }
+                m.l[i] = q;
             }
             rem = r;
         }
@@ -192,8 +214,9 @@ template <class F>
 __global__ __launch_bounds__(256) void recompose_kernel(typename F::storage *out, const typename F::storage *in, size_t d,
                                                         size_t batch_out, uint64_t b, size_t k) {
     const size_t n = batch_out * d;
-    // Montgomery image of R::from(b): b <= 2^32 is below p except for BabyBear
-    const uint64_t bred = std::is_same<F, BabyBear>::value ? b % (uint64_t)BabyBear::P : b;
+    // Montgomery image of R::from(b): b mod p first for the one-limb fields (b < 2^64 may exceed p); b < p for Stark
+    uint64_t bred = b;
+    if constexpr (!std::is_same<F, Stark>::value) bred = b % (uint64_t)F::P;
     const typename F::elem bimg = F::mul_boundary(Consts<F>::from_u64(bred), Consts<F>::r2());
     for (size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x; t < n; t += (size_t)gridDim.x * blockDim.x) {
         const size_t e = t / d, i = t - e * d;

@@ -232,6 +232,69 @@ class CyclotomicRing:
         self._check(self._lib.sr_recompose_batch(self._ctx, _np_ptr(out), _np_ptr(src), basis, padding_size, batch_out))
         return out[:batch_out * self.words_per_elem]
 
+    # -- GadgetDecompose / GadgetRecompose for Matrix<R> and SparseMatrix<R> (balanced_decomposition/mod.rs:276-352) ------------
+    def matrix_gadget_decompose(self, mat, nrows, ncols, basis, padding_size):
+        """Matrix<R> of nrows x ncols ring elements (row-major, coefficient form) -> nrows x (padding_size * ncols): every row
+        is gadget-decomposed as a slice (mod.rs:291-296), i.e. entry (r, c) becomes entries (r, c * k .. c * k + k - 1).  Row-major
+        storage makes this the batch decomposition of the flat element array.  Returns (flat words, nrows, ncols * padding_size)."""
+        if mat.size != nrows * ncols * self.words_per_elem:
+            raise RingError("matrix_gadget_decompose: DifferentLengths")
+        return self.gadget_decompose(mat, basis, padding_size), nrows, ncols * padding_size
+
+    def matrix_gadget_recompose(self, mat, nrows, ncols, basis, padding_size):
+        """Inverse shape map (mod.rs:299-307): nrows x ncols -> nrows x (ncols / padding_size)."""
+        if mat.size != nrows * ncols * self.words_per_elem or padding_size == 0 or ncols % padding_size:
+            raise RingError("matrix_gadget_recompose: ncols is not a multiple of padding_size")
+        return self.gadget_recompose(mat, basis, padding_size), nrows, ncols // padding_size
+
+    def sparse_gadget_decompose(self, rows, ncols, basis, padding_size):
+        """SparseMatrix<R> (rows: list of lists of (element words, column)) -> the same with ncols * padding_size columns
+        (mod.rs:323-336): stored entry (e, c) becomes (digit_i(e), c * k + i) for i < k, zero digits dropped ("maintain full
+        sparsity", mod.rs:208-229).  One batched device decomposition over all stored entries."""
+        w = self.words_per_elem
+        flat = [np.ascontiguousarray(e, dtype=np.uint64) for row in rows for e, _ in row]
+        if any(e.size != w for e in flat):
+            raise RingError("sparse_gadget_decompose: entry is not one ring element")
+        if any(c >= ncols for row in rows for _, c in row):
+            raise RingError("sparse_gadget_decompose: column out of range")
+        digits = self.gadget_decompose(np.concatenate(flat) if flat else np.zeros(0, dtype=np.uint64), basis, padding_size)
+        out, j = [], 0
+        for row in rows:
+            new = []
+            for _, c in row:
+                for i in range(padding_size):
+                    dgt = digits[(j * padding_size + i) * w:(j * padding_size + i + 1) * w]
+                    if dgt.any():               # r != R::zero(): the Montgomery image of zero is all-zero words
+                        new.append((dgt.copy(), c * padding_size + i))
+                j += 1
+            out.append(new)
+        return out, ncols * padding_size
+
+    def sparse_gadget_recompose(self, rows, ncols, basis, padding_size):
+        """mod.rs:231-266, 339-351: consecutive entries whose column / padding_size agree form one original entry; missing
+        digits are zero."""
+        if padding_size == 0 or ncols % padding_size:
+            raise RingError("sparse_gadget_recompose: ncols is not a multiple of padding_size")
+        w = self.words_per_elem
+        groups, shape = [], []
+        for row in rows:
+            cnt, prev = 0, None
+            for e, c in row:
+                idx = c // padding_size
+                if idx != prev:
+                    groups.append((idx, np.zeros(padding_size * w, dtype=np.uint64)))
+                    cnt += 1
+                    prev = idx
+                groups[-1][1][(c % padding_size) * w:(c % padding_size + 1) * w] = e
+            shape.append(cnt)
+        vals = self.gadget_recompose(np.concatenate([g[1] for g in groups]) if groups else np.zeros(0, dtype=np.uint64), basis,
+                                     padding_size)
+        out, j = [], 0
+        for cnt in shape:
+            out.append([(vals[(j + t) * w:(j + t + 1) * w].copy(), groups[j + t][0]) for t in range(cnt)])
+            j += cnt
+        return out, ncols // padding_size
+
     @property
     def wire_coeff_bytes(self):
         """Bytes per coefficient on the ark-serialize wire: 8 (Goldilocks, frog), 4 (BabyBear), 32 (Stark)."""

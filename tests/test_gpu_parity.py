@@ -652,7 +652,7 @@ def test_decomposition_reference_kats_on_gpu(torch_cuda, kats):
 
 
 @pytest.mark.parametrize("name,k", [("goldilocks", 7), ("babybear", 7), ("stark", 4), ("goldilocks24", 0), ("babybear72", 0)])
-@pytest.mark.parametrize("basis", [2, 4, 16, 1 << 16, 10, 1 << 32])
+@pytest.mark.parametrize("basis", [2, 4, 16, 1 << 16, 10, 1 << 32, (1 << 32) + 2, 1 << 40, 3 * (1 << 40) + 10, 1 << 63, (1 << 64) - 2])
 def test_decomposition_matches_oracle(torch_cuda, name, k, basis):
     """test_decompose_balanced / _vec / _polyring (mod.rs:409-467) shapes on every ring: digits equal the oracle's,
     |digit| <= b/2, recompose(decompose(v)) == v; edge coefficients 0, 1, p-1, (p-1)/2, (p-1)/2 + 1."""
@@ -696,7 +696,7 @@ def test_decomposition_errors(torch_cuda):
     ring = ring_for("goldilocks", 7)
     F, p = O.GOLDILOCKS, P.PRIMES["goldilocks"][0]
     a = O.fill_uniform(F, 9, 0, 2 * ring.degree)
-    for bad, msg in ((0, "basis 0 or 1"), (1, "basis 0 or 1"), (7, "must be even"), ((1 << 32) + 2, "not supported")):
+    for bad, msg in ((0, "basis 0 or 1"), (1, "basis 0 or 1"), (7, "must be even"), ((1 << 63) + 1, "must be even")):
         with pytest.raises(RingError, match=msg):
             ring.gadget_decompose(a, bad, 8)
     with pytest.raises(RingError, match="more than padding_size"):
@@ -1335,3 +1335,46 @@ def test_linear_algebra_over_the_reference_rings(torch_cuda, name, base, fn):
     assert ring.matvec_ntt(np.zeros(0, dtype=np.uint64), np.zeros(0, dtype=np.uint64), 0, 0).size == 0
     z = ring.matvec_ntt(np.zeros(0, dtype=np.uint64), np.zeros(0, dtype=np.uint64), 2, 0)
     assert z.size == 2 * d and not z.any()
+
+
+# ----------------------------------------------------------------------------- round 2: GadgetDecompose for Matrix / SparseMatrix
+@pytest.mark.parametrize("name,k,basis,pad", [("goldilocks", 4, 4, 33), ("babybear", 3, 16, 9), ("goldilocks24", 0, 1 << 16, 5), ("stark", 2, 1 << 32, 9)])
+def test_matrix_and_sparse_matrix_gadget_decompose(torch_cuda, name, k, basis, pad):
+    """balanced_decomposition/mod.rs:276-352: Matrix<R> n x m -> n x (k m) row by row; SparseMatrix<R> entry (e, c) ->
+    (digit_i, c k + i) with zero digits dropped; recompose inverts both.  Digits are the oracle's."""
+    base = {"goldilocks24": "goldilocks"}.get(name, name)
+    F = O.FIELD_ID[base]
+    p = P.PRIMES[base][0]
+    ring = ring_for(name, k)
+    d, w = ring.degree, ring.words_per_elem
+    nrows, ncols = 3, 4
+    mat = O.fill_uniform(F, 0x91, 0, nrows * ncols * d)
+    small = O.to_mont(F, [1] + [0] * (d - 1))          # the constant 1: exactly one non-zero digit in any basis
+    mat[5 * w:6 * w] = small
+    dec, r2, c2 = ring.matrix_gadget_decompose(mat, nrows, ncols, basis, pad)
+    assert (r2, c2) == (nrows, ncols * pad)
+    want, over = O.decompose_balanced(F, mat, d, nrows * ncols, basis, pad)
+    assert not over and np.array_equal(dec, want)
+    # entry (r, c) of the input is the recomposition of entries (r, c k .. c k + k - 1) of the output
+    back, r3, c3 = ring.matrix_gadget_recompose(dec, r2, c2, basis, pad)
+    assert (r3, c3) == (nrows, ncols) and np.array_equal(back, mat)
+    # sparse: rows with 2, 0 and 3 stored entries
+    el = lambda i: mat[i * w:(i + 1) * w]
+    rows = [[(el(0), 1), (el(1), 3)], [], [(el(4), 0), (el(5), 2), (el(6), 3)]]
+    srows, sc = ring.sparse_gadget_decompose(rows, ncols, basis, pad)
+    assert sc == ncols * pad and len(srows) == 3 and srows[1] == []
+    for row, srow in zip(rows, srows):
+        exp = []
+        for e, c in row:
+            dg, _ = O.decompose_balanced(F, np.ascontiguousarray(e), d, 1, basis, pad)
+            exp += [(dg[i * w:(i + 1) * w], c * pad + i) for i in range(pad) if dg[i * w:(i + 1) * w].any()]
+        assert len(srow) == len(exp)
+        for (g, gc), (x, xc) in zip(srow, exp):
+            assert gc == xc and np.array_equal(g, x)
+    assert len([1 for e, c in srows[2] if c // pad == 2]) == 1      # the small element keeps ONE non-zero digit
+    rrows, rc = ring.sparse_gadget_recompose(srows, sc, basis, pad)
+    assert rc == ncols
+    for row, rrow in zip(rows, rrows):
+        assert len(row) == len(rrow)
+        for (e, c), (g, gc) in zip(row, rrow):
+            assert c == gc and np.array_equal(e, g)
