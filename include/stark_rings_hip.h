@@ -107,6 +107,13 @@ int sr_ctx_limbs(const sr_ctx *ctx, int *limbs);
 int sr_ctx_twiddle_block(sr_ctx *ctx, void **dev_ptr, size_t *bytes);
 /* Tell the context its twiddle block was overwritten (e.g. by a broadcast). */
 int sr_ctx_twiddles_updated(sr_ctx *ctx);
+/* Single-process multi-GPU form of the above ("sr_ctx_create(.., device_ids[], n)"; what a Rust host that drives the
+ * 8 GPUs of a node from one process binds): n contexts, one per device_ids[i], whose twiddle blocks are all copies of the block
+ * device_ids[0] built (hipMemcpyPeer, i.e. xGMI between the GPUs of a node) -- the only inter-GPU traffic of the path.  out[]
+ * receives n contexts (all destroyed again on failure).  sr_shard_range gives part i of a batch split contiguously and evenly
+ * (the first batch % n parts get one element more), the partition of stark_rings_amd/sharding.py. */
+int sr_ctx_create_group(int ring, int log2_degree, const int *device_ids, int n, const sr_plan *plan, sr_ctx **out);
+int sr_shard_range(size_t batch, int n, int i, size_t *first, size_t *count);
 
 /* ---- host-buffer entry points (stage through device memory; PCIe-inclusive) ------------- */
 /* CRT::elementwise_crt  (crt.rs:10-25): coefficient form -> CRT/NTT form, in place.       */

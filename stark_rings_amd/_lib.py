@@ -16,6 +16,8 @@ _c = ctypes
 SYMBOLS = {
     "sr_ctx_create": (_c.c_int, [_c.c_int, _c.c_int, _c.c_int, _c.POINTER(_c.c_void_p)]),
     "sr_ctx_create_ex": (_c.c_int, [_c.c_int, _c.c_int, _c.c_int, _c.c_void_p, _c.POINTER(_c.c_void_p)]),
+    "sr_ctx_create_group": (_c.c_int, [_c.c_int, _c.c_int, _c.POINTER(_c.c_int), _c.c_int, _c.c_void_p, _c.POINTER(_c.c_void_p)]),
+    "sr_shard_range": (_c.c_int, [_c.c_size_t, _c.c_int, _c.c_int, _c.POINTER(_c.c_size_t), _c.POINTER(_c.c_size_t)]),
     "sr_ctx_reserve_scratch": (_c.c_int, [_c.c_void_p, _c.c_size_t]),
     "sr_ctx_destroy": (_c.c_int, [_c.c_void_p]),
     "sr_ctx_degree": (_c.c_int, [_c.c_void_p, _c.POINTER(_c.c_size_t)]),

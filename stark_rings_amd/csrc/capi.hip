@@ -1055,6 +1055,42 @@ int sr_ctx_twiddles_updated(sr_ctx *c) {
     return SR_OK;
 }
 
+// One context per device of a node, twiddles built ONCE: device_ids[0] builds the block, every other context's block is
+// overwritten with a peer copy of it (over xGMI between the GPUs of one node) -- the single-process form of the one-shot
+// twiddle broadcast of SURVEY 8e (processes use RCCL: stark_rings_amd/sharding.py).  No data-path traffic afterwards.
+int sr_ctx_create_group(int ring, int log2_degree, const int *device_ids, int n, const sr_plan *plan, sr_ctx **out) {
+    if (!device_ids || !out || n <= 0) return fail(SR_E_INVALID, "create_group: null argument or n <= 0");
+    for (int i = 0; i < n; i++) out[i] = nullptr;
+    auto undo = [&](int rc) {
+        for (int i = 0; i < n; i++) {
+            if (out[i]) sr_ctx_destroy(out[i]);
+            out[i] = nullptr;
+        }
+        return rc;
+    };
+    for (int i = 0; i < n; i++)
+        if (int rc = sr_ctx_create_ex(ring, log2_degree, device_ids[i], plan, &out[i])) return undo(rc);
+    if (!is_pow2_ring(ring)) return SR_OK;  // the small rings keep their constants in kernel arguments
+    for (int i = 1; i < n; i++) {
+        if (out[i]->table_bytes != out[0]->table_bytes) return undo(fail(SR_E_INVALID, "create_group: table sizes differ"));
+        // poison first, so that a failed copy cannot leave a locally built (and therefore plausible) table behind
+        DeviceGuard g(out[i]->device);
+        if (hipMemset(out[i]->tables, 0xFF, out[i]->table_bytes) != hipSuccess) return undo(fail(SR_E_HIP, "create_group: hipMemset failed"));
+        if (hipMemcpyPeer(out[i]->tables, out[i]->device, out[0]->tables, out[0]->device, out[0]->table_bytes) != hipSuccess)
+            return undo(fail(SR_E_HIP, "create_group: hipMemcpyPeer of the twiddle block failed"));
+        if (int rc = sr_ctx_twiddles_updated(out[i])) return undo(rc);
+    }
+    return SR_OK;
+}
+// contiguous, balanced split of `batch` ring elements over n contexts: part i gets [*first, *first + *count)
+int sr_shard_range(size_t batch, int n, int i, size_t *first, size_t *count) {
+    if (!first || !count || n <= 0 || i < 0 || i >= n) return fail(SR_E_INVALID, "shard_range: bad argument");
+    const size_t q = batch / (size_t)n, r = batch % (size_t)n;
+    *first = (size_t)i * q + ((size_t)i < r ? (size_t)i : r);
+    *count = q + ((size_t)i < r ? 1 : 0);
+    return SR_OK;
+}
+
 // ---- device-resident entry points ----
 int sr_ntt_fwd_batch_dev(sr_ctx *c, uint64_t *d, size_t batch, void *stream) {
     if (int rc = check(c, d)) return rc;

@@ -1378,3 +1378,41 @@ def test_matrix_and_sparse_matrix_gadget_decompose(torch_cuda, name, k, basis, p
         assert len(row) == len(rrow)
         for (e, c), (g, gc) in zip(row, rrow):
             assert c == gc and np.array_equal(e, g)
+
+
+def test_context_group_shares_one_twiddle_block(torch_cuda):
+    """sr_ctx_create_group: n contexts whose tables are peer copies of the first one's (here both on device 0: the copy path is the
+    same call), and sr_shard_range == sharding.shard_range.  The second context computes with the COPIED tables."""
+    import ctypes
+
+    torch = torch_cuda
+    from stark_rings_amd import _lib
+    from stark_rings_amd.sharding import shard_range
+
+    lib = _lib.load()
+    ids = (ctypes.c_int * 2)(0, 0)
+    ctxs = (ctypes.c_void_p * 2)()
+    k, batch = 13, 5
+    assert lib.sr_ctx_create_group(0, k, ids, 2, None, ctxs) == 0, _lib.last_error()
+    try:
+        F = O.GOLDILOCKS
+        a = O.fill_uniform(F, 3, 0, batch << k)
+        b = O.fill_uniform(F, 4, 0, batch << k)
+        want = O.pow2_ring_mul(F, a, b, k, batch, 4)
+        ta, tb = torch.from_numpy(a.view(np.int64)).cuda(), torch.from_numpy(b.view(np.int64)).cuda()
+        out = torch.empty_like(ta)
+        first, count = ctypes.c_size_t(), ctypes.c_size_t()
+        for i in range(2):
+            assert lib.sr_shard_range(batch, 2, i, ctypes.byref(first), ctypes.byref(count)) == 0
+            assert (first.value, count.value) == shard_range(batch, 2, i)
+            off = first.value << k
+            rc = lib.sr_ring_mul_batch_dev(ctxs[i], ctypes.c_void_p(out.data_ptr() + off * 8), ctypes.c_void_p(ta.data_ptr() + off * 8),
+                                           ctypes.c_void_p(tb.data_ptr() + off * 8), count.value,
+                                           ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+            assert rc == 0, _lib.last_error()
+        torch.cuda.synchronize()
+        assert np.array_equal(out.cpu().numpy().view(np.uint64), want)
+        assert lib.sr_shard_range(5, 2, 2, ctypes.byref(first), ctypes.byref(count)) != 0
+    finally:
+        for c in ctxs:
+            lib.sr_ctx_destroy(c)
