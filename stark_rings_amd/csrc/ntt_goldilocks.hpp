@@ -399,11 +399,22 @@ template <int LC>
 struct ColsTile {
     static constexpr int C = 1 << LC;
     static constexpr int kLanes = 16 * C;
+#if defined(SR_COLS_SWIZZLE)
+    // LC = 4 without padding: 32 KiB per workgroup, five workgroups per CU.  The pass-B pattern (two leg groups 256 words apart
+    // in one 32-lane LDS group) is spread over both bank halves by flipping bit 4 of the position for odd leg groups; the
+    // pass-A pattern (256 consecutive words per instruction) sees a flip that is uniform per instruction.
+    static constexpr int kElems = 256 * C;
+    static __device__ __forceinline__ int idx(int leg, int col) {
+        const int pos = leg * C + col;
+        return LC == 4 ? pos ^ (((pos >> 8) & 1) << 4) : pos;
+    }
+#else
     static constexpr int kElems = LC == 4 ? kLdsElems : 256 * C;
     static __device__ __forceinline__ int idx(int leg, int col) {
         const int pos = leg * C + col;
         return LC == 4 ? pos + (pos >> 4) : pos;
     }
+#endif
 };
 #ifndef SR_COLS_WAVES
 #define SR_COLS_WAVES 4

@@ -47,7 +47,7 @@ int main(int argc, char **argv) {
     const unsigned pgrid = PERSIST * (LCV == 6 ? 1 : LCV == 5 ? 2 : 4);  // PERSIST = number of CUs to fill
 #define COLS(DIRV, buf, wcp, twp) hipLaunchKernelGGL((cols256p_kernel<DIRV, LCV>), dim3(pgrid < ntiles ? pgrid : ntiles), dim3(16 << LCV), 0, 0, buf, k, wcp, twp, ntiles)
 #else
-#define COLS(DIRV, buf, wcp, twp) hipLaunchKernelGGL((cols256_kernel<DIRV, LCV>), dim3(cblocks), dim3(16 << LCV), 0, 0, buf, k, wcp, twp)
+#define COLS(DIRV, buf, wcp, twp) hipLaunchKernelGGL((cols256_kernel<DIRV, LCV>), dim3(cblocks), dim3(16 << LCV), 0, 0, buf, buf, k, wcp, twp)
 #endif
     double acc[4] = {0, 0, 0, 0};
     for (int r = -1; r < reps; r++) {
