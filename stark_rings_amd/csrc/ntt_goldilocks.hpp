@@ -36,6 +36,25 @@ typedef uint64_t u64;
 typedef uint32_t u32;
 
 constexpr int kW16Exp = 156;  // omega_16 = 2^156 (= (8^13)^4)
+
+// coefficient streams are read once and written once per launch: SR_GL_NT = 1 marks them non-temporal (A/B switch)
+#ifndef SR_GL_NT
+#define SR_GL_NT 1
+#endif
+__device__ __forceinline__ u64 ld_stream(const u64 *p) {
+#if SR_GL_NT
+    return __builtin_nontemporal_load(p);
+#else
+    return *p;
+#endif
+}
+__device__ __forceinline__ void st_stream(u64 *p, u64 v) {
+#if SR_GL_NT
+    __builtin_nontemporal_store(v, p);
+#else
+    *p = v;
+#endif
+}
 constexpr int kTile = 4096;
 constexpr int kLdsElems = kTile + kTile / 16;  // padded: pos + (pos >> 4)
 
@@ -444,7 +463,7 @@ __global__ __launch_bounds__(16 << LC, LC == 4 ? SR_COLS_WAVES : 4) void cols256
 
     if (DIR == 0) {
 #pragma unroll
-        for (int jj = 0; jj < 16; jj++) x[jj] = *reinterpret_cast<const u64 *>(ps + (offA + (unsigned)jj * 16u * leg));
+        for (int jj = 0; jj < 16; jj++) x[jj] = ld_stream(reinterpret_cast<const u64 *>(ps + (offA + (unsigned)jj * 16u * leg)));
 #ifndef SR_DIAG_COLS_NOCOMPUTE
         cols_stage_fwd<0>(x, seq16{});
         cols_stage_fwd<1>(x, seq16{});
@@ -465,7 +484,7 @@ __global__ __launch_bounds__(16 << LC, LC == 4 ? SR_COLS_WAVES : 4) void cols256
         dft16_fwd(x);
 #pragma unroll
         for (int sg = 0; sg < 16; sg++)
-            *reinterpret_cast<u64 *>(pb + (offB + (unsigned)sg * leg)) = G::mul(x[sg], tw[sg]);
+            st_stream(reinterpret_cast<u64 *>(pb + (offB + (unsigned)sg * leg)), G::mul(x[sg], tw[sg]));
 #else
 #pragma unroll
         for (int sg = 0; sg < 16; sg++) *reinterpret_cast<u64 *>(pb + (offB + (unsigned)sg * leg)) = x[sg] ^ tw[sg];
@@ -474,7 +493,7 @@ __global__ __launch_bounds__(16 << LC, LC == 4 ? SR_COLS_WAVES : 4) void cols256
         u64 tw[16];
 #pragma unroll
         for (int sg = 0; sg < 16; sg++) {
-            x[sg] = *reinterpret_cast<const u64 *>(ps + (offB + (unsigned)sg * leg));
+            x[sg] = ld_stream(reinterpret_cast<const u64 *>(ps + (offB + (unsigned)sg * leg)));
             tw[sg] = *reinterpret_cast<const u64 *>(tb + (offB + (unsigned)sg * leg));
         }
 #pragma unroll
@@ -492,7 +511,7 @@ __global__ __launch_bounds__(16 << LC, LC == 4 ? SR_COLS_WAVES : 4) void cols256
         cols_stage_inv<1>(x, seq16{});
         cols_stage_inv<0>(x, seq16{});
 #pragma unroll
-        for (int jj = 0; jj < 16; jj++) *reinterpret_cast<u64 *>(pb + (offA + (unsigned)jj * 16u * leg)) = x[jj];
+        for (int jj = 0; jj < 16; jj++) st_stream(reinterpret_cast<u64 *>(pb + (offA + (unsigned)jj * 16u * leg)), x[jj]);
     }
 }
 
@@ -511,7 +530,7 @@ __device__ __forceinline__ void tile_fwd(const u64 *__restrict__ src, u64 *lds, 
         const int pos = j * 256 + t;
         // ragged last tile (TW only): out-of-range lanes re-read the last valid coefficient; their results belong to ring
         // elements that do not exist and are never stored, and no pass mixes ring elements, so no branch is needed
-        x[j] = src[(!TW || pos < nvalid) ? pos : nvalid - 1];
+        x[j] = ld_stream(src + ((!TW || pos < nvalid) ? pos : nvalid - 1));
     }
     if (TW) twist_rows<Q, false>(x, std::make_integer_sequence<int, 16>{});
     dft16_fwd_q<Q>(x);
@@ -563,7 +582,7 @@ __device__ __forceinline__ void tile_inv(u64 *x, u64 *lds, const int t, const Ta
 #pragma unroll
     for (int j = 0; j < 16; j++) {
         const int pos = j * 256 + t;
-        if (!TW || pos < nvalid) dst[pos] = x[j];
+        if (!TW || pos < nvalid) st_stream(dst + pos, x[j]);
     }
 }
 
@@ -639,7 +658,7 @@ __global__ __launch_bounds__(256, TW ? SR_ROWS_WAVES_TW : SR_ROWS_WAVES) void ro
 __device__ __forceinline__ void tile256_fwd(const u64 *__restrict__ src, u64 *lds, const int t, const Tables &T, u64 *x) {
     const int i0 = t & 15, base2 = (t >> 4) * 256 + i0;
 #pragma unroll
-    for (int j = 0; j < 16; j++) x[j] = src[base2 + j * 16];
+    for (int j = 0; j < 16; j++) x[j] = ld_stream(src + base2 + j * 16);
     dft16_fwd(x);
 #pragma unroll
     for (int s = 1; s < 16; s++) x[s] = G::mul(x[s], T.w2f[s * 16 + i0]);
@@ -662,7 +681,7 @@ __device__ __forceinline__ void tile256_inv(u64 *x, u64 *lds, const int t, const
     for (int s = 1; s < 16; s++) x[s] = G::mul(x[s], T.w2i[s * 16 + i0]);
     dft16_inv(x);
 #pragma unroll
-    for (int j = 0; j < 16; j++) dst[base2 + j * 16] = x[j];
+    for (int j = 0; j < 16; j++) st_stream(dst + base2 + j * 16, x[j]);
 }
 template <int MODE>
 __global__ __launch_bounds__(256, 4) void rows256_kernel(u64 *a, const u64 *b, u64 *out, Tables T) {
@@ -874,9 +893,10 @@ inline int gl_plan(int c, int *ms) {
 }
 // columns per workgroup (2^LC): measured at D = 2^16, batch 2^14 (tools/ubench/gl_bench.hip): forward 3.86 / 3.75 / 4.38 ms and
 // inverse 4.26 / 4.39 / 5.07 ms for LC = 4 / 5 / 6 -- wider segments stream better (strided_pattern.hip) but one or two big
-// workgroups per CU overlap their load, exchange and store phases worse than four small ones
+// workgroups per CU overlap their load, exchange and store phases worse than four small ones.  With non-temporal coefficient
+// accesses (SR_GL_NT) LC = 4 runs 3.70 / 4.09 ms and LC = 5 3.73 / 4.21 ms: LC = 4 both ways.
 #ifndef SR_COLS_LC_FWD
-#define SR_COLS_LC_FWD 5
+#define SR_COLS_LC_FWD 4
 #endif
 #ifndef SR_COLS_LC_INV
 #define SR_COLS_LC_INV 4
