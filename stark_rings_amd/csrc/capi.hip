@@ -677,8 +677,7 @@ int decompose_dev(sr_ctx *c, uint64_t *out, const uint64_t *in, uint64_t b, size
     using S = typename F::storage;
     const size_t n = batch * c->degree;
     if (n == 0 || k == 0) return SR_OK;
-    size_t blocks = (n + 255) / 256;
-    if (blocks > 1u << 20) blocks = 1u << 20;
+    const unsigned blocks = sr::stream_blocks<F>(n);
     ProfScope ps(c, st, K_OTHER);
     hipLaunchKernelGGL((sr::dec::decompose_kernel<F>), dim3((unsigned)blocks), dim3(256), 0, st, reinterpret_cast<S *>(out),
                        reinterpret_cast<const S *>(in), c->degree, batch, b, sr::dec::exact_log2(b), k, c->d_counter + 2);
@@ -690,8 +689,7 @@ int recompose_dev(sr_ctx *c, uint64_t *out, const uint64_t *in, uint64_t b, size
     using S = typename F::storage;
     const size_t n = batch_out * c->degree;
     if (n == 0) return SR_OK;
-    size_t blocks = (n + 255) / 256;
-    if (blocks > 1u << 20) blocks = 1u << 20;
+    const unsigned blocks = sr::stream_blocks<F>(n);
     ProfScope ps(c, st, K_OTHER);
     hipLaunchKernelGGL((sr::dec::recompose_kernel<F>), dim3((unsigned)blocks), dim3(256), 0, st, reinterpret_cast<S *>(out),
                        reinterpret_cast<const S *>(in), c->degree, batch_out, b, k);
@@ -705,8 +703,7 @@ int rot_dev(sr_ctx *c, uint64_t *out, const uint64_t *in, size_t batch, hipStrea
     using S = typename F::storage;
     const size_t n = batch * c->degree;
     if (n == 0) return SR_OK;
-    size_t blocks = (n + 255) / 256;
-    if (blocks > 1u << 20) blocks = 1u << 20;
+    const unsigned blocks = sr::stream_blocks<F>(n);
     const size_t half = (c->ring == SR_RING_GOLDILOCKS_24 || c->ring == SR_RING_BABYBEAR_72) ? c->degree / 2 : 0;
     ProfScope ps(c, st, K_OTHER);
     hipLaunchKernelGGL((sr::rot_kernel<F>), dim3((unsigned)blocks), dim3(256), 0, st, reinterpret_cast<S *>(out),
@@ -721,8 +718,7 @@ int wire_dev(sr_ctx *c, bool ser, void *out, const void *in, const uint64_t *off
     using S = typename F::storage;
     const size_t n = batch * c->degree;
     if (n == 0) return SR_OK;
-    size_t blocks = (n + 255) / 256;
-    if (blocks > 1u << 20) blocks = 1u << 20;
+    const unsigned blocks = sr::stream_blocks<F>(n);
     ProfScope ps(c, st, K_OTHER);
     if (ser)
         hipLaunchKernelGGL((sr::wire::serialize_kernel<F>), dim3((unsigned)blocks), dim3(256), 0, st, (uint8_t *)out,

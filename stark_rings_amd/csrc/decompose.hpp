@@ -183,33 +183,80 @@ SR_HD typename F::elem digit_image(uint64_t dig, bool neg) {
     return (neg && dig) ? F::sub(F::zero(), v) : v;
 }
 
+// k balanced digits of one coefficient, written d coefficients apart (digit-major); returns true when more were needed
+template <class F, class Store>
+__device__ __forceinline__ bool decompose_one(typename F::elem img, uint64_t b, int log2b, size_t k, Store store) {
+    Mag<F> cur = Mag<F>::from_image(img);
+    for (size_t j = 0; j < k; j++) {
+        const uint64_t rem = cur.divrem(b, log2b);
+        uint64_t dig = rem;
+        bool dneg = cur.neg;
+        if (rem > b / 2) {
+            dig = b - rem;
+            dneg = !cur.neg;
+            cur.inc();
+        }
+        store(j, digit_image<F>(dig, dneg));
+    }
+    return !cur.is_zero();
+}
+
 // in: batch ring elements of d coefficients; out: batch * k ring elements.  *overflow counts coefficients that needed more
-// than k digits (the reference indexes out[k] and panics).
+// than k digits (the reference indexes out[k] and panics).  One-limb fields move two neighbouring coefficients per lane
+// (16-byte accesses: the input pair and each of the k digit pairs) when d is even and the buffers are 16-byte aligned.
 template <class F>
 __global__ __launch_bounds__(256) void decompose_kernel(typename F::storage *out, const typename F::storage *in, size_t d,
                                                         size_t batch, uint64_t b, int log2b, size_t k,
                                                         unsigned long long *overflow) {
     const size_t n = batch * d;
-    for (size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x; t < n; t += (size_t)gridDim.x * blockDim.x) {
-        const size_t e = t / d, i = t - e * d;
-        Mag<F> cur = Mag<F>::from_image(F::load(in + t));
-        typename F::storage *o = out + e * k * d + i;
-        for (size_t j = 0; j < k; j++) {
-            const uint64_t rem = cur.divrem(b, log2b);
-            uint64_t dig = rem;
-            bool dneg = cur.neg;
-            if (rem > b / 2) {
-                dig = b - rem;
-                dneg = !cur.neg;
-                cur.inc();
+    const size_t gid = blockIdx.x * (size_t)blockDim.x + threadIdx.x, stride = (size_t)gridDim.x * blockDim.x;
+    if constexpr (sizeof(typename F::storage) == 8) {
+        if ((d & 1) == 0 && ((((uintptr_t)in | (uintptr_t)out) & 15u) == 0)) {
+            for (size_t t2 = gid; t2 < (n >> 1); t2 += stride) {
+                const size_t t = t2 << 1, e = t / d, i = t - e * d;
+                const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(in + t);
+                typename F::storage w[2] = {v.x, v.y};
+                typename F::storage *o = out + e * k * d + i;
+                // digit j of both coefficients leaves as one 16-byte store: buffer the first coefficient's digits in registers
+                // would cost k registers; instead the two digit streams are produced in lock step
+                Mag<F> c0 = Mag<F>::from_image(F::load(&w[0])), c1 = Mag<F>::from_image(F::load(&w[1]));
+                for (size_t j = 0; j < k; j++) {
+                    typename F::storage dg[2];
+                    Mag<F> *cs[2] = {&c0, &c1};
+#pragma unroll
+                    for (int q = 0; q < 2; q++) {
+                        Mag<F> &cur = *cs[q];
+                        const uint64_t rem = cur.divrem(b, log2b);
+                        uint64_t dig = rem;
+                        bool dneg = cur.neg;
+                        if (rem > b / 2) {
+                            dig = b - rem;
+                            dneg = !cur.neg;
+                            cur.inc();
+                        }
+                        F::store(&dg[q], digit_image<F>(dig, dneg));
+                    }
+                    ulonglong2 ov;
+                    ov.x = dg[0];
+                    ov.y = dg[1];
+                    *reinterpret_cast<ulonglong2 *>(o + j * d) = ov;
+                }
+                const unsigned over = (c0.is_zero() ? 0u : 1u) + (c1.is_zero() ? 0u : 1u);
+                if (over) atomicAdd(overflow, (unsigned long long)over);
             }
-            F::store(o + j * d, digit_image<F>(dig, dneg));
+            return;
         }
-        if (!cur.is_zero()) atomicAdd(overflow, 1ull);
+    }
+    for (size_t t = gid; t < n; t += stride) {
+        const size_t e = t / d, i = t - e * d;
+        typename F::storage *o = out + e * k * d + i;
+        if (decompose_one<F>(F::load(in + t), b, log2b, k, [&](size_t j, const typename F::elem &v) { F::store(o + j * d, v); }))
+            atomicAdd(overflow, 1ull);
     }
 }
 
-// out[e][i] = sum_j b^j in[e * k + j][i]: Horner from the top digit (mod.rs:119-131, 177-189)
+// out[e][i] = sum_j b^j in[e * k + j][i]: Horner from the top digit (mod.rs:119-131, 177-189); two coefficients per lane like
+// decompose_kernel
 template <class F>
 __global__ __launch_bounds__(256) void recompose_kernel(typename F::storage *out, const typename F::storage *in, size_t d,
                                                         size_t batch_out, uint64_t b, size_t k) {
@@ -218,7 +265,31 @@ __global__ __launch_bounds__(256) void recompose_kernel(typename F::storage *out
     uint64_t bred = b;
     if constexpr (!std::is_same<F, Stark>::value) bred = b % (uint64_t)F::P;
     const typename F::elem bimg = F::mul_boundary(Consts<F>::from_u64(bred), Consts<F>::r2());
-    for (size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x; t < n; t += (size_t)gridDim.x * blockDim.x) {
+    const size_t gid = blockIdx.x * (size_t)blockDim.x + threadIdx.x, stride = (size_t)gridDim.x * blockDim.x;
+    if constexpr (sizeof(typename F::storage) == 8) {
+        if ((d & 1) == 0 && ((((uintptr_t)in | (uintptr_t)out) & 15u) == 0)) {
+            for (size_t t2 = gid; t2 < (n >> 1); t2 += stride) {
+                const size_t t = t2 << 1, e = t / d, i = t - e * d;
+                const typename F::storage *src = in + e * k * d + i;
+                typename F::elem a0 = F::zero(), a1 = F::zero();
+                for (size_t j = k; j-- > 0;) {
+                    const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(src + j * d);
+                    typename F::storage w[2] = {v.x, v.y};
+                    a0 = F::add(F::mul_boundary(a0, bimg), F::load(&w[0]));
+                    a1 = F::add(F::mul_boundary(a1, bimg), F::load(&w[1]));
+                }
+                typename F::storage o[2];
+                F::store(&o[0], a0);
+                F::store(&o[1], a1);
+                ulonglong2 ov;
+                ov.x = o[0];
+                ov.y = o[1];
+                *reinterpret_cast<ulonglong2 *>(out + t) = ov;
+            }
+            return;
+        }
+    }
+    for (size_t t = gid; t < n; t += stride) {
         const size_t e = t / d, i = t - e * d;
         const typename F::storage *src = in + e * k * d + i;
         typename F::elem acc = F::zero();

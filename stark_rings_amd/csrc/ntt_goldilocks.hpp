@@ -41,6 +41,21 @@ constexpr int kW16Exp = 156;  // omega_16 = 2^156 (= (8^13)^4)
 #ifndef SR_GL_NT
 #define SR_GL_NT 1
 #endif
+// The workgroups that share a CU all run the same program and start together, so their load, compute and store phases tend to
+// stay aligned for the whole launch (everyone waits on HBM, then everyone competes for the VALU).  SR_GL_STAGGER delays the
+// first-round workgroups of a launch by a quarter of a tile time per resident slot, which de-phases the slots for good (a slot
+// is refilled when its workgroup ends).  Only timing changes.
+#ifndef SR_GL_STAGGER
+#define SR_GL_STAGGER 0
+#endif
+__device__ __forceinline__ void stagger_first_round() {
+#if SR_GL_STAGGER
+    if (blockIdx.x < 1024u) {  // 256 CUs x 4 resident workgroups: the first round
+        const unsigned slot = (blockIdx.x >> 8) & 3u;
+        for (unsigned i = 0; i < slot * SR_GL_STAGGER; i++) __builtin_amdgcn_s_sleep(127);
+    }
+#endif
+}
 __device__ __forceinline__ u64 ld_stream(const u64 *p) {
 #if SR_GL_NT
     return __builtin_nontemporal_load(p);
@@ -446,6 +461,7 @@ __global__ __launch_bounds__(16 << LC, LC == 4 ? SR_COLS_WAVES : 4) void cols256
     constexpr int C = CT::C;
     __shared__ u64 lds[CT::kElems];
     const int t = threadIdx.x;
+    stagger_first_round();
     const int ls = k - 8;  // log2 N2
     const unsigned ci = blockIdx.x & ((1u << (ls - LC)) - 1u);
     const size_t poly = blockIdx.x >> (ls - LC);
@@ -687,6 +703,7 @@ template <int MODE>
 __global__ __launch_bounds__(256, 4) void rows256_kernel(u64 *a, const u64 *b, u64 *out, Tables T) {
     __shared__ u64 lds[kLdsElems];
     const int t = threadIdx.x;
+    stagger_first_round();
     const size_t base = (size_t)blockIdx.x * kTile;
     u64 A[16];
     if (MODE == 1) {

@@ -117,11 +117,20 @@ def summarize(indir, workload, outdir):
     for r in full_batch(rows, "Grid_Size"):
         sq[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
     shutil.copy(os.path.join(indir, "pmc_SQ.counters.csv"), os.path.join(outdir, "pmc_SQ_%s.csv" % workload))
+    # a tag's figures come from its full-batch kernels only: the property gate of bench.py also runs 2-tile launches of the
+    # forward-only / inverse-only rows kernels, which carry the same tag
+    grid = collections.defaultdict(int)
+    for r in rows:
+        grid[r["Kernel_Name"]] = max(grid[r["Kernel_Name"]], int(r["Grid_Size"]))
+    tag_max = collections.defaultdict(int)
+    for kname, g in grid.items():
+        if tag_of(kname):
+            tag_max[tag_of(kname)] = max(tag_max[tag_of(kname)], g)
     bytes_per_launch, valu = {}, {}
     md.append("\n| kernel | tag | 2 x FETCH_SIZE (GiB) | WRITE_SIZE (GiB) | waves | VALU / wave | SALU / wave |\n|---|---|---|---|---|---|---|")
     for kname in sorted(agg["FETCH_SIZE"]):
         t = tag_of(kname)
-        if not t:
+        if not t or grid.get(kname, 0) * 4 < tag_max[t]:
             continue
         f, w = 2 * agg["FETCH_SIZE"][kname] * 1024, agg["WRITE_SIZE"].get(kname, 0) * 1024  # the CSVs are in KiB
         bytes_per_launch.setdefault(t, []).append(f + w)
