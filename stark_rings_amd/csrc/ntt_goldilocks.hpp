@@ -671,10 +671,14 @@ __global__ __launch_bounds__(256, TW ? SR_ROWS_WAVES_TW : SR_ROWS_WAVES) void ro
 // rho; global accesses are 128-byte segments (16 lanes x 8 B).  MODE as rows_kernel.
 // tools/model_fast_goldilocks.py: rows256_fwd / rows256_inv.
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void tile256_fwd(const u64 *__restrict__ src, u64 *lds, const int t, const Tables &T, u64 *x) {
+__device__ __forceinline__ void tile256_load(const u64 *__restrict__ src, const int t, u64 *x) {
     const int i0 = t & 15, base2 = (t >> 4) * 256 + i0;
 #pragma unroll
     for (int j = 0; j < 16; j++) x[j] = ld_stream(src + base2 + j * 16);
+}
+// x holds the lane's 16 coefficients (tile256_load) on entry, its 16 consecutive NTT slots on return
+__device__ __forceinline__ void tile256_fwd_regs(u64 *lds, const int t, const Tables &T, u64 *x) {
+    const int i0 = t & 15, base2 = (t >> 4) * 256 + i0;
     dft16_fwd(x);
 #pragma unroll
     for (int s = 1; s < 16; s++) x[s] = G::mul(x[s], T.w2f[s * 16 + i0]);
@@ -684,6 +688,10 @@ __device__ __forceinline__ void tile256_fwd(const u64 *__restrict__ src, u64 *ld
 #pragma unroll
     for (int j = 0; j < 16; j++) x[j] = lds[17 * t + j];
     dft16_fwd(x);
+}
+__device__ __forceinline__ void tile256_fwd(const u64 *__restrict__ src, u64 *lds, const int t, const Tables &T, u64 *x) {
+    tile256_load(src, t, x);
+    tile256_fwd_regs(lds, t, T, x);
 }
 __device__ __forceinline__ void tile256_inv(u64 *x, u64 *lds, const int t, const Tables &T, u64 *__restrict__ dst) {
     const int i0 = t & 15, base2 = (t >> 4) * 256 + i0;
@@ -699,6 +707,11 @@ __device__ __forceinline__ void tile256_inv(u64 *x, u64 *lds, const int t, const
 #pragma unroll
     for (int j = 0; j < 16; j++) st_stream(dst + base2 + j * 16, x[j]);
 }
+// SR_ROWS256_PREFETCH_B = 1: the fused product requests b's tile together with a's (16 more registers in flight) instead of
+// after a's transform
+#ifndef SR_ROWS256_PREFETCH_B
+#define SR_ROWS256_PREFETCH_B 0
+#endif
 template <int MODE>
 __global__ __launch_bounds__(256, 4) void rows256_kernel(u64 *a, const u64 *b, u64 *out, Tables T) {
     __shared__ u64 lds[kLdsElems];
@@ -714,7 +727,14 @@ __global__ __launch_bounds__(256, 4) void rows256_kernel(u64 *a, const u64 *b, u
 #pragma unroll
         for (int j = 0; j < 16; j++) A[j] = lds[17 * t + j];  // own slots from here on: no barrier before tile256_inv's writes
     } else {
+#if SR_ROWS256_PREFETCH_B
+        u64 B[16];
+        tile256_load(a + base, t, A);
+        if (MODE == 2) tile256_load(b + base, t, B);  // both operands' loads in flight before the first butterfly
+        tile256_fwd_regs(lds, t, T, A);
+#else
         tile256_fwd(a + base, lds, t, T, A);
+#endif
         if (MODE == 0) {
 #pragma unroll
             for (int j = 0; j < 16; j++) lds[17 * t + j] = A[j];  // own slots
@@ -723,7 +743,9 @@ __global__ __launch_bounds__(256, 4) void rows256_kernel(u64 *a, const u64 *b, u
             for (int j = 0; j < 16; j++) a[base + j * 256 + t] = lds[pad(j * 256 + t)];
             return;
         }
+#if !SR_ROWS256_PREFETCH_B
         u64 B[16];
+#endif
         __syncthreads();  // every lane has read a's exchange before b's lands
         if (MODE == 3) {  // b already in NTT order (see rows_kernel)
 #pragma unroll
@@ -732,7 +754,11 @@ __global__ __launch_bounds__(256, 4) void rows256_kernel(u64 *a, const u64 *b, u
 #pragma unroll
             for (int j = 0; j < 16; j++) B[j] = lds[17 * t + j];
         } else {
+#if SR_ROWS256_PREFETCH_B
+            tile256_fwd_regs(lds, t, T, B);
+#else
             tile256_fwd(b + base, lds, t, T, B);
+#endif
         }
 #pragma unroll
         for (int j = 0; j < 16; j++) A[j] = G::mul(A[j], B[j]);
