@@ -93,6 +93,7 @@ def summarize(indir, workload, outdir):
     md = ["## %s\n" % workload]
     # kernel durations (trace pass)
     shutil.copy(os.path.join(indir, "trace.kernel_stats.csv"), os.path.join(outdir, "kernel_stats_%s.csv" % workload))
+    shutil.copy(os.path.join(indir, "trace.kernel_trace.csv"), os.path.join(outdir, "kernel_trace_%s.csv" % workload))
     trace = list(csv.DictReader(open(os.path.join(indir, "trace.kernel_trace.csv"))))
     gk = "Grid_Size_X" if "Grid_Size_X" in trace[0] else "Grid_Size"
     dur = collections.defaultdict(list)
@@ -156,8 +157,66 @@ def summarize(indir, workload, outdir):
     print("\n".join(md))
 
 
+def readme(outdir):
+    """profiles/<round>/README.md: one table with the roofline fraction of every config, recomputed from the committed files."""
+    import bench
+
+    md = ["# %s -- MI355X (gfx950), rocprofv3 summaries and bench lines of the round\n" % outdir,
+          "Collected with `python3 tools/profile_workload.py collect <workload> <dir>` on the GPU box (four rocprofv3 passes: `--kernel-trace --stats`,",
+          "`--pmc FETCH_SIZE`, `--pmc WRITE_SIZE`, `--pmc SQ_WAVES SQ_INSTS_VALU ...`, each around `python3 bench.py --workload ... --no-cpu-baseline`),",
+          "summarised with `... summarize` / `... readme`.  FETCH_SIZE is doubled (MI355X_MICROARCH.md: half of a streaming read is counted on gfx950);",
+          "the CSVs are in KiB.  `pmc_<workload>.json` carries the source hash it was collected at; `bench.py` replays its numbers only while the hash matches.\n",
+          "## roofline fraction per config, recomputed\n",
+          "`achieved` = bytes the dominant kernel has to move per launch (DESIGN.md section 5; `dominant_kernel_bytes_per_ring_mul` x batch / launches) / its average",
+          "duration from the kernel trace of the SAME profile run; `bench` = the `roofline.frac` of the stand-alone bench line in `bench_<name>.json`.\n",
+          "| config | workload | dominant kernel | bytes per launch (GB) | trace avg ms | achieved GB/s | frac of 8 TB/s | bench line frac | HBM bytes per launch from PMC (GB) |",
+          "|---|---|---|---|---|---|---|---|---|"]
+    names = {"goldilocks_d65536_b16384": ("2 (headline)", "default"), "babybear_d65536_b16384": ("3", "babybear"),
+             "goldilocks_d1048576_b8192": ("4 (per-GPU shard)", "c4_shard"), "stark_d4096_b4096": ("5", "stark")}
+    for w, (cfg, bname) in names.items():
+        bj = json.load(open(os.path.join(outdir, "bench_%s.json" % bname)))
+        pj = json.load(open(os.path.join(outdir, "pmc_%s.json" % w)))
+        r = bj["roofline"]
+        batch = bench.WORKLOADS[w][2]
+        # launches per step of the dominant kernel and its full-batch trace average
+        tpath = os.path.join(outdir, "kernel_trace_%s.csv" % w)
+        trace = list(csv.DictReader(open(tpath))) if os.path.exists(tpath) else []
+        avg_ms = None
+        if trace:
+            gk = "Grid_Size_X" if "Grid_Size_X" in trace[0] else "Grid_Size"
+            dur = collections.defaultdict(list)
+            for row in full_batch(trace, gk):
+                if tag_of(row["Kernel_Name"]) == r["kernel"]:
+                    dur[row["Kernel_Name"]].append(int(row["End_Timestamp"]) - int(row["Start_Timestamp"]))
+            big = max(dur.values(), key=lambda v: sum(v)) if dur else []
+            avg_ms = sum(big) / len(big) / 1e6 if big else None
+        per_launch = r["dominant_kernel_bytes_per_ring_mul"] * batch / r["launches_per_step"]
+        ach = per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms else float("nan")
+        md.append("| %s | `%s` | %s | %.2f | %s | %.0f | %.3f | %.3f | %.2f |" % (
+            cfg, w, r["kernel"], per_launch / 1e9, ("%.3f" % avg_ms) if avg_ms else "n/a", ach, ach / 8000.0, r["frac"],
+            pj["bytes_per_launch"].get(r["kernel"], 0) / 1e9))
+    md.append("\nThe trace run and the stand-alone bench run are different launches on (possibly) different boxes: the two fractions agree within the")
+    md.append("box-to-box spread (a few percent).  PMC bytes per launch equal the algorithmic bytes of each kernel (no re-reads).\n")
+    for w in names:
+        sp = os.path.join(outdir, "summary_%s.md" % w)
+        if os.path.exists(sp):
+            md.append(open(sp).read())
+    md.append("## other files\n")
+    md.append("* `bench_default.json` -- plain `python bench.py --steps 10 --warmup 3` (with the CPU baseline leg); `bench_ntt_rhs.json` -- `--variant mul_ntt_rhs`;")
+    md.append("  `bench_babybear.json`, `bench_stark.json`, `bench_c4_shard.json` -- the other BASELINE configs; `bench_2rank_gloo.json` -- `python bench.py --gpus 2 --backend gloo --batch 4096`")
+    md.append("  (bench.py launching its own two ranks on the one GPU of the box).")
+    md.append("* `bench_under_trace_<workload>.json`, `bench_under_pmc_SQ_<workload>.json` -- bench.py's own lines from inside the profiler runs.")
+    md.append("* `bench_matvec.txt`, `bench_next_rows.jsonl`, `bench_small_rings.txt` -- tools/bench_matvec.py (incl. the three reference rings), tools/bench_next_rows.py, tools/bench_small_rings.py.")
+    md.append("* `experiments_gl_bench.txt` -- the A/B timings quoted in DESIGN.md section 6.0 (tools/ubench/gl_bench.hip, strided_pattern.hip).")
+    open(os.path.join(outdir, "README.md"), "w").write("\n".join(md) + "\n")
+    print("\n".join(md[:22]))
+
+
 if __name__ == "__main__":
     if sys.argv[1] == "collect":
         steps = int(sys.argv[sys.argv.index("--steps") + 1]) if "--steps" in sys.argv else 3
         sys.exit(collect(sys.argv[2], sys.argv[3], steps))
+    if sys.argv[1] == "readme":
+        readme(sys.argv[2])
+        sys.exit(0)
     summarize(sys.argv[2], sys.argv[3], sys.argv[4])
