@@ -236,7 +236,8 @@ int sr_ctx_profile_read(sr_ctx *ctx, double ms_total[SR_PROF_NTAGS], uint64_t la
 
 /* Host-side self-test hook for the CPU test-suite: one scalar field operation computed by the same
  * source the kernels compile (fields.hpp).  field: 0 Goldilocks, 1 BabyBear, 2 Stark.
- * op: 0 add, 1 sub, 2 in-memory (Montgomery) product, 3 twiddle product, 4 table form of a[0].
+ * op: 0 add, 1 sub, 2 in-memory (Montgomery) product, 3 twiddle product, 4 table form of a[0]; field 0 only: 5 = the tuned path's
+ * compile-time shift product a[0] * 2^b[0] mod p, 1 <= b[0] <= 95.
  * Not a compute path. */
 int sr_selftest_field_op(int field, int op, const uint64_t *a, const uint64_t *b, uint64_t *out);
 

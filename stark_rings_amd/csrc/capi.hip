@@ -1684,8 +1684,22 @@ static int selftest_lazy(int op, const uint64_t *a, const uint64_t *b, uint64_t 
     return SR_OK;
 }
 }  // extern "C++"
+// op 5, field 0: the compile-time shift product of the tuned Goldilocks path, gl::mul_pow2<E>(a[0]) with E = b[0] in [1, 95]
+extern "C++" {
+template <int... Es>
+static uint64_t mul_pow2_any(uint64_t x, int e, std::integer_sequence<int, Es...>) {
+    uint64_t r = 0;
+    ((e == Es + 1 ? (r = sr::gl::mul_pow2<Es + 1>(x), 0) : 0), ...);
+    return r;
+}
+}
 int sr_selftest_field_op(int field, int op, const uint64_t *a, const uint64_t *b, uint64_t *out) {
     if (!a || !b || !out) return fail(SR_E_INVALID, "null argument");
+    if (field == 0 && op == 5) {
+        if (b[0] < 1 || b[0] > 95) return fail(SR_E_INVALID, "selftest: shift out of range");
+        out[0] = mul_pow2_any(a[0], (int)b[0], std::make_integer_sequence<int, 95>{});
+        return SR_OK;
+    }
     alignas(16) uint64_t ta[4] = {0, 0, 0, 0}, tb[4] = {0, 0, 0, 0}, to[4] = {0, 0, 0, 0};
     int words = (field == 2 || field == 4) ? 4 : 1;
     memcpy(ta, a, words * 8);

@@ -89,11 +89,21 @@ SR_HD u64 mul_pow2(u64 x) {
     } else if constexpr (q == 1) {
         return G::reduce128(xs << 32, (xs >> 32) | ((u64)y2 << 32));
     } else {
-        // (y0 + y1 2^32 + y2 2^64) * 2^64 = y0 * EPS - (y1 + y2 2^32)      [2^96 = -1, 2^128 = -2^32]
+#if !defined(SR_GL_POW2_RIGHT)  // (y0 + y1 2^32 + y2 2^64) * 2^64 = y0 * EPS - (y1 + y2 2^32): 7 VALU
         const u32 y0 = (u32)xs;
         const u64 B = ((u64)y0 << 32) - y0;                  // y0 * (2^32 - 1) < p
         const u64 C = (xs >> 32) | ((u64)y2 << 32);          // < 2^63 < p
         return G::sub(B, C);
+#else
+        // Round-2 experiment (SR_GL_POW2_RIGHT; also 7 VALU once compiled, so not the default): 64 <= E < 96 as a RIGHT shift:
+        // 2^E = -2^-s with s = 96 - E in (0, 32].  Split x = xh 2^s + xl:
+        // x 2^-s = xh + xl 2^-s, and 2^-s = -2^(96-s) = -2^(32-s) 2^64, so xl 2^-s = -(xl << (32 - s)) EPS = -t EPS with
+        // t < 2^32.  Hence x 2^E = t EPS - xh: one product by 0xFFFFFFFF (t EPS < p) and one subtraction (xh < 2^63 < p).
+        constexpr int sft = 96 - E;
+        const u32 t = sft == 32 ? (u32)x : (u32)x << (32 - sft);
+        const u64 xh = x >> sft;
+        return G::sub((u64)t * 0xFFFFFFFFull, xh);
+#endif
     }
 }
 
@@ -453,18 +463,16 @@ struct ColsTile {
 #ifndef SR_COLS_WAVES
 #define SR_COLS_WAVES 4
 #endif
+// tile = position of the workgroup's tile in the launch: ring element tile >> (log2 N2 - LC), column chunk in the low bits
 template <int DIR, int LC>
-__global__ __launch_bounds__(16 << LC, LC == 4 ? SR_COLS_WAVES : 4) void cols256_kernel(u64 *data, const u64 *src, int k,
-                                                                                       const u64 *__restrict__ wc,
-                                                                                       const u64 *__restrict__ twist) {
+__device__ __forceinline__ void cols256_tile(const unsigned tile, u64 *data, const u64 *src, int k, const u64 *__restrict__ wc,
+                                             const u64 *__restrict__ twist, u64 *lds) {
     using CT = ColsTile<LC>;
     constexpr int C = CT::C;
-    __shared__ u64 lds[CT::kElems];
     const int t = threadIdx.x;
-    stagger_first_round();
     const int ls = k - 8;  // log2 N2
-    const unsigned ci = blockIdx.x & ((1u << (ls - LC)) - 1u);
-    const size_t poly = blockIdx.x >> (ls - LC);
+    const unsigned ci = tile & ((1u << (ls - LC)) - 1u);
+    const size_t poly = tile >> (ls - LC);
     const int col = t & (C - 1), rg = t >> LC;
     const unsigned i = ci * (unsigned)C + (unsigned)col;  // column = position inside a leg
     // wave-uniform base + 32-bit byte offsets (a ring element is at most 8 MiB): one v_add_u32 per access
@@ -529,6 +537,15 @@ __global__ __launch_bounds__(16 << LC, LC == 4 ? SR_COLS_WAVES : 4) void cols256
 #pragma unroll
         for (int jj = 0; jj < 16; jj++) st_stream(reinterpret_cast<u64 *>(pb + (offA + (unsigned)jj * 16u * leg)), x[jj]);
     }
+}
+
+template <int DIR, int LC>
+__global__ __launch_bounds__(16 << LC, LC == 4 ? SR_COLS_WAVES : 4) void cols256_kernel(u64 *data, const u64 *src, int k,
+                                                                                       const u64 *__restrict__ wc,
+                                                                                       const u64 *__restrict__ twist) {
+    __shared__ u64 lds[ColsTile<LC>::kElems];
+    stagger_first_round();
+    cols256_tile<DIR, LC>(blockIdx.x, data, src, k, wc, twist, lds);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -713,11 +730,9 @@ __device__ __forceinline__ void tile256_inv(u64 *x, u64 *lds, const int t, const
 #define SR_ROWS256_PREFETCH_B 0
 #endif
 template <int MODE>
-__global__ __launch_bounds__(256, 4) void rows256_kernel(u64 *a, const u64 *b, u64 *out, Tables T) {
-    __shared__ u64 lds[kLdsElems];
+__device__ __forceinline__ void rows256_tile(const unsigned tile, u64 *a, const u64 *b, u64 *out, const Tables &T, u64 *lds) {
     const int t = threadIdx.x;
-    stagger_first_round();
-    const size_t base = (size_t)blockIdx.x * kTile;
+    const size_t base = (size_t)tile * kTile;
     u64 A[16];
     if (MODE == 1) {
         // the inverse starts from 16 consecutive slots per lane: lane-contiguous load, one exchange
@@ -765,6 +780,13 @@ __global__ __launch_bounds__(256, 4) void rows256_kernel(u64 *a, const u64 *b, u
     }
     tile256_inv(A, lds, t, T, out + base);
 }
+template <int MODE>
+__global__ __launch_bounds__(256, 4) void rows256_kernel(u64 *a, const u64 *b, u64 *out, Tables T) {
+    __shared__ u64 lds[kLdsElems];
+    stagger_first_round();
+    rows256_tile<MODE>(blockIdx.x, a, b, out, T, lds);
+}
+
 
 // ------------------------------------------------------------------------------------------------
 // table builder.  pows[j] = psi^(2^j), ipows[j] = psi^-(2^j), j = 0..k  (psi^(2^k) = -1)

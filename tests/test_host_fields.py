@@ -114,3 +114,23 @@ def test_stark_lazy_limb_arithmetic_matches_python_model():
         for b in bnd:
             assert _op(4, 7, a, b, 4) == (3 * a - 5 * b) % p
             assert _op(4, 8, a, b, 4) == (7 * a - 2 * b) % p
+
+
+def test_goldilocks_shift_products_all_exponents():
+    """gl::mul_pow2<E> (ntt_goldilocks.hpp), every E in [1, 95]: the three forms (left shift + fold for E < 64, right shift for
+    64 <= E < 96) against Python integers on boundary values and random canonical inputs."""
+    import random
+
+    lib = _lib.load()
+    p = 2**64 - 2**32 + 1
+    rnd = random.Random(7)
+    xs = [0, 1, 2, p - 1, p - 2, 2**32 - 1, 2**32, 2**32 + 1, 2**63, 2**63 - 1, 0xFFFFFFFF00000000, 0x00000000FFFFFFFF,
+          0xFFFFFFFE00000001, 0x8000000000000001, (p - 1) // 2, (p + 1) // 2] + [rnd.randrange(p) for _ in range(48)]
+    A = (ctypes.c_uint64 * 4)()
+    B = (ctypes.c_uint64 * 4)()
+    out = (ctypes.c_uint64 * 4)()
+    for e in range(1, 96):
+        for x in xs:
+            A[0], B[0] = x, e
+            assert lib.sr_selftest_field_op(0, 5, A, B, out) == 0
+            assert out[0] == (x << e) % p, (hex(x), e)

@@ -8,6 +8,9 @@
 #ifdef PERSIST
 #include "cols256p_experiment.hpp"
 #endif
+#if defined(MIXED) || defined(PIPE)
+#include "mixed256_experiment.hpp"
+#endif
 using namespace sr::gl;
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); return 1; } } while (0)
 __global__ void junk_kernel(u64 *p, size_t n, u64 seed) {
@@ -64,6 +67,63 @@ int main(int argc, char **argv) {
         if (r < 0) continue;
         for (int i = 0; i < 4; i++) { float ms; CK(hipEventElapsedTime(&ms, ev[i], ev[i + 1])); acc[i] += ms; }
     }
+#ifdef MIXED
+    {   // the same four phases as ONE mixed-role launch (junk data: the roles work on four independent buffers)
+        u64 *c2, *c3;
+        CK(hipMalloc(&c2, n * 8)); CK(hipMalloc(&c3, n * 8));
+        hipLaunchKernelGGL(junk_kernel, dim3(8192), dim3(256), 0, 0, c2, n, 4);
+        hipLaunchKernelGGL(junk_kernel, dim3(8192), dim3(256), 0, 0, c3, n, 5);
+        MixedArgs m{};
+        m.fa_dst = a; m.fa_src = a; m.fb_dst = b; m.fb_src = b; m.rows_a = c2; m.rows_b = b; m.inv = c3;
+        for (int r = 0; r < 4; r++) m.n_tiles[r] = blocks;
+        const unsigned grid = ((4u * blocks + 255u) / 256u) * 256u;
+        double tot = 0;
+        for (int r = -1; r < reps; r++) {
+            CK(hipEventRecord(ev[0]));
+            hipLaunchKernelGGL(mixed256_kernel, dim3(grid), dim3(256), 0, 0, m, k, T, T.twist_i_mul);
+            CK(hipEventRecord(ev[1]));
+            CK(hipDeviceSynchronize());
+            float ms; CK(hipEventElapsedTime(&ms, ev[0], ev[1]));
+            if (r >= 0) tot += ms;
+        }
+        printf("mixed-role single launch over the same work: %.3f ms\n", tot / reps);
+    }
+#endif
+#ifdef PIPE
+    {   // chunk pipeline: launch i = fwd cols of a, b for chunk i + rows of chunk i - 1 + inverse cols of chunk i - 2, mixed roles
+        u64 *sc[2];
+        for (size_t N : {32, 48, 64, 96, 128, 256, 512, 1024}) {
+            if (N > npoly) continue;
+            CK(hipMalloc(&sc[0], N << 19)); CK(hipMalloc(&sc[1], N << 19));
+            const size_t nch = (npoly + N - 1) / N;
+            double tot = 0;
+            for (int r = -1; r < reps; r++) {
+                CK(hipEventRecord(ev[0]));
+                for (size_t i = 0; i < nch + 2; i++) {
+                    MixedArgs m{};
+                    auto cnt = [&](size_t c) { return c < nch ? (unsigned)(((c + 1) * N <= npoly ? N : npoly - c * N) << 4) : 0u; };
+                    if (i < nch) {
+                        m.fa_dst = a + ((i * N) << k); m.fa_src = m.fa_dst;      // in place on a (timing only)
+                        m.fb_dst = sc[i & 1]; m.fb_src = b + ((i * N) << k);
+                        m.n_tiles[0] = m.n_tiles[1] = cnt(i);
+                    }
+                    if (i >= 1 && i - 1 < nch) { m.rows_a = a + (((i - 1) * N) << k); m.rows_b = sc[(i - 1) & 1]; m.n_tiles[2] = cnt(i - 1); }
+                    if (i >= 2 && i - 2 < nch) { m.inv = a + (((i - 2) * N) << k); m.n_tiles[3] = cnt(i - 2); }
+                    unsigned mx = 0;
+                    for (int q = 0; q < 4; q++) mx = m.n_tiles[q] > mx ? m.n_tiles[q] : mx;
+                    const unsigned grid = ((4u * mx + 255u) / 256u) * 256u;
+                    hipLaunchKernelGGL(mixed256_kernel, dim3(grid), dim3(256), 0, 0, m, k, T, T.twist_i_mul);
+                }
+                CK(hipEventRecord(ev[1]));
+                CK(hipDeviceSynchronize());
+                float ms; CK(hipEventElapsedTime(&ms, ev[0], ev[1]));
+                if (r >= 0) tot += ms;
+            }
+            printf("pipeline, chunks of %4zu elements (%zu launches): %.3f ms per batch\n", N, nch + 2, tot / reps);
+            CK(hipFree(sc[0])); CK(hipFree(sc[1]));
+        }
+    }
+#endif
     printf("npoly %zu  cols_a %.3f  cols_b %.3f  rows %.3f  cols_inv %.3f  total %.3f ms\n", npoly, acc[0] / reps, acc[1] / reps,
            acc[2] / reps, acc[3] / reps, (acc[0] + acc[1] + acc[2] + acc[3]) / reps);
     return 0;
