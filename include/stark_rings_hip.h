@@ -86,8 +86,9 @@ typedef struct sr_plan {
     uint32_t flags;               /* OR of sr_plan_flags                                                                       */
     int32_t log_tile;             /* 0 = default; 8..12: LDS tile of the generic kernels                                       */
     int32_t stark_whole_max;      /* 0 = default (11); 9..12: largest log2 D the Stark kernels keep as one tile per element    */
-    uint32_t chunk_polys;         /* fused ring products above one tile: ring elements per chunk of launches (0 = as many as the
-                                     operand scratch holds)                                                                    */
+    uint32_t chunk_polys;         /* fused ring products above one tile: ring elements per chunk of launches (0 = default: as many
+                                     as the operand scratch holds; the tuned Goldilocks path cuts a batch of 64 or more elements
+                                     into eight chunks)                                                                        */
     uint64_t scratch_limit_bytes; /* cap of the operand scratch (0 = default 16 GiB); larger batches run in chunks             */
     uint32_t host_chunk_mb;       /* chunk of the host-pointer pipeline in MiB (0 = default 128)                               */
     uint32_t reserved;

@@ -441,6 +441,14 @@ size_t scratch_polys(const sr_ctx *c, size_t batch, size_t elem_bytes) {
     if (c->plan.chunk_polys && n > c->plan.chunk_polys) n = c->plan.chunk_polys;
     return n < batch ? n : batch;
 }
+// tuned Goldilocks path: a large batch runs as eight chunks of launches (unless the plan fixes chunk_polys) -- measured on config 2:
+// 18.6 ms as one set of launches, 18.27 / 18.3 / 18.5 ms in chunks of 2048 / 4096 / 1024 ring elements (the inverse column pass
+// finds part of the rows kernel's output still in the Infinity Cache), and the operand scratch is an eighth of the batch
+size_t gl_chunk_polys(const sr_ctx *c, size_t batch) {
+    size_t chunk = scratch_polys(c, batch, (size_t)8 << c->k);
+    if (!c->plan.chunk_polys && batch >= 64 && chunk > (batch + 7) / 8) chunk = (batch + 7) / 8;
+    return chunk;
+}
 template <class F>
 int ring_mul_dev(sr_ctx *c, uint64_t *out, const uint64_t *a, const uint64_t *b, size_t batch, hipStream_t st) {
     using S = typename F::storage;
@@ -876,9 +884,8 @@ int dev_ring_mul(sr_ctx *c, uint64_t *out, const uint64_t *a, const uint64_t *b,
         uint64_t *scratch = nullptr;
         size_t chunk = 0;
         if (c->k > 12 && batch) {  // b's column stages go through the operand scratch
-            const size_t elem = (size_t)8 << c->k;
-            chunk = scratch_polys(c, batch, elem);
-            if (int rc = ensure_scratch(c, 1, chunk * elem)) return rc;
+            chunk = gl_chunk_polys(c, batch);
+            if (int rc = ensure_scratch(c, 1, chunk * ((size_t)8 << c->k))) return rc;
             if (int rc = rt_scratch_acquire(c, st)) return rc;
             scratch = reinterpret_cast<uint64_t *>(c->rt_scratch[0]);
         }
@@ -1428,7 +1435,8 @@ int sr_ctx_reserve_scratch(sr_ctx *c, size_t batch) {
                                 ? c->k <= 12
                                 : (c->stark_tuned ? c->stark_one_tile : c->k <= c->log_tile);
     if (one_launch) return SR_OK;
-    return ensure_scratch(c, 1, scratch_polys(c, batch, elem) * elem);
+    const bool gl = c->ring == SR_RING_GOLDILOCKS_POW2 && c->fast_goldilocks && sr::gl_fast_supported(c->gl_fast);
+    return ensure_scratch(c, 1, (gl ? gl_chunk_polys(c, batch) : scratch_polys(c, batch, elem)) * elem);
 }
 int sr_reduce_batch_dev(sr_ctx *c, const uint64_t *in, size_t in_len, uint64_t *out, size_t batch, void *stream) {
     if (int rc = check(c, in, out)) return rc;
