@@ -170,9 +170,8 @@ int sr_rot_batch(sr_ctx *ctx, uint64_t *data, size_t batch);
  * form: digit j of element e is ring element e * padding_size + j of d_out (batch * padding_size elements) --
  * GadgetDecompose for &[R] (crates/ring/src/balanced_decomposition/mod.rs:163-175) over Decompose for the ring
  * (cyclotomic_ring/coeff_form.rs:587-605) over decompose_balanced_in_place (mod.rs:62-117; signed representative
- * fq_convertible.rs:21-35, stark_prime/decomposition.rs:41-53).  basis: any even value in [2, 2^64) (the reference takes a u128
- * and panics on 0, 1 and odd values: SR_E_INVALID here; a basis of 2^64 or more, which only the 252-bit prime could use, is the
- * one remaining narrowing).  Every ring id; digits are field elements in the same Montgomery
+ * fq_convertible.rs:21-35, stark_prime/decomposition.rs:41-53).  basis: any even value in [2, 2^64) here and the reference's whole u128 range through the
+ * _wide forms below (it panics on 0, 1 and odd values: SR_E_INVALID).  Every ring id; digits are field elements in the same Montgomery
  * layout.  A coefficient that needs more than padding_size digits makes the reference panic (out[i] out of bounds): the
  * device form writes the first padding_size digits and counts it (sr_decompose_overflow_count reads and clears the count,
  * synchronising the stream); the host form returns SR_E_INVALID. */
@@ -184,6 +183,17 @@ int sr_recompose_batch_dev(sr_ctx *ctx, uint64_t *d_out, const uint64_t *d_in, u
                            size_t batch_out, void *stream);
 int sr_decompose_balanced_batch(sr_ctx *ctx, uint64_t *out, const uint64_t *in, uint64_t basis, size_t padding_size, size_t batch);
 int sr_recompose_batch(sr_ctx *ctx, uint64_t *out, const uint64_t *in, uint64_t basis, size_t padding_size, size_t batch_out);
+/* The reference's full u128 basis range: basis = basis_hi * 2^64 + basis_lo (basis_hi = 0: the calls above).  With basis >= 2^64 a
+ * coefficient of a one-limb field (|x| < 2^63 < basis / 2) is its own digit 0 and every other digit is zero; for the 252-bit Stark
+ * prime the digits come from a 256-by-128-bit division per digit. */
+int sr_decompose_balanced_batch_wide_dev(sr_ctx *ctx, uint64_t *d_out, const uint64_t *d_in, uint64_t basis_lo, uint64_t basis_hi,
+                                         size_t padding_size, size_t batch, void *stream);
+int sr_recompose_batch_wide_dev(sr_ctx *ctx, uint64_t *d_out, const uint64_t *d_in, uint64_t basis_lo, uint64_t basis_hi,
+                                size_t padding_size, size_t batch_out, void *stream);
+int sr_decompose_balanced_batch_wide(sr_ctx *ctx, uint64_t *out, const uint64_t *in, uint64_t basis_lo, uint64_t basis_hi,
+                                     size_t padding_size, size_t batch);
+int sr_recompose_batch_wide(sr_ctx *ctx, uint64_t *out, const uint64_t *in, uint64_t basis_lo, uint64_t basis_hi, size_t padding_size,
+                            size_t batch_out);
 /* Third "next" row: the ark-serialize canonical wire format of a batch of ring elements --
  * CanonicalSerialize / CanonicalDeserialize for RqPoly (crates/ring/src/cyclotomic_ring/coeff_form.rs:154-189) and RqNTT
  * (ntt_form.rs:24, derived), both the flat coefficient array: each coefficient is the standard-form integer (out of

@@ -48,6 +48,10 @@ SYMBOLS = {
     "sr_recompose_batch_dev": (_c.c_int, [_c.c_void_p] * 3 + [_c.c_uint64, _c.c_size_t, _c.c_size_t, _c.c_void_p]),
     "sr_decompose_balanced_batch": (_c.c_int, [_c.c_void_p] * 3 + [_c.c_uint64, _c.c_size_t, _c.c_size_t]),
     "sr_recompose_batch": (_c.c_int, [_c.c_void_p] * 3 + [_c.c_uint64, _c.c_size_t, _c.c_size_t]),
+    "sr_decompose_balanced_batch_wide_dev": (_c.c_int, [_c.c_void_p] * 3 + [_c.c_uint64, _c.c_uint64, _c.c_size_t, _c.c_size_t, _c.c_void_p]),
+    "sr_recompose_batch_wide_dev": (_c.c_int, [_c.c_void_p] * 3 + [_c.c_uint64, _c.c_uint64, _c.c_size_t, _c.c_size_t, _c.c_void_p]),
+    "sr_decompose_balanced_batch_wide": (_c.c_int, [_c.c_void_p] * 3 + [_c.c_uint64, _c.c_uint64, _c.c_size_t, _c.c_size_t]),
+    "sr_recompose_batch_wide": (_c.c_int, [_c.c_void_p] * 3 + [_c.c_uint64, _c.c_uint64, _c.c_size_t, _c.c_size_t]),
     "sr_wire_coeff_bytes": (_c.c_size_t, [_c.c_void_p]),
     "sr_serialize_batch_dev": (_c.c_int, [_c.c_void_p] * 4 + [_c.c_size_t, _c.c_void_p]),
     "sr_deserialize_batch_dev": (_c.c_int, [_c.c_void_p] * 4 + [_c.c_size_t, _c.c_void_p]),

@@ -767,6 +767,56 @@ int dev_decompose(sr_ctx *c, uint64_t *out, const uint64_t *in, uint64_t b, size
 int dev_recompose(sr_ctx *c, uint64_t *out, const uint64_t *in, uint64_t b, size_t k, size_t batch_out, hipStream_t st) {
     DISPATCH_FIELD(c, (recompose_dev<F>(c, out, in, b, k, batch_out, st)));
 }
+uint64_t field_modulus64(const sr_ctx *c) {
+    switch (c->ring) {
+        case SR_RING_GOLDILOCKS_POW2: case SR_RING_GOLDILOCKS_24: return sr::Goldilocks::P;
+        case SR_RING_BABYBEAR_POW2: case SR_RING_BABYBEAR_72: return sr::BabyBear::P;
+        default: return sr::Frog::P;
+    }
+}
+// basis = hi * 2^64 + lo with hi != 0 (the reference takes a u128).  One-limb fields: |x| <= (p - 1) / 2 < 2^63 < basis / 2, so digit 0
+// is the coefficient itself and every other digit is zero -- a strided copy; Stark: 128-bit restoring division (decompose.hpp).
+int dev_decompose_wide(sr_ctx *c, uint64_t *out, const uint64_t *in, uint64_t lo, uint64_t hi, size_t k, size_t batch, hipStream_t st) {
+    if (batch == 0 || k == 0) return SR_OK;
+    const size_t w = c->degree * c->limbs * 8;
+    ProfScope ps(c, st, K_OTHER);
+    if (c->ring == SR_RING_STARK_POW2) {
+        const size_t n = batch * c->degree;
+        hipLaunchKernelGGL(sr::dec::decompose_wide_kernel, dim3(sr::stream_blocks<sr::Stark>(n)), dim3(256), 0, st,
+                           reinterpret_cast<sr::U256Storage *>(out), reinterpret_cast<const sr::U256Storage *>(in), c->degree, batch,
+                           sr::dec::U128{lo, hi}, k, c->d_counter + 2);
+        HIP_TRY(hipGetLastError());
+        return SR_OK;
+    }
+    HIP_TRY(hipMemsetAsync(out, 0, batch * k * w, st));
+    HIP_TRY(hipMemcpy2DAsync(out, k * w, in, w, w, batch, hipMemcpyDeviceToDevice, st));
+    return SR_OK;
+}
+int dev_recompose_wide(sr_ctx *c, uint64_t *out, const uint64_t *in, uint64_t lo, uint64_t hi, size_t k, size_t batch_out, hipStream_t st) {
+    if (batch_out == 0) return SR_OK;
+    if (c->ring == SR_RING_STARK_POW2) {
+        const size_t n = batch_out * c->degree;
+        ProfScope ps(c, st, K_OTHER);
+        hipLaunchKernelGGL(sr::dec::recompose_wide_kernel, dim3(sr::stream_blocks<sr::Stark>(n)), dim3(256), 0, st,
+                           reinterpret_cast<sr::U256Storage *>(out), reinterpret_cast<const sr::U256Storage *>(in), c->degree, batch_out,
+                           sr::dec::U128{lo, hi}, k);
+        HIP_TRY(hipGetLastError());
+        return SR_OK;
+    }
+    const unsigned __int128 b = ((unsigned __int128)hi << 64) | lo;  // R::from(b): b mod p, then the narrow Horner kernel
+    return dev_recompose(c, out, in, (uint64_t)(b % field_modulus64(c)), k, batch_out, st);
+}
+int check_basis_wide(uint64_t lo, uint64_t hi) {
+    if (hi == 0) return check_basis(lo);
+    if (lo & 1) return fail(SR_E_INVALID, "decomposition basis must be even");
+    return SR_OK;
+}
+int dev_decompose_any(sr_ctx *c, uint64_t *out, const uint64_t *in, uint64_t lo, uint64_t hi, size_t k, size_t batch, hipStream_t st) {
+    return hi ? dev_decompose_wide(c, out, in, lo, hi, k, batch, st) : dev_decompose(c, out, in, lo, k, batch, st);
+}
+int dev_recompose_any(sr_ctx *c, uint64_t *out, const uint64_t *in, uint64_t lo, uint64_t hi, size_t k, size_t batch_out, hipStream_t st) {
+    return hi ? dev_recompose_wide(c, out, in, lo, hi, k, batch_out, st) : dev_recompose(c, out, in, lo, k, batch_out, st);
+}
 
 int ensure_stage(sr_ctx *c, int which, size_t bytes) {
     if (c->stage_bytes[which] >= bytes) return SR_OK;
@@ -1216,15 +1266,19 @@ int sr_wire_invalid_count(sr_ctx *c, unsigned long long *out, void *stream) {
     HIP_TRY(hipStreamSynchronize(st));
     return SR_OK;
 }
-int sr_decompose_balanced_batch_dev(sr_ctx *c, uint64_t *out, const uint64_t *in, uint64_t basis, size_t padding_size, size_t batch,
-                                    void *stream) {
+int sr_decompose_balanced_batch_wide_dev(sr_ctx *c, uint64_t *out, const uint64_t *in, uint64_t basis_lo, uint64_t basis_hi,
+                                         size_t padding_size, size_t batch, void *stream) {
     if (int rc = check(c, out, in)) return rc;
     if (int rc = check_count(c, batch, padding_size)) return rc;
-    if (int rc = check_basis(basis)) return rc;
+    if (int rc = check_basis_wide(basis_lo, basis_hi)) return rc;
     if (out == in) return fail(SR_E_INVALID, "decompose: out must not alias in");
     std::lock_guard<std::mutex> lk(c->mu);
     DeviceGuard g(c->device);
-    return dev_decompose(c, out, in, basis, padding_size, batch, (hipStream_t)stream);
+    return dev_decompose_any(c, out, in, basis_lo, basis_hi, padding_size, batch, (hipStream_t)stream);
+}
+int sr_decompose_balanced_batch_dev(sr_ctx *c, uint64_t *out, const uint64_t *in, uint64_t basis, size_t padding_size, size_t batch,
+                                    void *stream) {
+    return sr_decompose_balanced_batch_wide_dev(c, out, in, basis, 0, padding_size, batch, stream);
 }
 int sr_decompose_overflow_count(sr_ctx *c, unsigned long long *out, void *stream) {
     if (int rc = check(c, out)) return rc;
@@ -1236,14 +1290,18 @@ int sr_decompose_overflow_count(sr_ctx *c, unsigned long long *out, void *stream
     HIP_TRY(hipStreamSynchronize(st));
     return SR_OK;
 }
-int sr_recompose_batch_dev(sr_ctx *c, uint64_t *out, const uint64_t *in, uint64_t basis, size_t padding_size, size_t batch_out,
-                           void *stream) {
+int sr_recompose_batch_wide_dev(sr_ctx *c, uint64_t *out, const uint64_t *in, uint64_t basis_lo, uint64_t basis_hi, size_t padding_size,
+                                size_t batch_out, void *stream) {
     if (int rc = check(c, out, in)) return rc;
     if (int rc = check_count(c, batch_out, padding_size)) return rc;
     if (out == in) return fail(SR_E_INVALID, "recompose: out must not alias in");
     std::lock_guard<std::mutex> lk(c->mu);
     DeviceGuard g(c->device);
-    return dev_recompose(c, out, in, basis, padding_size, batch_out, (hipStream_t)stream);
+    return dev_recompose_any(c, out, in, basis_lo, basis_hi, padding_size, batch_out, (hipStream_t)stream);
+}
+int sr_recompose_batch_dev(sr_ctx *c, uint64_t *out, const uint64_t *in, uint64_t basis, size_t padding_size, size_t batch_out,
+                           void *stream) {
+    return sr_recompose_batch_wide_dev(c, out, in, basis, 0, padding_size, batch_out, stream);
 }
 
 // ---- host-pointer variants of the linear-algebra entry points: temporaries are allocated per call (these are
@@ -1327,9 +1385,13 @@ int sr_spmv_ntt(sr_ctx *c, uint64_t *y, const uint64_t *vals, const uint32_t *co
     return SR_OK;
 }
 int sr_decompose_balanced_batch(sr_ctx *c, uint64_t *out, const uint64_t *in, uint64_t basis, size_t padding_size, size_t batch) {
+    return sr_decompose_balanced_batch_wide(c, out, in, basis, 0, padding_size, batch);
+}
+int sr_decompose_balanced_batch_wide(sr_ctx *c, uint64_t *out, const uint64_t *in, uint64_t basis, uint64_t basis_hi, size_t padding_size,
+                                     size_t batch) {
     if (int rc = check(c, out, in)) return rc;
     if (int rc = check_count(c, batch, padding_size)) return rc;
-    if (int rc = check_basis(basis)) return rc;
+    if (int rc = check_basis_wide(basis, basis_hi)) return rc;
     std::lock_guard<std::mutex> lk(c->mu);
     DeviceGuard g(c->device);
     const size_t w = c->degree * c->limbs * 8;
@@ -1339,7 +1401,7 @@ int sr_decompose_balanced_batch(sr_ctx *c, uint64_t *out, const uint64_t *in, ui
     if (int rc = dout.alloc(batch * padding_size * w)) return rc;
     HIP_TRY(hipMemcpyAsync(din.p, in, batch * w, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemsetAsync(c->d_counter + 2, 0, sizeof(unsigned long long), c->stream));
-    if (int rc = dev_decompose(c, (uint64_t *)dout.p, (const uint64_t *)din.p, basis, padding_size, batch, c->stream)) return rc;
+    if (int rc = dev_decompose_any(c, (uint64_t *)dout.p, (const uint64_t *)din.p, basis, basis_hi, padding_size, batch, c->stream)) return rc;
     unsigned long long over = 0;
     HIP_TRY(hipMemcpyAsync(&over, c->d_counter + 2, sizeof over, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipMemcpyAsync(out, dout.p, batch * padding_size * w, hipMemcpyDeviceToHost, c->stream));
@@ -1389,6 +1451,10 @@ int sr_deserialize_batch(sr_ctx *c, uint64_t *out, const uint8_t *wire, size_t b
     return SR_OK;
 }
 int sr_recompose_batch(sr_ctx *c, uint64_t *out, const uint64_t *in, uint64_t basis, size_t padding_size, size_t batch_out) {
+    return sr_recompose_batch_wide(c, out, in, basis, 0, padding_size, batch_out);
+}
+int sr_recompose_batch_wide(sr_ctx *c, uint64_t *out, const uint64_t *in, uint64_t basis, uint64_t basis_hi, size_t padding_size,
+                            size_t batch_out) {
     if (int rc = check(c, out, in)) return rc;
     if (int rc = check_count(c, batch_out, padding_size)) return rc;
     std::lock_guard<std::mutex> lk(c->mu);
@@ -1399,7 +1465,7 @@ int sr_recompose_batch(sr_ctx *c, uint64_t *out, const uint64_t *in, uint64_t ba
     if (int rc = din.alloc(batch_out * padding_size * w)) return rc;
     if (int rc = dout.alloc(batch_out * w)) return rc;
     if (padding_size) HIP_TRY(hipMemcpyAsync(din.p, in, batch_out * padding_size * w, hipMemcpyHostToDevice, c->stream));
-    if (int rc = dev_recompose(c, (uint64_t *)dout.p, (const uint64_t *)din.p, basis, padding_size, batch_out, c->stream)) return rc;
+    if (int rc = dev_recompose_any(c, (uint64_t *)dout.p, (const uint64_t *)din.p, basis, basis_hi, padding_size, batch_out, c->stream)) return rc;
     HIP_TRY(hipMemcpyAsync(out, dout.p, batch_out * w, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return SR_OK;

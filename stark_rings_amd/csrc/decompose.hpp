@@ -298,5 +298,84 @@ __global__ __launch_bounds__(256) void recompose_kernel(typename F::storage *out
     }
 }
 
+// ---- bases of 2^64 and more (the reference takes a u128) -- Stark only: the one-limb fields have |x| <= (p - 1) / 2 < 2^63 < b / 2,
+// so their decomposition is digit 0 = x, every other digit 0, and capi.hip does that with a copy ----------------------------------
+struct U128 {
+    uint64_t lo, hi;
+};
+SR_HD bool u128_gt(const U128 &a, const U128 &b) { return a.hi > b.hi || (a.hi == b.hi && a.lo > b.lo); }
+SR_HD bool u128_geq(const U128 &a, const U128 &b) { return a.hi > b.hi || (a.hi == b.hi && a.lo >= b.lo); }
+SR_HD U128 u128_sub(const U128 &a, const U128 &b) {
+    U128 r;
+    r.lo = a.lo - b.lo;
+    r.hi = a.hi - b.hi - (a.lo < b.lo ? 1 : 0);
+    return r;
+}
+SR_HD U256 u256_from_u128(const U128 &v) {
+    U256 e = Stark::zero();
+    e.l[0] = (uint32_t)v.lo;
+    e.l[1] = (uint32_t)(v.lo >> 32);
+    e.l[2] = (uint32_t)v.hi;
+    e.l[3] = (uint32_t)(v.hi >> 32);
+    return e;
+}
+// m /= b, returns m mod b, for 2^64 <= b < 2^128: restoring division, one quotient bit per step
+SR_HD U128 divrem_wide(U256 &m, const U128 &b) {
+    U128 r{0, 0};
+#pragma unroll 1
+    for (int i = 7; i >= 0; i--) {
+        uint32_t q = 0;
+        const uint32_t limb = m.l[i];
+#pragma unroll 1
+        for (int bit = 31; bit >= 0; bit--) {
+            const bool carry = (r.hi >> 63) != 0;
+            r.hi = (r.hi << 1) | (r.lo >> 63);
+            r.lo = (r.lo << 1) | ((limb >> bit) & 1u);
+            if (carry || u128_geq(r, b)) {
+                r = u128_sub(r, b);
+                q |= 1u << bit;
+            }
+        }
+        m.l[i] = q;
+    }
+    return r;
+}
+__global__ __launch_bounds__(256) void decompose_wide_kernel(U256Storage *out, const U256Storage *in, size_t d, size_t batch, U128 b,
+                                                             size_t k, unsigned long long *overflow) {
+    const size_t n = batch * d;
+    const U128 half{(b.lo >> 1) | (b.hi << 63), b.hi >> 1};
+    for (size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x; t < n; t += (size_t)gridDim.x * blockDim.x) {
+        const size_t e = t / d, i = t - e * d;
+        Mag<Stark> cur = Mag<Stark>::from_image(Stark::load(in + t));
+        U256Storage *o = out + e * k * d + i;
+        for (size_t j = 0; j < k; j++) {
+            const U128 rem = divrem_wide(cur.m, b);
+            U128 dig = rem;
+            bool dneg = cur.neg;
+            if (u128_gt(rem, half)) {
+                dig = u128_sub(b, rem);
+                dneg = !cur.neg;
+                cur.inc();
+            }
+            U256 v = Stark::mul_boundary(u256_from_u128(dig), Consts<Stark>::r2());
+            if (dneg && (dig.lo | dig.hi)) v = Stark::sub(Stark::zero(), v);
+            Stark::store(o + j * d, v);
+        }
+        if (!cur.is_zero()) atomicAdd(overflow, 1ull);
+    }
+}
+__global__ __launch_bounds__(256) void recompose_wide_kernel(U256Storage *out, const U256Storage *in, size_t d, size_t batch_out,
+                                                             U128 b, size_t k) {
+    const size_t n = batch_out * d;
+    const U256 bimg = Stark::mul_boundary(u256_from_u128(b), Consts<Stark>::r2());  // b < 2^128 < p
+    for (size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x; t < n; t += (size_t)gridDim.x * blockDim.x) {
+        const size_t e = t / d, i = t - e * d;
+        const U256Storage *src = in + e * k * d + i;
+        U256 acc = Stark::zero();
+        for (size_t j = k; j-- > 0;) acc = Stark::add(Stark::mul_boundary(acc, bimg), Stark::load(src + j * d));
+        Stark::store(out + t, acc);
+    }
+}
+
 }  // namespace dec
 }  // namespace sr

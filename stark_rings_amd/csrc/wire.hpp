@@ -93,6 +93,20 @@ __global__ __launch_bounds__(256) void serialize_kernel(uint8_t *out, const type
             return;
         }
     }
+    if constexpr (W == 8 && sizeof(typename F::storage) == 8) {
+        if (!offsets && !(n & 1) && !((((uintptr_t)in) | ((uintptr_t)out)) & 15)) {  // dense 8-byte fields: two coefficients per lane, 16 B each way
+            const ulonglong2 *src = reinterpret_cast<const ulonglong2 *>(in);
+            for (size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x; t < n / 2; t += (size_t)gridDim.x * blockDim.x) {
+                const ulonglong2 v = src[t];
+                typename F::storage w[2] = {v.x, v.y};
+                alignas(16) uint8_t o[16];
+                Codec<F>::put(o, F::load(&w[0]));
+                Codec<F>::put(o + 8, F::load(&w[1]));
+                reinterpret_cast<ulonglong2 *>(out)[t] = *reinterpret_cast<const ulonglong2 *>(o);
+            }
+            return;
+        }
+    }
     for (size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x; t < n; t += (size_t)gridDim.x * blockDim.x) {
         const size_t e = t / d, i = t - e * d;
         const size_t base = offsets ? (size_t)offsets[e] : e * d * W;
@@ -121,6 +135,27 @@ __global__ __launch_bounds__(256) void deserialize_kernel(typename F::storage *o
                 nbad += !ok0 + !ok1;
                 dst[t] = make_uint4(BabyBear::mul_boundary(ok0 ? v.x : 0u, dec::Consts<BabyBear>::r2()), 0u,
                                     BabyBear::mul_boundary(ok1 ? v.y : 0u, dec::Consts<BabyBear>::r2()), 0u);
+            }
+            if (nbad) atomicAdd(bad, nbad);
+            return;
+        }
+    }
+    if constexpr (W == 8 && sizeof(typename F::storage) == 8) {
+        if (!offsets && !(n & 1) && !((((uintptr_t)in) | ((uintptr_t)out)) & 15)) {  // dense 8-byte fields: two coefficients per lane
+            unsigned long long nbad = 0;
+            for (size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x; t < n / 2; t += (size_t)gridDim.x * blockDim.x) {
+                alignas(16) uint8_t w[16];
+                *reinterpret_cast<ulonglong2 *>(w) = reinterpret_cast<const ulonglong2 *>(in)[t];
+                typename F::elem i0, i1;
+                nbad += !Codec<F>::get(i0, w);
+                nbad += !Codec<F>::get(i1, w + 8);
+                typename F::storage o[2];
+                F::store(&o[0], i0);
+                F::store(&o[1], i1);
+                ulonglong2 ov;
+                ov.x = o[0];
+                ov.y = o[1];
+                reinterpret_cast<ulonglong2 *>(out)[t] = ov;
             }
             if (nbad) atomicAdd(bad, nbad);
             return;

@@ -218,7 +218,10 @@ class CyclotomicRing:
         batch = self._batch_of(a.size)
         out = np.empty(max(batch * padding_size * self.words_per_elem, 1), dtype=np.uint64)
         src = a if a.size else np.zeros(1, dtype=np.uint64)
-        self._check(self._lib.sr_decompose_balanced_batch(self._ctx, _np_ptr(out), _np_ptr(src), basis, padding_size, batch))
+        if not 0 <= basis < 1 << 128:
+            raise RingError("basis out of the u128 range")
+        self._check(self._lib.sr_decompose_balanced_batch_wide(self._ctx, _np_ptr(out), _np_ptr(src), basis & (2**64 - 1), basis >> 64,
+                                                               padding_size, batch))
         return out[:batch * padding_size * self.words_per_elem]
 
     def gadget_recompose(self, digits, basis, padding_size):
@@ -229,7 +232,8 @@ class CyclotomicRing:
         batch_out = n // padding_size
         out = np.empty(max(batch_out * self.words_per_elem, 1), dtype=np.uint64)
         src = digits if digits.size else np.zeros(1, dtype=np.uint64)
-        self._check(self._lib.sr_recompose_batch(self._ctx, _np_ptr(out), _np_ptr(src), basis, padding_size, batch_out))
+        self._check(self._lib.sr_recompose_batch_wide(self._ctx, _np_ptr(out), _np_ptr(src), basis & (2**64 - 1), basis >> 64,
+                                                      padding_size, batch_out))
         return out[:batch_out * self.words_per_elem]
 
     # -- GadgetDecompose / GadgetRecompose for Matrix<R> and SparseMatrix<R> (balanced_decomposition/mod.rs:276-352) ------------
@@ -446,8 +450,8 @@ class CyclotomicRing:
         pa, m = self._dev(a)
         if n != m * padding_size:
             raise RingError("decompose: out must hold len * padding_size elements")
-        self._check(self._lib.sr_decompose_balanced_batch_dev(self._ctx, po, pa, basis, padding_size, self._batch_of(m),
-                                                             self._stream(stream)))
+        self._check(self._lib.sr_decompose_balanced_batch_wide_dev(self._ctx, po, pa, basis & (2**64 - 1), basis >> 64, padding_size,
+                                                                  self._batch_of(m), self._stream(stream)))
         return out
 
     def decompose_overflow_count(self, stream=None):
@@ -460,7 +464,8 @@ class CyclotomicRing:
         pd, m = self._dev(digits)
         if m != n * padding_size:
             raise RingError("recompose: digits must hold len(out) * padding_size elements")
-        self._check(self._lib.sr_recompose_batch_dev(self._ctx, po, pd, basis, padding_size, self._batch_of(n), self._stream(stream)))
+        self._check(self._lib.sr_recompose_batch_wide_dev(self._ctx, po, pd, basis & (2**64 - 1), basis >> 64, padding_size,
+                                                         self._batch_of(n), self._stream(stream)))
         return out
 
     def serialize_dev(self, wire, a, offsets=None, stream=None):
