@@ -323,7 +323,8 @@ def main():
                 peak = 256 * 4 * 2.4e9 / 4
                 valu = {"bound": "valu-issue", "achieved": rate, "peak": peak, "unit": "wave-instructions/s", "frac": rate / peak,
                         "valu_instructions_per_wave": kv["valu_per_wave"], "waves_per_launch": kv["waves_per_launch"],
-                        "note": "supplementary, replayed like roofline.traffic: one wave-instruction per 4 cycles per SIMD as the peak"}
+                        "note": "supplementary, replayed like roofline.traffic: one wave-instruction per 4 cycles per SIMD at the nominal 2.4 GHz as the "
+                                "peak; under this integer-dense kernel the chip holds about 2.0 GHz (profiles/r02/clock_*.txt, DESIGN.md 6.0)"}
     except (OSError, ValueError, KeyError, IndexError, NameError):
         pass
 
