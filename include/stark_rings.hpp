@@ -128,6 +128,13 @@ public:
         CyclotomicConfig::check(sr_ring_mul_batch(cfg_.raw(), w_.data(), w_.data(), rhs.w_.data(), len()), "RqPoly *");
         return *this;
     }
+    // *this = icrt(crt(*this) (.) rhs_ntt words): the constant-operand product (rhs kept in NTT form); defined below RqNTTVec
+    RqPolyVec &mul_assign_ntt_rhs(const std::vector<uint64_t> &rhs_ntt_words) {
+        if (rhs_ntt_words.size() != w_.size()) throw std::length_error("operand lengths differ");
+        CyclotomicConfig::check(sr_ring_mul_ntt_rhs_batch(cfg_.raw(), w_.data(), w_.data(), rhs_ntt_words.data(), len()),
+                                "RqPoly * RqNTT");
+        return *this;
+    }
     friend RqPolyVec operator*(RqPolyVec lhs, const RqPolyVec &rhs) {
         lhs *= rhs;
         return lhs;

@@ -224,6 +224,8 @@ int sr_ring_mul_batch_dev(sr_ctx *ctx, uint64_t *d_out, const uint64_t *d_a, con
  * one of the three transforms saved.  Every ring id (rings without a fused kernel run forward transform, slot product and
  * inverse transform one after the other on d_out).  d_out may alias d_a; d_b_ntt is only read and must not alias d_out. */
 int sr_ring_mul_ntt_rhs_batch_dev(sr_ctx *ctx, uint64_t *d_out, const uint64_t *d_a, const uint64_t *d_b_ntt, size_t batch, void *stream);
+/* host-pointer form (staged through device memory like sr_ring_mul_batch) */
+int sr_ring_mul_ntt_rhs_batch(sr_ctx *ctx, uint64_t *out, const uint64_t *a, const uint64_t *b_ntt, size_t batch);
 int sr_reduce_batch_dev(sr_ctx *ctx, const uint64_t *d_in, size_t in_len_per_elem, uint64_t *d_out, size_t batch, void *stream);
 /* Synthetic coefficients, uniform in [0,p), counter-based (same definition as the oracle's
  * sro_fill_uniform): fills n_coeffs coefficients starting at flat coefficient index first_coeff. */

@@ -61,6 +61,7 @@ SYMBOLS = {
     "sr_rot_batch_dev": (_c.c_int, [_c.c_void_p] * 3 + [_c.c_size_t, _c.c_void_p]),
     "sr_rot_batch": (_c.c_int, [_c.c_void_p, u64p, _c.c_size_t]),
     "sr_ring_mul_batch_dev": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_size_t, _c.c_void_p]),
+    "sr_ring_mul_ntt_rhs_batch": (_c.c_int, [_c.c_void_p, u64p, u64p, u64p, _c.c_size_t]),
     "sr_ring_mul_ntt_rhs_batch_dev": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_size_t, _c.c_void_p]),
     "sr_reduce_batch_dev": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_size_t, _c.c_void_p, _c.c_size_t, _c.c_void_p]),
     "sr_fill_uniform_dev": (_c.c_int, [_c.c_void_p, _c.c_uint64, _c.c_uint64, _c.c_size_t, _c.c_void_p, _c.c_void_p]),

@@ -1660,7 +1660,7 @@ static int host_inplace(sr_ctx *c, uint64_t *data, size_t batch, bool fwd) {
 int sr_ntt_fwd_batch(sr_ctx *c, uint64_t *data, size_t batch) { return host_inplace(c, data, batch, true); }
 int sr_ntt_inv_batch(sr_ctx *c, uint64_t *data, size_t batch) { return host_inplace(c, data, batch, false); }
 
-enum { HB_POINTWISE = 0, HB_RING_MUL = 1, HB_ADD = 2, HB_SUB = 3 };
+enum { HB_POINTWISE = 0, HB_RING_MUL = 1, HB_ADD = 2, HB_SUB = 3, HB_RING_MUL_NTT_RHS = 4 };
 static int host_binary(sr_ctx *c, uint64_t *out, const uint64_t *a, const uint64_t *b, size_t batch, int op) {
     if (int rc = check(c, out, a, b)) return rc;
     if (int rc = check_count(c, batch)) return rc;
@@ -1668,6 +1668,7 @@ static int host_binary(sr_ctx *c, uint64_t *out, const uint64_t *a, const uint64
     DeviceGuard g(c->device);
     return host_pipeline(c, out, a, b, batch, [&](uint64_t *s0, uint64_t *s1, size_t n, hipStream_t st) {
         return op == HB_RING_MUL ? dev_ring_mul(c, s0, s0, s1, n, st)
+               : op == HB_RING_MUL_NTT_RHS ? dev_ring_mul_ntt_rhs(c, s0, s0, s1, n, st)
                : op == HB_POINTWISE ? dev_pointwise(c, s0, s1, n, st)
                                     : dev_addsub(c, s0, s1, n, op == HB_SUB, st);
     });
@@ -1679,6 +1680,9 @@ int sr_add_batch(sr_ctx *c, uint64_t *lhs, const uint64_t *rhs, size_t batch) { 
 int sr_sub_batch(sr_ctx *c, uint64_t *lhs, const uint64_t *rhs, size_t batch) { return host_binary(c, lhs, lhs, rhs, batch, HB_SUB); }
 int sr_ring_mul_batch(sr_ctx *c, uint64_t *out, const uint64_t *a, const uint64_t *b, size_t batch) {
     return host_binary(c, out, a, b, batch, HB_RING_MUL);
+}
+int sr_ring_mul_ntt_rhs_batch(sr_ctx *c, uint64_t *out, const uint64_t *a, const uint64_t *b_ntt, size_t batch) {
+    return host_binary(c, out, a, b_ntt, batch, HB_RING_MUL_NTT_RHS);
 }
 int sr_reduce_batch(sr_ctx *c, const uint64_t *in, size_t in_len, uint64_t *out, size_t batch) {
     if (int rc = check(c, in, out)) return rc;

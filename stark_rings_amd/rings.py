@@ -512,6 +512,14 @@ class CyclotomicRing:
         self._check(self._lib.sr_wire_invalid_count(self._ctx, ctypes.byref(n), self._stream(stream)))
         return int(n.value)
 
+    def mul_ntt_rhs(self, a, b_ntt):
+        """Host buffers: icrt(crt(a) (.) b_ntt) with b_ntt = crt(b) already in CRT/NTT form; returns a new array."""
+        if a.size != b_ntt.size:
+            raise RingError("operand lengths differ")
+        out = np.empty_like(a)
+        self._check(self._lib.sr_ring_mul_ntt_rhs_batch(self._ctx, _np_ptr(out), _np_ptr(a), _np_ptr(b_ntt), self._batch_of(a.size)))
+        return out
+
     def mul_ntt_rhs_dev(self, out, a, b_ntt, stream=None):
         """out = icrt(crt(a) (.) b_ntt) for b_ntt = crt(b) already in CRT/NTT form (the constant-operand product); a and b_ntt
         are only read; out may be a."""

@@ -1246,6 +1246,8 @@ def test_ring_mul_with_ntt_form_rhs(torch_cuda, name, k):
     ring.mul_ntt_rhs_dev(ta, ta, tbn)
     assert torch.equal(ta, want)
     assert w * batch == ta.numel()
+    # host-pointer form
+    assert np.array_equal(ring.mul_ntt_rhs(a, ring.elementwise_crt(b.copy())), want.cpu().numpy().view(np.uint64))
 
 
 def test_plan_struct_is_validated_and_env_free(torch_cuda):
