@@ -589,16 +589,29 @@ int rt_inv(sr_ctx *c, uint64_t *d, size_t batch, hipStream_t st) {
         return fail(SR_E_HIP, "register-tiled launch failed");
     return rt_scratch_release(c, st);
 }
+// a large batch runs as eight chunks of launches (unless the plan fixes chunk_polys), like the tuned Goldilocks path: measured on
+// config 3 (BabyBear D = 2^16, batch 2^14): 11.68 ms as one set of launches, 11.38 / 11.41 / 11.56 ms in chunks of 2048 / 4096 / 1024
+// ring elements, 12.4 ms and worse below 512 -- and the packed scratch is an eighth of the batch
+size_t rt_chunk_polys(const sr_ctx *c, size_t batch) {
+    if (c->plan.chunk_polys) return c->plan.chunk_polys < batch ? c->plan.chunk_polys : batch;
+    return batch >= 64 ? (batch + 7) / 8 : batch;
+}
 template <class F>
 int rt_ring_mul(sr_ctx *c, uint64_t *out, const uint64_t *a, const uint64_t *b, size_t batch, hipStream_t st) {
     using S = typename F::storage;
     using E = typename F::elem;
-    if (int rc = rt_ensure_scratch(c, 2, (batch << c->k) * sizeof(E))) return rc;
+    if (batch == 0) return SR_OK;
+    const size_t chunk = c->k > 12 ? rt_chunk_polys(c, batch) : batch;
+    if (int rc = rt_ensure_scratch(c, 2, (chunk << c->k) * sizeof(E))) return rc;
     if (int rc = rt_scratch_acquire(c, st)) return rc;
-    if (sr::rt::ring_mul<F>(c->rt_hooks, reinterpret_cast<S *>(out), reinterpret_cast<const S *>(a),
-                            reinterpret_cast<const S *>(b), batch, make_rt_params<F>(c, true), (E *)c->rt_scratch[0],
-                            (E *)c->rt_scratch[1], st))
-        return fail(SR_E_HIP, "register-tiled launch failed");
+    for (size_t e = 0; e < batch; e += chunk) {
+        const size_t n = batch - e < chunk ? batch - e : chunk;
+        const size_t off = e << c->k;
+        if (sr::rt::ring_mul<F>(c->rt_hooks, reinterpret_cast<S *>(out) + off, reinterpret_cast<const S *>(a) + off,
+                                reinterpret_cast<const S *>(b) + off, n, make_rt_params<F>(c, true), (E *)c->rt_scratch[0],
+                                (E *)c->rt_scratch[1], st))
+            return fail(SR_E_HIP, "register-tiled launch failed");
+    }
     return rt_scratch_release(c, st);
 }
 
@@ -1495,7 +1508,7 @@ int sr_ctx_reserve_scratch(sr_ctx *c, size_t batch) {
     const size_t elem = c->degree * c->limbs * 8;
     if (c->regtile) {
         const size_t w = c->ring == SR_RING_BABYBEAR_POW2 ? 4 : 8;
-        return rt_ensure_scratch(c, 2, (batch << c->k) * w);
+        return rt_ensure_scratch(c, 2, ((c->k > 12 ? rt_chunk_polys(c, batch) : batch) << c->k) * w);
     }
     const bool one_launch = c->ring == SR_RING_GOLDILOCKS_POW2 && c->fast_goldilocks && sr::gl_fast_supported(c->gl_fast)
                                 ? c->k <= 12

@@ -1420,21 +1420,21 @@ def test_context_group_shares_one_twiddle_block(torch_cuda):
             lib.sr_ctx_destroy(c)
 
 
-@pytest.mark.parametrize("k,batch", [(13, 70), (16, 67)])
-def test_ring_mul_in_default_chunks(torch_cuda, k, batch):
-    """Default plan of the tuned Goldilocks path for batches >= 64 above one tile: eight chunks of launches through a scratch of one
+@pytest.mark.parametrize("name,k,batch", [("goldilocks", 13, 70), ("goldilocks", 16, 67), ("babybear", 16, 67), ("babybear", 13, 70)])
+def test_ring_mul_in_default_chunks(torch_cuda, name, k, batch):
+    """Default plan of the tuned Goldilocks path and of the register-tiled BabyBear path for batches >= 64 above one tile: eight chunks of launches through a scratch of one
     chunk (ragged last chunk here); a plan with chunk_polys = batch runs one set of launches.  Same products, operands intact, and
     work queued behind the call on the caller's stream sees the results."""
     torch = torch_cuda
     from stark_rings_amd import CyclotomicRing
 
-    F = O.GOLDILOCKS
+    F = O.FIELD_ID[name]
     n = batch << k
     a = O.fill_uniform(F, 0x61, 0, n)
     b = O.fill_uniform(F, 0x62, 0, n)
     want = O.pow2_ring_mul(F, a, b, k, batch, 8)
     for plan in (_plan(), _plan(chunk_polys=batch)):
-        ring = CyclotomicRing("goldilocks", k, device=0, plan=plan)
+        ring = CyclotomicRing(name, k, device=0, plan=plan)
         ta = torch.from_numpy(a.view(np.int64)).cuda()
         tb = torch.from_numpy(b.view(np.int64)).cuda()
         out = torch.empty_like(ta)
