@@ -213,6 +213,16 @@ def main():
     torch.cuda.synchronize()
     prof = ring.profile_read()
     ring.profile_enable(False)
+    # the timed steps kept multiplying a by the (unchanged) b: the final state must still be a batch of canonical ring elements
+    # whose transform round-trips -- outputs after the warm-up are checked, not only the first step
+    if ring.count_noncanonical_dev(a) != 0:
+        raise SystemExit("PROPERTY FAILURE rank %d: non-canonical outputs after the timed steps" % rank)
+    rt = a[-min(batch, 8) * wpe:].clone()
+    ring.elementwise_crt_dev(rt)
+    ring.elementwise_icrt_dev(rt)
+    if not torch.equal(rt, a[-rt.numel():]):
+        raise SystemExit("PROPERTY FAILURE rank %d: icrt(crt(c)) != c after the timed steps" % rank)
+    del rt
 
     # ---- achievable streaming bandwidth on this box (SURVEY.md 8d asks for the fraction against it as well as against the
     #      8 TB/s spec): a plain device-to-device copy of one operand, read + write counted ----
