@@ -214,7 +214,8 @@ __global__ __launch_bounds__(256) void decompose_kernel(typename F::storage *out
         if ((d & 1) == 0 && ((((uintptr_t)in | (uintptr_t)out) & 15u) == 0)) {
             for (size_t t2 = gid; t2 < (n >> 1); t2 += stride) {
                 const size_t t = t2 << 1, e = t / d, i = t - e * d;
-                const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(in + t);
+                typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+                const u64x2 v = __builtin_nontemporal_load(reinterpret_cast<const u64x2 *>(in + t));
                 typename F::storage w[2] = {v.x, v.y};
                 typename F::storage *o = out + e * k * d + i;
                 // digit j of both coefficients leaves as one 16-byte store: buffer the first coefficient's digits in registers
@@ -236,10 +237,10 @@ __global__ __launch_bounds__(256) void decompose_kernel(typename F::storage *out
                         }
                         F::store(&dg[q], digit_image<F>(dig, dneg));
                     }
-                    ulonglong2 ov;
+                    u64x2 ov;
                     ov.x = dg[0];
                     ov.y = dg[1];
-                    *reinterpret_cast<ulonglong2 *>(o + j * d) = ov;
+                    __builtin_nontemporal_store(ov, reinterpret_cast<u64x2 *>(o + j * d));
                 }
                 const unsigned over = (c0.is_zero() ? 0u : 1u) + (c1.is_zero() ? 0u : 1u);
                 if (over) atomicAdd(overflow, (unsigned long long)over);
@@ -272,8 +273,9 @@ __global__ __launch_bounds__(256) void recompose_kernel(typename F::storage *out
                 const size_t t = t2 << 1, e = t / d, i = t - e * d;
                 const typename F::storage *src = in + e * k * d + i;
                 typename F::elem a0 = F::zero(), a1 = F::zero();
+                typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
                 for (size_t j = k; j-- > 0;) {
-                    const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(src + j * d);
+                    const u64x2 v = __builtin_nontemporal_load(reinterpret_cast<const u64x2 *>(src + j * d));
                     typename F::storage w[2] = {v.x, v.y};
                     a0 = F::add(F::mul_boundary(a0, bimg), F::load(&w[0]));
                     a1 = F::add(F::mul_boundary(a1, bimg), F::load(&w[1]));
@@ -281,10 +283,10 @@ __global__ __launch_bounds__(256) void recompose_kernel(typename F::storage *out
                 typename F::storage o[2];
                 F::store(&o[0], a0);
                 F::store(&o[1], a1);
-                ulonglong2 ov;
+                u64x2 ov;
                 ov.x = o[0];
                 ov.y = o[1];
-                *reinterpret_cast<ulonglong2 *>(out + t) = ov;
+                __builtin_nontemporal_store(ov, reinterpret_cast<u64x2 *>(out + t));
             }
             return;
         }

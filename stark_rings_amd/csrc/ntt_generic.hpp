@@ -211,18 +211,22 @@ __device__ __forceinline__ void elementwise2(typename F::storage *lhs, const typ
     size_t done = 0;
     if constexpr (sizeof(typename F::storage) == 8) {
         if ((((uintptr_t)lhs | (uintptr_t)rhs) & 15u) == 0) {
+            // non-temporal 16-byte accesses, one pair per lane when the grid allows (stream_blocks): the form that streams best on
+            // this box (tools/ubench/stream_rates.hip: a += b at 6.45 TB/s; 5.86 with the default cache policy, 5.6 / 5.2 / 4.9 when
+            // a lane loops 2 / 32 / 256 times)
+            typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
             const size_t pairs = n >> 1;
-            ulonglong2 *l2 = reinterpret_cast<ulonglong2 *>(lhs);
-            const ulonglong2 *r2 = reinterpret_cast<const ulonglong2 *>(rhs);
+            u64x2 *l2 = reinterpret_cast<u64x2 *>(lhs);
+            const u64x2 *r2 = reinterpret_cast<const u64x2 *>(rhs);
             for (size_t i = gid; i < pairs; i += stride) {
-                ulonglong2 x = l2[i];
-                const ulonglong2 y = r2[i];
+                u64x2 x = __builtin_nontemporal_load(l2 + i);
+                const u64x2 y = __builtin_nontemporal_load(r2 + i);
                 typename F::storage xs[2] = {x.x, x.y}, ys[2] = {y.x, y.y};
                 F::store(&xs[0], op(F::load(&xs[0]), F::load(&ys[0])));
                 F::store(&xs[1], op(F::load(&xs[1]), F::load(&ys[1])));
                 x.x = xs[0];
                 x.y = xs[1];
-                l2[i] = x;
+                __builtin_nontemporal_store(x, l2 + i);
             }
             done = pairs << 1;
         }
@@ -241,13 +245,13 @@ template <class F, bool SUB>
 __global__ __launch_bounds__(256) void addsub_kernel(typename F::storage *lhs, const typename F::storage *rhs, size_t n) {
     elementwise2<F>(lhs, rhs, n, [](const typename F::elem &a, const typename F::elem &b) { return SUB ? F::sub(a, b) : F::add(a, b); });
 }
-// workgroups for a streaming kernel over n coefficients: one 16-byte access per lane where the field allows it, a grid-stride
-// loop beyond 2^20 workgroups
+// workgroups for a streaming kernel over n coefficients: one 16-byte access per lane where the field allows it (no grid-stride
+// loop below 2^31 workgroups: a lane that loops streams measurably worse, see elementwise2)
 template <class F>
 inline unsigned stream_blocks(size_t n) {
     const size_t per_lane = sizeof(typename F::storage) == 8 ? 2 : 1;
     size_t blocks = ((n + per_lane - 1) / per_lane + 255) / 256;
-    if (blocks > ((size_t)1 << 20)) blocks = (size_t)1 << 20;
+    if (blocks > 0x7FFFFFFFull) blocks = 0x7FFFFFFFull;
     return (unsigned)(blocks ? blocks : 1);
 }
 
