@@ -33,6 +33,26 @@
 
 namespace sr {
 
+// Workgroup -> tile order of the column passes.  The hardware hands consecutive workgroups to the eight XCDs in turn, so with
+// tile = blockIdx the neighbouring 128-byte column chunks of one leg are fetched through eight different L2s at unrelated moments
+// and DRAM sees its pages opened once per chunk.  xcd_tile() gives runs of 2^cl consecutive tiles (column chunks of one ring
+// element) to ONE XCD, back to back (run 8 g + x goes to XCD x): the 16-column pattern of D = 2^16 then streams at 6.0 instead
+// of 5.4 TB/s (tools/ubench/blocked_pattern.hip).  `grouped` = the launch's tile count rounded down to a multiple of 8 * 2^cl
+// (xcd_grouped_tiles); tiles at or beyond it keep tile = blockIdx.  SR_COLS_XCD_MAP = 0: A/B switch.
+#ifndef SR_COLS_XCD_MAP
+#define SR_COLS_XCD_MAP 1
+#endif
+__device__ __forceinline__ unsigned xcd_tile(unsigned bid, int cl, unsigned grouped) {
+#if SR_COLS_XCD_MAP
+    if (bid < grouped) {
+        const unsigned xcd = bid & 7u, slot = bid >> 3;
+        return ((((slot >> cl) << 3) + xcd) << cl) | (slot & ((1u << cl) - 1u));
+    }
+#endif
+    return bid;
+}
+inline unsigned xcd_grouped_tiles(size_t tiles, int cl) { return (unsigned)(tiles & ~(((size_t)8 << cl) - 1)); }
+
 // ------------------------------------------------------------------------------------------
 // Goldilocks  p = 2^64 - 2^32 + 1
 // ------------------------------------------------------------------------------------------

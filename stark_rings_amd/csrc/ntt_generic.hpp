@@ -246,12 +246,12 @@ __global__ __launch_bounds__(256) void addsub_kernel(typename F::storage *lhs, c
     elementwise2<F>(lhs, rhs, n, [](const typename F::elem &a, const typename F::elem &b) { return SUB ? F::sub(a, b) : F::add(a, b); });
 }
 // workgroups for a streaming kernel over n coefficients: one 16-byte access per lane where the field allows it (no grid-stride
-// loop below 2^31 workgroups: a lane that loops streams measurably worse, see elementwise2)
+// loop below 2^24 workgroups (HIP limits a launch to 2^32 lanes): a lane that loops streams measurably worse, see elementwise2)
 template <class F>
 inline unsigned stream_blocks(size_t n) {
     const size_t per_lane = sizeof(typename F::storage) == 8 ? 2 : 1;
     size_t blocks = ((n + per_lane - 1) / per_lane + 255) / 256;
-    if (blocks > 0x7FFFFFFFull) blocks = 0x7FFFFFFFull;
+    if (blocks > 0xFFFFFFull) blocks = 0xFFFFFFull;  // gridDim.x * 256 must stay below 2^32
     return (unsigned)(blocks ? blocks : 1);
 }
 

@@ -539,13 +539,18 @@ __device__ __forceinline__ void cols256_tile(const unsigned tile, u64 *data, con
     }
 }
 
+// 2^SR_COLS_XCD_GROUP consecutive tiles (column chunks of one ring element: 2 KiB of every leg at 16 columns) per XCD turn
+#ifndef SR_COLS_XCD_GROUP
+#define SR_COLS_XCD_GROUP 4
+#endif
 template <int DIR, int LC>
 __global__ __launch_bounds__(16 << LC, LC == 4 ? SR_COLS_WAVES : 4) void cols256_kernel(u64 *data, const u64 *src, int k,
                                                                                        const u64 *__restrict__ wc,
-                                                                                       const u64 *__restrict__ twist) {
+                                                                                       const u64 *__restrict__ twist,
+                                                                                       unsigned grouped) {
     __shared__ u64 lds[ColsTile<LC>::kElems];
     stagger_first_round();
-    cols256_tile<DIR, LC>(blockIdx.x, data, src, k, wc, twist, lds);
+    cols256_tile<DIR, LC>(xcd_tile(blockIdx.x, SR_COLS_XCD_GROUP, grouped), data, src, k, wc, twist, lds);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -973,7 +978,9 @@ inline int gl_launch_cols256(const GoldilocksFastTables &f, uint64_t *data, cons
     constexpr int LC = DIR == 0 ? SR_COLS_LC_FWD : SR_COLS_LC_INV;
     const size_t blocks = npoly << (f.k - 8 - LC);  // N2 / 2^LC per ring element
     if (blocks == 0 || blocks > 0x7FFFFFFFull) return 1;
-    hipLaunchKernelGGL((gl::cols256_kernel<DIR, LC>), dim3((unsigned)blocks), dim3(16 << LC), 0, st, data, src, f.k, wc, twist);
+    const unsigned grouped = xcd_grouped_tiles(blocks, SR_COLS_XCD_GROUP);
+    hipLaunchKernelGGL((gl::cols256_kernel<DIR, LC>), dim3((unsigned)blocks), dim3(16 << LC), 0, st, data, src, f.k, wc, twist,
+                       grouped);
     return hipGetLastError() != hipSuccess;
 }
 // forward column stages of npoly ring elements: src -> d (src == d: in place).  Only the first pass reads src.

@@ -328,17 +328,19 @@ __global__ __launch_bounds__(256) void strided_kernel(const typename View<F, VI>
 // pass B (stages 4..7, the lane's block is rg') on legs 16 rg' + j.  The pass streams one operand once and has VALU to
 // spare, so the four stages it takes over from the rows kernel are free.  grid.x = npoly * N2 / 16.
 // ------------------------------------------------------------------------------------------------------------------
+constexpr int kXcdGroup = 3;  // 8 consecutive tiles per XCD turn: 1 KiB (4-byte words, 32 columns) or 1 KiB (8-byte, 16 columns) of every leg
 template <class F, int DIR, class VI, class VO, int COLS>
 __global__ __launch_bounds__(16 * COLS) void cols256_kernel(const typename View<F, VI>::T *src, typename View<F, VO>::T *dst,
-                                                            Params<F> p) {
+                                                            Params<F> p, unsigned grouped) {
     using E = typename F::elem;
     // [leg][column] words; COLS = 32 for 4-byte elements so that a leg's segment is a whole 128-byte line on the packed side
     __shared__ E lds[256 * COLS + 16 * COLS];
     constexpr int LC = COLS == 32 ? 5 : 4;
     const int t = threadIdx.x;
     const int ls = p.k - 8;  // log2 N2
-    const unsigned ci = blockIdx.x & ((1u << (ls - LC)) - 1u);
-    const size_t poly = blockIdx.x >> (ls - LC);
+    const unsigned tile = xcd_tile(blockIdx.x, kXcdGroup, grouped);  // runs of column chunks share an XCD (fields.hpp)
+    const unsigned ci = tile & ((1u << (ls - LC)) - 1u);
+    const size_t poly = tile >> (ls - LC);
     const int col = t & (COLS - 1), rg = t >> LC;
     const size_t off = (poly << p.k) + ci * (unsigned)COLS + (unsigned)col;
     auto at = [](int leg, int c) { const int pos = leg * COLS + c; return pos + (pos >> 8) * (COLS == 32 ? 0 : 16); };
@@ -530,7 +532,8 @@ inline int launch_cols256(const Hooks &hk, const typename View<F, VI>::T *src, t
     const size_t blocks = (npoly << (p.k - 8)) / COLS;
     if (blocks == 0 || blocks > 0x7FFFFFFFull) return 1;
     Scope sc(hk, DIR == 0 ? 0 : 2, st);
-    hipLaunchKernelGGL((cols256_kernel<F, DIR, VI, VO, COLS>), dim3((unsigned)blocks), dim3(16 * COLS), 0, st, src, dst, p);
+    hipLaunchKernelGGL((cols256_kernel<F, DIR, VI, VO, COLS>), dim3((unsigned)blocks), dim3(16 * COLS), 0, st, src, dst, p,
+                       xcd_grouped_tiles(blocks, kXcdGroup));
     return hipGetLastError() != hipSuccess;
 }
 // forward strided stages: boundary words at `src` -> packed words at `dst` (c >= 1)

@@ -48,25 +48,57 @@ int main(int argc, char **argv) {
 #ifdef PERSIST
     const unsigned ntiles = cblocks;
     const unsigned pgrid = PERSIST * (LCV == 6 ? 1 : LCV == 5 ? 2 : 4);  // PERSIST = number of CUs to fill
-#define COLS(DIRV, buf, wcp, twp) hipLaunchKernelGGL((cols256p_kernel<DIRV, LCV>), dim3(pgrid < ntiles ? pgrid : ntiles), dim3(16 << LCV), 0, 0, buf, k, wcp, twp, ntiles)
+#define COLS(DIRV, buf, srcbuf, np, wcp, twp) hipLaunchKernelGGL((cols256p_kernel<DIRV, LCV>), dim3(pgrid < ntiles ? pgrid : ntiles), dim3(16 << LCV), 0, 0, buf, k, wcp, twp, ntiles)
 #else
-#define COLS(DIRV, buf, wcp, twp) hipLaunchKernelGGL((cols256_kernel<DIRV, LCV>), dim3(cblocks), dim3(16 << LCV), 0, 0, buf, buf, k, wcp, twp)
+#define COLS(DIRV, buf, srcbuf, np, wcp, twp) hipLaunchKernelGGL((cols256_kernel<DIRV, LCV>), dim3((unsigned)((np) << (k - 8 - LCV))), dim3(16 << LCV), 0, 0, buf, srcbuf, k, wcp, twp, sr::xcd_grouped_tiles((np) << (k - 8 - LCV), SR_COLS_XCD_GROUP))
 #endif
     double acc[4] = {0, 0, 0, 0};
+#ifdef INPLACE
     for (int r = -1; r < reps; r++) {
         CK(hipEventRecord(ev[0]));
-        COLS(0, a, T.wcf, T.twist_f);
+        COLS(0, a, a, npoly, T.wcf, T.twist_f);
         CK(hipEventRecord(ev[1]));
-        COLS(0, b, T.wcf, T.twist_f);
+        COLS(0, b, b, npoly, T.wcf, T.twist_f);
         CK(hipEventRecord(ev[2]));
         hipLaunchKernelGGL((rows256_kernel<2>), dim3(blocks), dim3(256), 0, 0, a, b, a, T);
         CK(hipEventRecord(ev[3]));
-        COLS(1, a, T.wci, T.twist_i_mul);
+        COLS(1, a, a, npoly, T.wci, T.twist_i_mul);
         CK(hipEventRecord(ev[4]));
         CK(hipDeviceSynchronize());
         if (r < 0) continue;
         for (int i = 0; i < 4; i++) { float ms; CK(hipEventElapsedTime(&ms, ev[i], ev[i + 1])); acc[i] += ms; }
     }
+#else
+    // the library's arrangement: chunks of launches, operands read in place, intermediates in a chunk-sized scratch pair
+    const size_t ch = argc > 3 ? strtoull(argv[3], 0, 10) : (npoly >= 64 ? npoly / 8 : npoly);
+    u64 *sa, *sb;
+    CK(hipMalloc(&sa, ch << (k + 3))); CK(hipMalloc(&sb, ch << (k + 3)));
+    const size_t nch = (npoly + ch - 1) / ch;
+    std::vector<hipEvent_t> cev(nch * 5);
+    for (auto &e : cev) CK(hipEventCreate(&e));
+    double wall = 0;
+    for (int r = -1; r < reps; r++) {
+        for (size_t c = 0; c < nch; c++) {
+            const size_t np = (c + 1) * ch <= npoly ? ch : npoly - c * ch;
+            u64 *ac = a + ((c * ch) << k), *bc = b + ((c * ch) << k);
+            CK(hipEventRecord(cev[c * 5 + 0]));
+            COLS(0, sa, ac, np, T.wcf, T.twist_f);
+            CK(hipEventRecord(cev[c * 5 + 1]));
+            COLS(0, sb, bc, np, T.wcf, T.twist_f);
+            CK(hipEventRecord(cev[c * 5 + 2]));
+            hipLaunchKernelGGL((rows256_kernel<2>), dim3((unsigned)(np << (k - 12))), dim3(256), 0, 0, sa, sb, sa, T);
+            CK(hipEventRecord(cev[c * 5 + 3]));
+            COLS(1, ac, sa, np, T.wci, T.twist_i_mul);
+            CK(hipEventRecord(cev[c * 5 + 4]));
+        }
+        CK(hipDeviceSynchronize());
+        if (r < 0) continue;
+        for (size_t c = 0; c < nch; c++)
+            for (int i = 0; i < 4; i++) { float ms; CK(hipEventElapsedTime(&ms, cev[c * 5 + i], cev[c * 5 + i + 1])); acc[i] += ms; }
+        float ms; CK(hipEventElapsedTime(&ms, cev[0], cev[nch * 5 - 1])); wall += ms;
+    }
+    printf("chunks of %zu: wall %.3f ms per batch; ", ch, wall / reps);
+#endif
 #ifdef MIXED
     {   // the same four phases as ONE mixed-role launch (junk data: the roles work on four independent buffers)
         u64 *c2, *c3;
