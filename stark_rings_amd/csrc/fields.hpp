@@ -82,6 +82,29 @@ struct Goldilocks {
         bool fix = (s < a) | (s >= P);
         return fix ? s + EPS : s;
     }
+#elif defined(__HIP_DEVICE_COMPILE__) && !defined(SR_GL_NO_EXECMASK) && defined(SR_ADD_CMP)
+    // 4 VALU like the form below, with the full-width pre-add of EPS (v_lshl_add_u64: 1.6 nJ per wave-instruction, the most
+    // expensive of the integer adds -- tools/ubench/valu_energy.hip) replaced by a 64-bit compare (0.8 nJ): s = a + b on a carry
+    // chain; the lanes with a carry or with s >= p take + EPS (= - p mod 2^64) under an EXEC mask.
+    static __device__ __forceinline__ elem add(elem a, elem b) {
+        uint64_t c, c2, sv;
+        uint32_t r0, r1;
+        asm("v_add_co_u32_e64 %0, %2, %3, %5\n\t"
+            "s_nop 1\n\t"
+            "v_addc_co_u32_e64 %1, %2, %4, %6, %2"
+            : "=&v"(r0), "=&v"(r1), "=&s"(c)
+            : "v"((uint32_t)a), "v"((uint32_t)(a >> 32)), "v"((uint32_t)b), "v"((uint32_t)(b >> 32)));
+        uint64_t r = (uint64_t)r0 | ((uint64_t)r1 << 32);
+        asm("v_cmp_le_u64_e64 %2, %4, %0\n\t"
+            "s_or_b64 %2, %2, %3\n\t"
+            "s_and_saveexec_b64 %1, %2\n\t"
+            "v_lshl_add_u64 %0, %0, 0, %5\n\t"
+            "s_mov_b64 exec, %1"
+            : "+v"(r), "=&s"(sv), "=&s"(c2)
+            : "s"(c), "s"((uint64_t)P), "s"((uint64_t)EPS)
+            : "scc");
+        return r;
+    }
 #elif defined(__HIP_DEVICE_COMPILE__) && !defined(SR_GL_NO_EXECMASK)
     // Round-2 form, 4 VALU (3 for sub): the conditional correction is ONE v_lshl_add_u64 executed under an EXEC mask made from
     // the carry (s_and / s_andn1_saveexec ... s_mov exec: SALU work, which the scalar unit issues beside the other waves' VALU)

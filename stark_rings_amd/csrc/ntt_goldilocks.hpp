@@ -56,6 +56,21 @@ __device__ __forceinline__ void stagger_first_round() {
     }
 #endif
 }
+// SR_GL_SETPRIO = 1: a wave raises its issue priority while it puts its coefficient loads (and, at the end, its stores) in flight,
+// so that memory requests of a fresh workgroup are not queued behind the butterflies of the resident ones (A/B switch)
+#ifndef SR_GL_SETPRIO
+#define SR_GL_SETPRIO 0
+#endif
+__device__ __forceinline__ void prio_mem() {
+#if SR_GL_SETPRIO
+    __builtin_amdgcn_s_setprio(3);
+#endif
+}
+__device__ __forceinline__ void prio_alu() {
+#if SR_GL_SETPRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
+}
 __device__ __forceinline__ u64 ld_stream(const u64 *p) {
 #if SR_GL_NT
     return __builtin_nontemporal_load(p);
@@ -486,8 +501,10 @@ __device__ __forceinline__ void cols256_tile(const unsigned tile, u64 *data, con
     u64 x[16];
 
     if (DIR == 0) {
+        prio_mem();
 #pragma unroll
         for (int jj = 0; jj < 16; jj++) x[jj] = ld_stream(reinterpret_cast<const u64 *>(ps + (offA + (unsigned)jj * 16u * leg)));
+        prio_alu();
 #ifndef SR_DIAG_COLS_NOCOMPUTE
         cols_stage_fwd<0>(x, seq16{});
         cols_stage_fwd<1>(x, seq16{});
@@ -515,11 +532,13 @@ __device__ __forceinline__ void cols256_tile(const unsigned tile, u64 *data, con
 #endif
     } else {
         u64 tw[16];
+        prio_mem();
 #pragma unroll
         for (int sg = 0; sg < 16; sg++) {
             x[sg] = ld_stream(reinterpret_cast<const u64 *>(ps + (offB + (unsigned)sg * leg)));
             tw[sg] = *reinterpret_cast<const u64 *>(tb + (offB + (unsigned)sg * leg));
         }
+        prio_alu();
 #pragma unroll
         for (int sg = 0; sg < 16; sg++) x[sg] = G::mul(x[sg], tw[sg]);
         dft16_inv(x);
@@ -695,8 +714,10 @@ __global__ __launch_bounds__(256, TW ? SR_ROWS_WAVES_TW : SR_ROWS_WAVES) void ro
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void tile256_load(const u64 *__restrict__ src, const int t, u64 *x) {
     const int i0 = t & 15, base2 = (t >> 4) * 256 + i0;
+    prio_mem();
 #pragma unroll
     for (int j = 0; j < 16; j++) x[j] = ld_stream(src + base2 + j * 16);
+    prio_alu();
 }
 // x holds the lane's 16 coefficients (tile256_load) on entry, its 16 consecutive NTT slots on return
 __device__ __forceinline__ void tile256_fwd_regs(u64 *lds, const int t, const Tables &T, u64 *x) {

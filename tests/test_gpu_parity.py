@@ -1453,6 +1453,36 @@ def test_ring_mul_in_default_chunks(torch_cuda, name, k, batch):
         ring.close()
 
 
+@pytest.mark.parametrize("name,k,batch", [("goldilocks", 16, 9), ("goldilocks", 16, 24), ("goldilocks", 17, 5), ("goldilocks", 18, 3), ("goldilocks", 20, 1),
+                                          ("babybear", 16, 9), ("babybear", 16, 16), ("babybear", 20, 1)])
+def test_column_pass_tile_order_covers_every_tile(torch_cuda, name, k, batch):
+    """The column passes hand runs of 16 (8 on the register-tiled path) consecutive tiles to one XCD (xcd_tile, csrc/fields.hpp); launches whose
+    tile count is not a multiple of 8 runs keep the plain order for the rest.  One set of launches per call (chunk_polys = batch), batches
+    with and without such a rest: every coefficient of every element must still be transformed exactly once -- product, forward and inverse
+    transform against the oracle."""
+    torch = torch_cuda
+    from stark_rings_amd import CyclotomicRing
+
+    F = O.FIELD_ID[name]
+    n = batch << k
+    a = O.fill_uniform(F, 0x71, 0, n)
+    b = O.fill_uniform(F, 0x72, 0, n)
+    ring = CyclotomicRing(name, k, device=0, plan=_plan(chunk_polys=batch))
+    ta = torch.from_numpy(a.view(np.int64)).cuda()
+    tb = torch.from_numpy(b.view(np.int64)).cuda()
+    out = torch.empty_like(ta)
+    ring.mul_dev(out, ta, tb)
+    torch.cuda.synchronize()
+    assert np.array_equal(out.cpu().numpy().view(np.uint64), O.pow2_ring_mul(F, a, b, k, batch, 8))
+    ring.elementwise_crt_dev(ta)
+    torch.cuda.synchronize()
+    assert np.array_equal(ta.cpu().numpy().view(np.uint64), O.pow2_fwd(F, a, k, batch, 8))
+    ring.elementwise_icrt_dev(ta)
+    torch.cuda.synchronize()
+    assert np.array_equal(ta.cpu().numpy().view(np.uint64), a)
+    ring.close()
+
+
 @pytest.mark.parametrize("name,k", [("stark", 3), ("goldilocks", 4), ("babybear", 3), ("frog16", 0)])
 @pytest.mark.parametrize("basis", [1 << 64, (1 << 64) + 2, 3 * (1 << 70) + 6, 1 << 100, (1 << 128) - 2])
 def test_decomposition_with_u128_bases(torch_cuda, name, k, basis):

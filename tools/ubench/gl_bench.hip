@@ -12,6 +12,16 @@
 #include "mixed256_experiment.hpp"
 #endif
 using namespace sr::gl;
+#ifdef PAIR
+// forward column passes of a and b as ONE launch (one tail and one launch gap fewer per chunk)
+__global__ __launch_bounds__(256, 4) void cols256_pair_kernel(u64 *da, const u64 *sa_, u64 *db, const u64 *sb_, int k, const u64 *__restrict__ wc,
+                                                              const u64 *__restrict__ twist, unsigned tiles, unsigned grouped) {
+    __shared__ u64 lds[ColsTile<4>::kElems];
+    const bool second = blockIdx.x >= tiles;
+    const unsigned bid = second ? blockIdx.x - tiles : blockIdx.x;
+    cols256_tile<0, 4>(sr::xcd_tile(bid, SR_COLS_XCD_GROUP, grouped), second ? db : da, second ? sb_ : sa_, k, wc, twist, lds);
+}
+#endif
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); return 1; } } while (0)
 __global__ void junk_kernel(u64 *p, size_t n, u64 seed) {
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
@@ -82,9 +92,18 @@ int main(int argc, char **argv) {
             const size_t np = (c + 1) * ch <= npoly ? ch : npoly - c * ch;
             u64 *ac = a + ((c * ch) << k), *bc = b + ((c * ch) << k);
             CK(hipEventRecord(cev[c * 5 + 0]));
+#ifdef PAIR
+            CK(hipEventRecord(cev[c * 5 + 1]));
+            {
+                const unsigned tiles = (unsigned)(np << (k - 12));
+                hipLaunchKernelGGL(cols256_pair_kernel, dim3(2 * tiles), dim3(256), 0, 0, sa, ac, sb, bc, k, T.wcf, T.twist_f, tiles,
+                                   sr::xcd_grouped_tiles(tiles, SR_COLS_XCD_GROUP));
+            }
+#else
             COLS(0, sa, ac, np, T.wcf, T.twist_f);
             CK(hipEventRecord(cev[c * 5 + 1]));
             COLS(0, sb, bc, np, T.wcf, T.twist_f);
+#endif
             CK(hipEventRecord(cev[c * 5 + 2]));
             hipLaunchKernelGGL((rows256_kernel<2>), dim3((unsigned)(np << (k - 12))), dim3(256), 0, 0, sa, sb, sa, T);
             CK(hipEventRecord(cev[c * 5 + 3]));
