@@ -32,7 +32,10 @@ PASSES = {
 
 
 def collect(workload, outdir, steps):
+    outdir = os.path.abspath(outdir)  # rocprofv3 runs with cwd = /tmp
     os.makedirs(outdir, exist_ok=True)
+    for old in glob.glob(os.path.join(outdir, "*.csv")):  # never summarise a previous build's counters as this one's
+        os.remove(old)
     env = dict(os.environ, TMPDIR="/tmp")
     for name, flags in PASSES.items():
         d = os.path.join(outdir, name)
@@ -52,6 +55,11 @@ def collect(workload, outdir, steps):
             if kind:
                 shutil.copy(f, os.path.join(outdir, "%s.%s.csv" % (name, kind)))
         shutil.rmtree(d, ignore_errors=True)
+        want = ["kernel_stats", "kernel_trace"] if name == "trace" else ["counters"]
+        for kind in want:
+            if not os.path.exists(os.path.join(outdir, "%s.%s.csv" % (name, kind))):
+                print("pass %s left no %s csv, see %s" % (name, kind, os.path.join(outdir, name + ".err")))
+                return 1
     return 0
 
 
