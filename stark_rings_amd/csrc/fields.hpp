@@ -330,10 +330,43 @@ struct Goldilocks {
     }
 #endif
 #endif
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(SR_GL_NO_EXECMASK) && !defined(SR_OLD_REDUCE) && !defined(SR_GL_MUL_PLAIN)
+    // Device form, 13 VALU.  The compiler's expansion of the 64 x 64 -> 128-bit product zero-extends four 32-bit halves into
+    // 64-bit addends of v_mad_u64_u32 (gfx950 wants 64-bit register pairs even-aligned, so {hi(x), 0} always costs a v_mov_b32)
+    // and adds the two middle carries with a v_lshl_add_u64: 4 mads + 5 moves + 1 add, 16 VALU with the reduction.  Here the middle
+    // product takes its FULL 64-bit addend, al*bh + (ah*bl + hi(al*bl)) = P2 + c 2^64, and the carry-out c (weight 2^96 = -1 mod p)
+    // goes straight into the borrow-in of the reduction's subtraction:
+    //   a b = LO + P3 2^64 + c 2^96,  LO = {lo(al bl), lo(P2)},  P3 = ah bh + hi(P2)   ==>   a b = LO - hi(P3) - c + lo(P3) eps  (mod p)
+    // Same value bit for bit as reduce128 of the 128-bit product (SR_GL_MUL_PLAIN: A/B switch).
+    static __device__ __forceinline__ elem mul(elem a, elem b) {
+        const uint32_t al = (uint32_t)a, ah = (uint32_t)(a >> 32), bl = (uint32_t)b, bh = (uint32_t)(b >> 32);
+        const uint64_t p0 = (uint64_t)al * bl;
+        const uint64_t p1 = (uint64_t)ah * bl + (p0 >> 32);  // <= 2^64 - 2^32
+        uint64_t p2, c, bo, sv;
+        asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(p2), "=s"(c) : "v"(al), "v"(bh), "v"(p1));
+        const uint64_t p3 = (uint64_t)ah * bh + (p2 >> 32);  // <= 2^64 - 2^32
+        uint32_t r0, r1;
+        // the move and the mad that make p3 stand between the write of c and its use as a borrow-in (2 wait states)
+        asm("v_subb_co_u32_e64 %0, %2, %3, %5, %6\n\t"
+            "s_nop 1\n\t"
+            "v_subb_co_u32_e64 %1, %2, %4, 0, %2"
+            : "=&v"(r0), "=&v"(r1), "=&s"(bo)
+            : "v"((uint32_t)p0), "v"((uint32_t)p2), "v"((uint32_t)(p3 >> 32)), "s"(c));
+        uint64_t r = (uint64_t)r0 | ((uint64_t)r1 << 32);
+        asm("s_and_saveexec_b64 %1, %2\n\t"
+            "v_lshl_add_u64 %0, %0, 0, %3\n\t"
+            "s_mov_b64 exec, %1"
+            : "+v"(r), "=&s"(sv)
+            : "s"(bo), "s"((uint64_t)P)
+            : "scc");
+        return mad_eps_fix(r, (uint32_t)p3);
+    }
+#else
     SR_HD static elem mul(elem a, elem b) {
         unsigned __int128 x = (unsigned __int128)a * b;
         return reduce128((uint64_t)x, (uint64_t)(x >> 64));
     }
+#endif
     SR_HD static elem mul_tw(elem a, elem w) { return mul(a, w); }
     // a * b * 2^-64: 2^-64 = -2^32 (mod p), so (hi, lo) -> hi - lo * 2^32
     SR_HD static elem mul_boundary(elem a, elem b) {

@@ -85,43 +85,6 @@ __device__ __forceinline__ void st_stream(u64 *p, u64 v) {
     *p = v;
 #endif
 }
-// General product of the tuned kernels.  The compiler's expansion of the 64 x 64 -> 128-bit product zero-extends four 32-bit halves
-// into 64-bit addends of v_mad_u64_u32 (gfx950 wants 64-bit register pairs even-aligned, so {hi(x), 0} always costs a v_mov_b32)
-// and adds the two middle carries with a v_lshl_add_u64: 4 mads + 5 moves + 1 add.  SR_GL_MUL_CARRY = 1 gives the middle product
-// its FULL 64-bit addend, al*bh + (ah*bl + hi(al*bl)) = P2' + c 2^64, and sends the carry-out c (weight 2^96 = -1 mod p) straight
-// into the borrow-in of the reduction's subtraction:
-//   x y = LO + P3 2^64 + c 2^96,  LO = {lo(al bl), lo(P2')},  P3 = ah bh + hi(P2')   ==>   x y = LO - hi(P3) - c + lo(P3) eps  (mod p)
-// 4 mads + 2 moves, same value bit for bit (13 VALU per product instead of 16).
-#ifndef SR_GL_MUL_CARRY
-#define SR_GL_MUL_CARRY 1
-#endif
-__device__ __forceinline__ u64 gmul(u64 a, u64 b) {
-#if SR_GL_MUL_CARRY && defined(__HIP_DEVICE_COMPILE__)
-    const u32 al = (u32)a, ah = (u32)(a >> 32), bl = (u32)b, bh = (u32)(b >> 32);
-    const u64 p0 = (u64)al * bl;
-    const u64 p1 = (u64)ah * bl + (p0 >> 32);  // <= 2^64 - 2^32
-    u64 p2, c, bo, sv;
-    asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(p2), "=s"(c) : "v"(al), "v"(bh), "v"(p1));
-    const u64 p3 = (u64)ah * bh + (p2 >> 32);  // <= 2^64 - 2^32
-    u32 r0, r1;
-    // the mad and the move that make p3 stand between the write of c and its use as a borrow-in (2 wait states)
-    asm("v_subb_co_u32_e64 %0, %2, %3, %5, %6\n\t"
-        "s_nop 1\n\t"
-        "v_subb_co_u32_e64 %1, %2, %4, 0, %2"
-        : "=&v"(r0), "=&v"(r1), "=&s"(bo)
-        : "v"((u32)p0), "v"((u32)p2), "v"((u32)(p3 >> 32)), "s"(c));
-    u64 r = (u64)r0 | ((u64)r1 << 32);
-    asm("s_and_saveexec_b64 %1, %2\n\t"
-        "v_lshl_add_u64 %0, %0, 0, %3\n\t"
-        "s_mov_b64 exec, %1"
-        : "+v"(r), "=&s"(sv)
-        : "s"(bo), "s"((u64)G::P)
-        : "scc");
-    return G::mad_eps_fix(r, (u32)p3);
-#else
-    return G::mul(a, b);
-#endif
-}
 constexpr int kTile = 4096;
 constexpr int kLdsElems = kTile + kTile / 16;  // padded: pos + (pos >> 4)
 
@@ -309,19 +272,19 @@ __global__ __launch_bounds__(256) void strided_kernel(u64 *data, const u64 *src,
             for (int j = 0; j < R; j++) {
                 if (j & half) continue;
                 const u64 w = tw[(1u << (s_lo + t)) + (h << t) + (unsigned)(j >> (M - t))];
-                const u64 u = x[j], v = gmul(x[j + half], w);
+                const u64 u = x[j], v = G::mul(x[j + half], w);
                 x[j] = G::add(u, v);
                 x[j + half] = G::sub(u, v);
             }
         }
         if (TWIST) {
 #pragma unroll
-            for (int j = 0; j < R; j++) x[j] = gmul(x[j], twist[((size_t)((h << M) + j) << 12) + i]);
+            for (int j = 0; j < R; j++) x[j] = G::mul(x[j], twist[((size_t)((h << M) + j) << 12) + i]);
         }
     } else {
         if (TWIST) {
 #pragma unroll
-            for (int j = 0; j < R; j++) x[j] = gmul(x[j], twist[((size_t)((h << M) + j) << 12) + i]);
+            for (int j = 0; j < R; j++) x[j] = G::mul(x[j], twist[((size_t)((h << M) + j) << 12) + i]);
         }
 #pragma unroll
         for (int t = M - 1; t >= 0; t--) {
@@ -332,7 +295,7 @@ __global__ __launch_bounds__(256) void strided_kernel(u64 *data, const u64 *src,
                 const u64 w = tw[(1u << (s_lo + t)) + (h << t) + (unsigned)(j >> (M - t))];
                 const u64 u = x[j], v = x[j + half];
                 x[j] = G::add(u, v);
-                x[j + half] = gmul(G::sub(u, v), w);
+                x[j + half] = G::mul(G::sub(u, v), w);
             }
         }
     }
@@ -379,7 +342,7 @@ __global__ __launch_bounds__(256, 4) void strided256_kernel(u64 *data, const u64
             for (int jj = 0; jj < 16; jj++) {
                 if (jj & half) continue;
                 const u64 w = tw[(1u << (s_lo + u)) + (h << u) + (unsigned)(jj >> (4 - u))];
-                const u64 a = x[jj], v = gmul(x[jj + half], w);
+                const u64 a = x[jj], v = G::mul(x[jj + half], w);
                 x[jj] = G::add(a, v);
                 x[jj + half] = G::sub(a, v);
             }
@@ -396,7 +359,7 @@ __global__ __launch_bounds__(256, 4) void strided256_kernel(u64 *data, const u64
             for (int jj = 0; jj < 16; jj++) {
                 if (jj & half) continue;
                 const u64 w = tw[(1u << (s_lo + 4 + u)) + (h << (4 + u)) + ((unsigned)rg << u) + (unsigned)(jj >> (4 - u))];
-                const u64 a = x[jj], v = gmul(x[jj + half], w);
+                const u64 a = x[jj], v = G::mul(x[jj + half], w);
                 x[jj] = G::add(a, v);
                 x[jj + half] = G::sub(a, v);
             }
@@ -404,14 +367,14 @@ __global__ __launch_bounds__(256, 4) void strided256_kernel(u64 *data, const u64
 #pragma unroll
         for (int jj = 0; jj < 16; jj++) {
             u64 v = x[jj];
-            if (TWIST) v = gmul(v, twist[((size_t)((h << 8) + (unsigned)(16 * rg + jj)) << 12) + i]);
+            if (TWIST) v = G::mul(v, twist[((size_t)((h << 8) + (unsigned)(16 * rg + jj)) << 12) + i]);
             base[(size_t)(16 * rg + jj) << ls] = v;
         }
     } else {
 #pragma unroll
         for (int jj = 0; jj < 16; jj++) {
             u64 v = sbase[(size_t)(16 * rg + jj) << ls];
-            if (TWIST) v = gmul(v, twist[((size_t)((h << 8) + (unsigned)(16 * rg + jj)) << 12) + i]);
+            if (TWIST) v = G::mul(v, twist[((size_t)((h << 8) + (unsigned)(16 * rg + jj)) << 12) + i]);
             x[jj] = v;
         }
 #pragma unroll
@@ -423,7 +386,7 @@ __global__ __launch_bounds__(256, 4) void strided256_kernel(u64 *data, const u64
                 const u64 w = tw[(1u << (s_lo + 4 + u)) + (h << (4 + u)) + ((unsigned)rg << u) + (unsigned)(jj >> (4 - u))];
                 const u64 a = x[jj], b = x[jj + half];
                 x[jj] = G::add(a, b);
-                x[jj + half] = gmul(G::sub(a, b), w);
+                x[jj + half] = G::mul(G::sub(a, b), w);
             }
         }
 #pragma unroll
@@ -440,7 +403,7 @@ __global__ __launch_bounds__(256, 4) void strided256_kernel(u64 *data, const u64
                 const u64 w = tw[(1u << (s_lo + u)) + (h << u) + (unsigned)(jj >> (4 - u))];
                 const u64 a = x[jj], b = x[jj + half];
                 x[jj] = G::add(a, b);
-                x[jj + half] = gmul(G::sub(a, b), w);
+                x[jj + half] = G::mul(G::sub(a, b), w);
             }
         }
 #pragma unroll
@@ -548,7 +511,7 @@ __device__ __forceinline__ void cols256_tile(const unsigned tile, u64 *data, con
         cols_stage_fwd<2>(x, seq16{});
         cols_stage_fwd<3>(x, seq16{});
 #pragma unroll
-        for (int h = 0; h < 16; h++) x[h] = gmul(x[h], wc[h * 16 + rg]);
+        for (int h = 0; h < 16; h++) x[h] = G::mul(x[h], wc[h * 16 + rg]);
 #endif
 #pragma unroll
         for (int h = 0; h < 16; h++) lds[CT::idx(16 * h + rg, col)] = x[h];  // leg 16 h + rg, column col
@@ -562,7 +525,7 @@ __device__ __forceinline__ void cols256_tile(const unsigned tile, u64 *data, con
         dft16_fwd(x);
 #pragma unroll
         for (int sg = 0; sg < 16; sg++)
-            st_stream(reinterpret_cast<u64 *>(pb + (offB + (unsigned)sg * leg)), gmul(x[sg], tw[sg]));
+            st_stream(reinterpret_cast<u64 *>(pb + (offB + (unsigned)sg * leg)), G::mul(x[sg], tw[sg]));
 #else
 #pragma unroll
         for (int sg = 0; sg < 16; sg++) *reinterpret_cast<u64 *>(pb + (offB + (unsigned)sg * leg)) = x[sg] ^ tw[sg];
@@ -577,7 +540,7 @@ __device__ __forceinline__ void cols256_tile(const unsigned tile, u64 *data, con
         }
         prio_alu();
 #pragma unroll
-        for (int sg = 0; sg < 16; sg++) x[sg] = gmul(x[sg], tw[sg]);
+        for (int sg = 0; sg < 16; sg++) x[sg] = G::mul(x[sg], tw[sg]);
         dft16_inv(x);
 #pragma unroll
         for (int j = 0; j < 16; j++) lds[CT::idx(16 * rg + j, col)] = x[j];
@@ -585,7 +548,7 @@ __device__ __forceinline__ void cols256_tile(const unsigned tile, u64 *data, con
 #pragma unroll
         for (int h = 0; h < 16; h++) x[h] = lds[CT::idx(16 * h + rg, col)];
 #pragma unroll
-        for (int h = 0; h < 16; h++) x[h] = gmul(x[h], wc[h * 16 + rg]);
+        for (int h = 0; h < 16; h++) x[h] = G::mul(x[h], wc[h * 16 + rg]);
         cols_stage_inv<3>(x, seq16{});
         cols_stage_inv<2>(x, seq16{});
         cols_stage_inv<1>(x, seq16{});
@@ -628,9 +591,9 @@ __device__ __forceinline__ void tile_fwd(const u64 *__restrict__ src, u64 *lds, 
     }
     if (TW) twist_rows<Q, false>(x, std::make_integer_sequence<int, 16>{});
     dft16_fwd_q<Q>(x);
-    if (TW) x[0] = gmul(x[0], T.w1f[t]);  // psi^t: with the twist merged in, slot 0 is no longer multiplied by 1
+    if (TW) x[0] = G::mul(x[0], T.w1f[t]);  // psi^t: with the twist merged in, slot 0 is no longer multiplied by 1
 #pragma unroll
-    for (int r = 1; r < 16; r++) x[r] = gmul(x[r], T.w1f[r * 256 + t]);
+    for (int r = 1; r < 16; r++) x[r] = G::mul(x[r], T.w1f[r * 256 + t]);
 #pragma unroll
     for (int r = 0; r < 16; r++) lds[pad(r * 256 + t)] = x[r];
     __syncthreads();
@@ -639,7 +602,7 @@ __device__ __forceinline__ void tile_fwd(const u64 *__restrict__ src, u64 *lds, 
     for (int j = 0; j < 16; j++) x[j] = lds[pad(base2 + j * 16)];
     dft16_fwd(x);
 #pragma unroll
-    for (int s = 1; s < 16; s++) x[s] = gmul(x[s], T.w2f[s * 16 + i0]);
+    for (int s = 1; s < 16; s++) x[s] = G::mul(x[s], T.w2f[s * 16 + i0]);
 #pragma unroll
     for (int s = 0; s < 16; s++) lds[pad(base2 + s * 16)] = x[s];  // the very slots this lane just read
     __syncthreads();
@@ -661,16 +624,16 @@ __device__ __forceinline__ void tile_inv(u64 *x, u64 *lds, const int t, const Ta
 #pragma unroll
     for (int s = 0; s < 16; s++) x[s] = lds[pad(base2 + s * 16)];
 #pragma unroll
-    for (int s = 1; s < 16; s++) x[s] = gmul(x[s], T.w2i[s * 16 + i0]);
+    for (int s = 1; s < 16; s++) x[s] = G::mul(x[s], T.w2i[s * 16 + i0]);
     dft16_inv(x);
 #pragma unroll
     for (int j = 0; j < 16; j++) lds[pad(base2 + j * 16)] = x[j];
     __syncthreads();
 #pragma unroll
     for (int r = 0; r < 16; r++) x[r] = lds[pad(r * 256 + t)];
-    if (TW) x[0] = gmul(x[0], w1i[t]);  // psi^-t * D^-1
+    if (TW) x[0] = G::mul(x[0], w1i[t]);  // psi^-t * D^-1
 #pragma unroll
-    for (int r = 1; r < 16; r++) x[r] = gmul(x[r], w1i[r * 256 + t]);
+    for (int r = 1; r < 16; r++) x[r] = G::mul(x[r], w1i[r * 256 + t]);
     dft16_inv_q<Q>(x);
     if (TW) twist_rows<Q, true>(x, std::make_integer_sequence<int, 16>{});
 #pragma unroll
@@ -737,7 +700,7 @@ __global__ __launch_bounds__(256, TW ? SR_ROWS_WAVES_TW : SR_ROWS_WAVES) void ro
             tile_fwd<Q, TW>(b + base, lds, t, T, B, nvalid);
         }
 #pragma unroll
-        for (int j = 0; j < 16; j++) A[j] = gmul(A[j], B[j]);
+        for (int j = 0; j < 16; j++) A[j] = G::mul(A[j], B[j]);
         // no barrier: tile_inv first writes the lane's own slots 17 t + j, which only this lane has just read
     }
     tile_inv<Q, TW>(A, lds, t, T, w1i, out + base, nvalid);
@@ -761,7 +724,7 @@ __device__ __forceinline__ void tile256_fwd_regs(u64 *lds, const int t, const Ta
     const int i0 = t & 15, base2 = (t >> 4) * 256 + i0;
     dft16_fwd(x);
 #pragma unroll
-    for (int s = 1; s < 16; s++) x[s] = gmul(x[s], T.w2f[s * 16 + i0]);
+    for (int s = 1; s < 16; s++) x[s] = G::mul(x[s], T.w2f[s * 16 + i0]);
 #pragma unroll
     for (int s = 0; s < 16; s++) lds[pad(base2 + s * 16)] = x[s];
     __syncthreads();
@@ -782,7 +745,7 @@ __device__ __forceinline__ void tile256_inv(u64 *x, u64 *lds, const int t, const
 #pragma unroll
     for (int s = 0; s < 16; s++) x[s] = lds[pad(base2 + s * 16)];
 #pragma unroll
-    for (int s = 1; s < 16; s++) x[s] = gmul(x[s], T.w2i[s * 16 + i0]);
+    for (int s = 1; s < 16; s++) x[s] = G::mul(x[s], T.w2i[s * 16 + i0]);
     dft16_inv(x);
 #pragma unroll
     for (int j = 0; j < 16; j++) st_stream(dst + base2 + j * 16, x[j]);
@@ -839,7 +802,7 @@ __device__ __forceinline__ void rows256_tile(const unsigned tile, u64 *a, const 
 #endif
         }
 #pragma unroll
-        for (int j = 0; j < 16; j++) A[j] = gmul(A[j], B[j]);
+        for (int j = 0; j < 16; j++) A[j] = G::mul(A[j], B[j]);
     }
     tile256_inv(A, lds, t, T, out + base);
 }
@@ -857,7 +820,7 @@ __global__ __launch_bounds__(256, 4) void rows256_kernel(u64 *a, const u64 *b, u
 __device__ __forceinline__ u64 pow_from_bits(const u64 *pw, unsigned e, int k) {
     u64 acc = 1;
     for (int j = 0; j <= k; j++)
-        if ((e >> j) & 1u) acc = gmul(acc, pw[j]);
+        if ((e >> j) & 1u) acc = G::mul(acc, pw[j]);
     return acc;
 }
 // c = number of merged stages the column passes run = log2 of the number of twisted blocks (of N2 = D >> c coefficients)
@@ -874,8 +837,8 @@ __global__ void build_tables_kernel(int k, int c, const u64 *pows, const u64 *ip
             unsigned e = (unsigned)(((unsigned long long)(2 * bitrev(b, c) + 1) * i) & mask2d);
             twist_f[idx] = pow_from_bits(pows, e, k);
             u64 inv = pow_from_bits(ipows, e, k);
-            twist_i_plain[idx] = gmul(inv, dinv);
-            twist_i_mul[idx] = gmul(inv, dinv_mul);
+            twist_i_plain[idx] = G::mul(inv, dinv);
+            twist_i_mul[idx] = G::mul(inv, dinv_mul);
         }
         if (idx < 4096) {
             // omega_N^(i0 * m0), N = D >> c = the cyclic size the stride-256 pass starts; slot r of a lane belongs to
@@ -886,8 +849,8 @@ __global__ void build_tables_kernel(int k, int c, const u64 *pows, const u64 *ip
             if (k <= 12) e1 = (e1 + i0) & mask2d;  // column part psi^i0 of the twist, merged (tile_fwd)
             w1f[idx] = pow_from_bits(pows, e1, k);
             const u64 inv1 = pow_from_bits(ipows, e1, k);
-            w1i[idx] = k <= 12 ? gmul(inv1, dinv) : inv1;
-            w1i_mul[idx] = k <= 12 ? gmul(inv1, dinv_mul) : inv1;
+            w1i[idx] = k <= 12 ? G::mul(inv1, dinv) : inv1;
+            w1i_mul[idx] = k <= 12 ? G::mul(inv1, dinv_mul) : inv1;
         }
         if (idx < 256) {
             unsigned s = (unsigned)(idx >> 4), i0 = (unsigned)(idx & 15);
