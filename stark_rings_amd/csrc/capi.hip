@@ -83,6 +83,8 @@ struct sr_ctx {
     bool stark_tuned = false;  // and k >= 4: the register-tiled kernels of ntt_stark.hpp (SR_STARK_TUNED=0: generic kernels on StarkL)
     bool stark_lazy = false;  // Stark rings: transforms run on StarkL (nine 28-bit limbs, lazy carries; stark_lazy.hpp)
     // staging for host-pointer entry points
+    void *host_tmp[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // device temporaries of the host-pointer linear-algebra /
+    size_t host_tmp_bytes[5] = {0, 0, 0, 0, 0};                         // decomposition calls (grow-only, see DevBuf)
     void *stage[4] = {nullptr, nullptr, nullptr, nullptr};  // [2], [3]: second lane of the chunked host pipeline
     size_t stage_bytes[4] = {0, 0, 0, 0};
     hipStream_t stream = nullptr;
@@ -1090,6 +1092,8 @@ int sr_ctx_destroy(sr_ctx *c) {
         if (c->rt_scratch[i]) (void)hipFree(c->rt_scratch[i]);
     if (c->out_stream) (void)hipStreamDestroy(c->out_stream);
     if (c->rt_scratch_free) (void)hipEventDestroy(c->rt_scratch_free);
+    for (int i = 0; i < 5; i++)
+        if (c->host_tmp[i]) (void)hipFree(c->host_tmp[i]);
     if (c->d_counter) (void)hipFree(c->d_counter);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -1317,17 +1321,30 @@ int sr_recompose_batch_dev(sr_ctx *c, uint64_t *out, const uint64_t *in, uint64_
     return sr_recompose_batch_wide_dev(c, out, in, basis, 0, padding_size, batch_out, stream);
 }
 
-// ---- host-pointer variants of the linear-algebra entry points: temporaries are allocated per call (these are
-// convenience entry points for callers that hold Vec<..> on the host; resident data uses the _dev forms)
+// ---- host-pointer variants of the linear-algebra entry points (convenience entry points for callers that hold Vec<..> on the
+// host; resident data uses the _dev forms): their device temporaries live in the context and only grow
 namespace {
+// device temporary of a host-pointer call: slot `slot` of the context's grow-only set (the calls hold the context mutex and end with a
+// stream synchronisation, so a slot is free again when the next call starts; nothing is allocated or freed per call once warm)
 struct DevBuf {
+    sr_ctx *c;
+    int slot;
     void *p = nullptr;
-    ~DevBuf() {
-        if (p) (void)hipFree(p);
-    }
+    DevBuf(sr_ctx *c_, int slot_) : c(c_), slot(slot_) {}
     int alloc(size_t bytes) {
-        hipError_t e = hipMalloc(&p, bytes ? bytes : 8);
-        return e == hipSuccess ? SR_OK : fail(SR_E_ALLOC, std::string("hipMalloc: ") + hipGetErrorString(e));
+        if (bytes == 0) bytes = 8;
+        if (c->host_tmp_bytes[slot] < bytes) {
+            if (c->host_tmp[slot]) {
+                (void)hipFree(c->host_tmp[slot]);
+                c->host_tmp[slot] = nullptr;
+                c->host_tmp_bytes[slot] = 0;
+            }
+            hipError_t e = hipMalloc(&c->host_tmp[slot], bytes);
+            if (e != hipSuccess) return fail(SR_E_ALLOC, std::string("hipMalloc: ") + hipGetErrorString(e));
+            c->host_tmp_bytes[slot] = bytes;
+        }
+        p = c->host_tmp[slot];
+        return SR_OK;
     }
 };
 }  // namespace
@@ -1337,7 +1354,7 @@ int sr_matmul_ntt(sr_ctx *c, uint64_t *y, const uint64_t *a, const uint64_t *b, 
     std::lock_guard<std::mutex> lk(c->mu);
     DeviceGuard g(c->device);
     const size_t w = c->degree * c->limbs * 8;
-    DevBuf da, db, dy;
+    DevBuf da(c, 0), db(c, 1), dy(c, 2);
     if (int rc = da.alloc(n * m * w)) return rc;
     if (int rc = db.alloc(m * p * w)) return rc;
     if (int rc = dy.alloc(n * p * w)) return rc;
@@ -1354,7 +1371,7 @@ int sr_matvec_ntt(sr_ctx *c, uint64_t *y, const uint64_t *m, const uint64_t *v, 
     std::lock_guard<std::mutex> lk(c->mu);
     DeviceGuard g(c->device);
     const size_t w = c->degree * c->limbs * 8;
-    DevBuf dm, dv, dy;
+    DevBuf dm(c, 0), dv(c, 1), dy(c, 2);
     if (int rc = dm.alloc(nrows * ncols * w)) return rc;
     if (int rc = dv.alloc(ncols * w)) return rc;
     if (int rc = dy.alloc(nrows * w)) return rc;
@@ -1378,7 +1395,7 @@ int sr_spmv_ntt(sr_ctx *c, uint64_t *y, const uint64_t *vals, const uint32_t *co
     std::lock_guard<std::mutex> lk(c->mu);
     DeviceGuard g(c->device);
     const size_t w = c->degree * c->limbs * 8;
-    DevBuf dvals, dcols, dptr, dv, dy;
+    DevBuf dvals(c, 0), dcols(c, 1), dptr(c, 2), dv(c, 3), dy(c, 4);
     if (int rc = dvals.alloc(nnz * w)) return rc;
     if (int rc = dcols.alloc(nnz * 4)) return rc;
     if (int rc = dptr.alloc((nrows + 1) * 8)) return rc;
@@ -1409,7 +1426,7 @@ int sr_decompose_balanced_batch_wide(sr_ctx *c, uint64_t *out, const uint64_t *i
     DeviceGuard g(c->device);
     const size_t w = c->degree * c->limbs * 8;
     if (batch == 0 || padding_size == 0) return SR_OK;
-    DevBuf din, dout;
+    DevBuf din(c, 0), dout(c, 1);
     if (int rc = din.alloc(batch * w)) return rc;
     if (int rc = dout.alloc(batch * padding_size * w)) return rc;
     HIP_TRY(hipMemcpyAsync(din.p, in, batch * w, hipMemcpyHostToDevice, c->stream));
@@ -1431,7 +1448,7 @@ int sr_serialize_batch(sr_ctx *c, uint8_t *wire, const uint64_t *in, size_t batc
     DeviceGuard g(c->device);
     const size_t n = batch * c->degree;
     if (n == 0) return SR_OK;
-    DevBuf din, dw;
+    DevBuf din(c, 0), dw(c, 1);
     if (int rc = din.alloc(n * c->limbs * 8)) return rc;
     if (int rc = dw.alloc(n * wire_coeff_bytes(c))) return rc;
     HIP_TRY(hipMemcpyAsync(din.p, in, n * c->limbs * 8, hipMemcpyHostToDevice, c->stream));
@@ -1447,7 +1464,7 @@ int sr_deserialize_batch(sr_ctx *c, uint64_t *out, const uint8_t *wire, size_t b
     DeviceGuard g(c->device);
     const size_t n = batch * c->degree;
     if (n == 0) return SR_OK;
-    DevBuf dout, dw;
+    DevBuf dout(c, 0), dw(c, 1);
     if (int rc = dout.alloc(n * c->limbs * 8)) return rc;
     if (int rc = dw.alloc(n * wire_coeff_bytes(c))) return rc;
     HIP_TRY(hipMemcpyAsync(dw.p, wire, n * wire_coeff_bytes(c), hipMemcpyHostToDevice, c->stream));
@@ -1474,7 +1491,7 @@ int sr_recompose_batch_wide(sr_ctx *c, uint64_t *out, const uint64_t *in, uint64
     DeviceGuard g(c->device);
     const size_t w = c->degree * c->limbs * 8;
     if (batch_out == 0) return SR_OK;
-    DevBuf din, dout;
+    DevBuf din(c, 0), dout(c, 1);
     if (int rc = din.alloc(batch_out * padding_size * w)) return rc;
     if (int rc = dout.alloc(batch_out * w)) return rc;
     if (padding_size) HIP_TRY(hipMemcpyAsync(din.p, in, batch_out * padding_size * w, hipMemcpyHostToDevice, c->stream));

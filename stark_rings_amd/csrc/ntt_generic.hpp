@@ -405,6 +405,28 @@ __global__ __launch_bounds__(256) void matmul_kernel(typename F::storage *y, con
 template <class F>
 __global__ void rot_kernel(typename F::storage *out, const typename F::storage *in, size_t d, size_t half, size_t batch) {
     const size_t n = batch * d;
+    if constexpr (sizeof(typename F::storage) == 8) {
+        // one-limb fields, even D and even D/2: a lane writes the pair (i, i + 1), i even, as one non-temporal 16-byte store from the
+        // two 8-byte words in[i - 1], in[i] (the shift by one word makes the read side 8-byte aligned only)
+        if ((d & 1) == 0 && (half & 1) == 0 && (((uintptr_t)out) & 15u) == 0) {
+            typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+            for (size_t t2 = blockIdx.x * (size_t)blockDim.x + threadIdx.x; t2 < (n >> 1); t2 += (size_t)gridDim.x * blockDim.x) {
+                const size_t t = t2 << 1, e = t / d, i = t - e * d;
+                const typename F::storage *src = in + e * d;
+                typename F::elem v0 = i == 0 ? F::sub(F::zero(), F::load(src + d - 1)) : F::load(src + i - 1);
+                if (half && i == half) v0 = F::add(v0, F::load(src + d - 1));
+                const typename F::elem v1 = F::load(src + i);
+                typename F::storage o[2];
+                F::store(&o[0], v0);
+                F::store(&o[1], v1);
+                u64x2 ov;
+                ov.x = o[0];
+                ov.y = o[1];
+                __builtin_nontemporal_store(ov, reinterpret_cast<u64x2 *>(out + t));
+            }
+            return;
+        }
+    }
     for (size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x; t < n; t += (size_t)gridDim.x * blockDim.x) {
         const size_t e = t / d, i = t - e * d;
         const typename F::storage *src = in + e * d;
