@@ -22,6 +22,11 @@ import os
 import sys
 import time
 
+# The HIP runtime multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues (4 by default); PyTorch's stream, the context's two
+# streams (the lanes of the tuned ring product) and a timing stream need one each, or two of them serialise.
+# A host setting for the runtime, made before anything initialises HIP; the library itself reads no environment variable.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 for _p in (ROOT, os.path.join(ROOT, "oracle")):
     if _p not in sys.path:

@@ -87,11 +87,12 @@ typedef struct sr_plan {
     int32_t log_tile;             /* 0 = default; 8..12: LDS tile of the generic kernels                                       */
     int32_t stark_whole_max;      /* 0 = default (11); 9..12: largest log2 D the Stark kernels keep as one tile per element    */
     uint32_t chunk_polys;         /* fused ring products above one tile: ring elements per chunk of launches (0 = default: as many
-                                     as the operand scratch holds; the tuned Goldilocks path cuts a batch of 64 or more elements
-                                     into eight chunks)                                                                        */
+                                     as the operand scratch holds; the tuned Goldilocks path: see lanes)                       */
     uint64_t scratch_limit_bytes; /* cap of the operand scratch (0 = default 16 GiB); larger batches run in chunks             */
     uint32_t host_chunk_mb;       /* chunk of the host-pointer pipeline in MiB (0 = default 128)                               */
-    uint32_t reserved;
+    uint32_t lanes;               /* tuned Goldilocks product, 2^16 <= D <= 2^20: 0 = default (two internal streams, chunks of
+                                     chunk_polys or 64 MiB of coefficients each, intermediates in per-lane scratch so that they are
+                                     re-read from the Infinity Cache), 1 = one stream (eight large chunks, or chunk_polys)       */
 } sr_plan;
 int sr_ctx_create_ex(int ring, int log2_degree, int device, const sr_plan *plan, sr_ctx **out);
 /* Pre-sizes the context's operand scratch for fused ring products of up to `batch` elements (capped by the plan's

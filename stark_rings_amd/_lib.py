@@ -78,7 +78,7 @@ SYMBOLS = {
 class Plan(ctypes.Structure):
     """sr_plan of include/stark_rings_hip.h: the kernel plan of a context, fixed when it is created."""
     _fields_ = [("flags", _c.c_uint32), ("log_tile", _c.c_int32), ("stark_whole_max", _c.c_int32), ("chunk_polys", _c.c_uint32),
-                ("scratch_limit_bytes", _c.c_uint64), ("host_chunk_mb", _c.c_uint32), ("reserved", _c.c_uint32)]
+                ("scratch_limit_bytes", _c.c_uint64), ("host_chunk_mb", _c.c_uint32), ("lanes", _c.c_uint32)]
 
 
 PLAN_GENERIC_KERNELS, PLAN_GL_NO_COLS256, PLAN_RT_NO_COLS256 = 1, 2, 4
@@ -109,6 +109,7 @@ def plan_from_env(ring=None):
     p.chunk_polys = int(e.get("SR_CHUNK_POLYS", "0") or 0)
     p.scratch_limit_bytes = int(e.get("SR_SCRATCH_LIMIT_MB", "0") or 0) << 20
     p.host_chunk_mb = int(e.get("SR_HOST_CHUNK_MB", "0") or 0)
+    p.lanes = int(e.get("SR_LANES", "0") or 0)
     return p
 
 

@@ -83,6 +83,7 @@ struct sr_ctx {
     bool stark_tuned = false;  // and k >= 4: the register-tiled kernels of ntt_stark.hpp (SR_STARK_TUNED=0: generic kernels on StarkL)
     bool stark_lazy = false;  // Stark rings: transforms run on StarkL (nine 28-bit limbs, lazy carries; stark_lazy.hpp)
     // staging for host-pointer entry points
+    sr::GlLanes gl_lanes;  // tuned Goldilocks ring product on two internal streams (streams and events created on first use)
     void *host_tmp[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // device temporaries of the host-pointer linear-algebra /
     size_t host_tmp_bytes[5] = {0, 0, 0, 0, 0};                         // decomposition calls (grow-only, see DevBuf)
     void *stage[4] = {nullptr, nullptr, nullptr, nullptr};  // [2], [3]: second lane of the chunked host pipeline
@@ -450,6 +451,36 @@ size_t gl_chunk_polys(const sr_ctx *c, size_t batch) {
     size_t chunk = scratch_polys(c, batch, (size_t)8 << c->k);
     if (!c->plan.chunk_polys && batch >= 64 && chunk > (batch + 7) / 8) chunk = (batch + 7) / 8;
     return chunk;
+}
+// Two-lane plan of the tuned Goldilocks product (sr::gl_fast_ring_mul_lanes): chunk of a lane in ring elements -- 64 MiB of
+// coefficients per scratch buffer by default, so that the four buffers of the two lanes are the 256 MiB of the Infinity Cache --
+// capped by the plan's scratch limit (four buffers) and by sr_plan.chunk_polys when set.  Taken when the plan allows lanes
+// (sr_plan.lanes != 1), the column passes are cols256 launches and the batch is more than one such chunk.
+size_t gl_lane_chunk(const sr_ctx *c) {
+    const size_t elem = (size_t)8 << c->k;
+    size_t chunk = c->plan.chunk_polys ? (size_t)c->plan.chunk_polys : (((size_t)64 << 20) / elem);
+    const size_t cap = c->plan.scratch_limit_bytes ? (size_t)c->plan.scratch_limit_bytes : ((size_t)16 << 30);
+    if (chunk > cap / (4 * elem)) chunk = cap / (4 * elem);
+    return chunk ? chunk : 1;
+}
+bool gl_use_lanes(const sr_ctx *c, size_t batch) {
+    return c->plan.lanes != 1 && c->k > 12 && c->gl_fast.cols256 && batch > gl_lane_chunk(c);
+}
+int gl_lanes_init(sr_ctx *c) {
+    sr::GlLanes &L = c->gl_lanes;
+    if (L.n) return SR_OK;
+    HIP_TRY(hipEventCreateWithFlags(&L.fork, hipEventDisableTiming));
+    // The runtime multiplexes streams onto a few hardware queues (GPU_MAX_HW_QUEUES, 4 by default) and two streams that share
+    // one run one after the other -- measured inside a PyTorch process: 20.4 ms per config-2 batch with two NEW streams for the
+    // lanes (the fifth stream of the process landed on a lane's queue), 16.3 ms with a queue each.  Different stream priorities
+    // do separate the queues but starve the lower lane (17.9 ms).  So the lanes are the two streams the context owns anyway (the
+    // host-pointer pipeline's; idle during a device call, and any earlier work on them simply runs first); a process that holds
+    // more streams than hardware queues should raise GPU_MAX_HW_QUEUES (bench.py does).
+    L.st[0] = c->stream;
+    L.st[1] = c->out_stream;
+    for (int i = 0; i < 2; i++) HIP_TRY(hipEventCreateWithFlags(&L.join[i], hipEventDisableTiming));
+    L.n = 2;
+    return SR_OK;
 }
 template <class F>
 int ring_mul_dev(sr_ctx *c, uint64_t *out, const uint64_t *a, const uint64_t *b, size_t batch, hipStream_t st) {
@@ -946,6 +977,24 @@ int dev_ring_mul(sr_ctx *c, uint64_t *out, const uint64_t *a, const uint64_t *b,
         return rt_ring_mul<sr::Goldilocks>(c, out, a, b, batch, st);
     }
     if (c->ring == SR_RING_GOLDILOCKS_POW2 && c->fast_goldilocks && sr::gl_fast_supported(c->gl_fast)) {
+        // chunks on two internal streams, intermediates in per-lane scratch pairs (not for the host-pointer pipeline, which
+        // drives this function on the very streams the lanes are and is bound by PCIe anyway)
+        if (gl_use_lanes(c, batch) && st != c->stream && st != c->out_stream) {
+            const size_t chunk = gl_lane_chunk(c), words = chunk << c->k;
+            if (int rc = ensure_scratch(c, 1, 4 * words * 8)) return rc;
+            if (int rc = gl_lanes_init(c)) return rc;
+            if (int rc = rt_scratch_acquire(c, st)) return rc;
+            sr::GlLanes &L = c->gl_lanes;
+            uint64_t *base = reinterpret_cast<uint64_t *>(c->rt_scratch[0]);
+            L.chunk = chunk;
+            for (int i = 0; i < 2; i++) {
+                L.sa[i] = base + (size_t)(2 * i) * words;
+                L.sb[i] = base + (size_t)(2 * i + 1) * words;
+            }
+            const int rc = sr::gl_fast_ring_mul_lanes(c->gl_fast, out, a, b, L, batch, st);
+            if (int r2 = rt_scratch_release(c, st)) return r2;
+            return rc ? fail(SR_E_HIP, "goldilocks fast-path launch failed") : SR_OK;
+        }
         uint64_t *scratch = nullptr;
         size_t chunk = 0;
         if (c->k > 12 && batch) {  // b's column stages go through the operand scratch
@@ -1004,6 +1053,7 @@ int sr_ctx_create_ex(int ring, int log2_degree, int device, const sr_plan *plan,
         if (plan->log_tile && (plan->log_tile < 8 || plan->log_tile > 12)) return fail(SR_E_INVALID, "sr_plan: log_tile must be 0 or 8..12");
         if (plan->stark_whole_max && (plan->stark_whole_max < 9 || plan->stark_whole_max > 12))
             return fail(SR_E_INVALID, "sr_plan: stark_whole_max must be 0 or 9..12");
+        if (plan->lanes > 2) return fail(SR_E_INVALID, "sr_plan: lanes must be 0 (default), 1 or 2");
     }
     if (ring < SR_RING_GOLDILOCKS_POW2 || ring > SR_RING_FROG_16) return fail(SR_E_INVALID, "unknown ring id");
     if (is_pow2_ring(ring) && (log2_degree < 0 || log2_degree > 24)) return fail(SR_E_INVALID, "log2_degree out of range");
@@ -1094,6 +1144,11 @@ int sr_ctx_destroy(sr_ctx *c) {
     if (c->rt_scratch_free) (void)hipEventDestroy(c->rt_scratch_free);
     for (int i = 0; i < 5; i++)
         if (c->host_tmp[i]) (void)hipFree(c->host_tmp[i]);
+    if (c->gl_lanes.n) {
+        for (int i = 0; i < 2; i++)
+            if (c->gl_lanes.join[i]) (void)hipEventDestroy(c->gl_lanes.join[i]);  // the streams are the context's own
+        if (c->gl_lanes.fork) (void)hipEventDestroy(c->gl_lanes.fork);
+    }
     if (c->d_counter) (void)hipFree(c->d_counter);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -1532,6 +1587,10 @@ int sr_ctx_reserve_scratch(sr_ctx *c, size_t batch) {
                                 : (c->stark_tuned ? c->stark_one_tile : c->k <= c->log_tile);
     if (one_launch) return SR_OK;
     const bool gl = c->ring == SR_RING_GOLDILOCKS_POW2 && c->fast_goldilocks && sr::gl_fast_supported(c->gl_fast);
+    if (gl && gl_use_lanes(c, batch)) {
+        if (int rc = gl_lanes_init(c)) return rc;
+        return ensure_scratch(c, 1, 4 * gl_lane_chunk(c) * elem);
+    }
     return ensure_scratch(c, 1, (gl ? gl_chunk_polys(c, batch) : scratch_polys(c, batch, elem)) * elem);
 }
 int sr_reduce_batch_dev(sr_ctx *c, const uint64_t *in, size_t in_len, uint64_t *out, size_t batch, void *stream) {

@@ -85,6 +85,26 @@ __device__ __forceinline__ void st_stream(u64 *p, u64 v) {
     *p = v;
 #endif
 }
+// Intermediates (column-pass output, rows output) are written and read WITHOUT the non-temporal hint, so that they allocate in the
+// 256 MB Infinity Cache: the ring product runs in chunks small enough for a chunk's intermediates to stay there (gl_fast_ring_mul_lanes).
+// Operand reads and result writes keep the hint.  SR_GL_NT_SCRATCH = 1: everything non-temporal (A/B switch).
+#ifndef SR_GL_NT_SCRATCH
+#define SR_GL_NT_SCRATCH 0
+#endif
+__device__ __forceinline__ u64 ld_scratch(const u64 *p) {
+#if SR_GL_NT_SCRATCH
+    return ld_stream(p);
+#else
+    return *p;
+#endif
+}
+__device__ __forceinline__ void st_scratch(u64 *p, u64 v) {
+#if SR_GL_NT_SCRATCH
+    st_stream(p, v);
+#else
+    *p = v;
+#endif
+}
 constexpr int kTile = 4096;
 constexpr int kLdsElems = kTile + kTile / 16;  // padded: pos + (pos >> 4)
 
@@ -525,7 +545,7 @@ __device__ __forceinline__ void cols256_tile(const unsigned tile, u64 *data, con
         dft16_fwd(x);
 #pragma unroll
         for (int sg = 0; sg < 16; sg++)
-            st_stream(reinterpret_cast<u64 *>(pb + (offB + (unsigned)sg * leg)), G::mul(x[sg], tw[sg]));
+            st_scratch(reinterpret_cast<u64 *>(pb + (offB + (unsigned)sg * leg)), G::mul(x[sg], tw[sg]));
 #else
 #pragma unroll
         for (int sg = 0; sg < 16; sg++) *reinterpret_cast<u64 *>(pb + (offB + (unsigned)sg * leg)) = x[sg] ^ tw[sg];
@@ -535,7 +555,7 @@ __device__ __forceinline__ void cols256_tile(const unsigned tile, u64 *data, con
         prio_mem();
 #pragma unroll
         for (int sg = 0; sg < 16; sg++) {
-            x[sg] = ld_stream(reinterpret_cast<const u64 *>(ps + (offB + (unsigned)sg * leg)));
+            x[sg] = ld_scratch(reinterpret_cast<const u64 *>(ps + (offB + (unsigned)sg * leg)));
             tw[sg] = *reinterpret_cast<const u64 *>(tb + (offB + (unsigned)sg * leg));
         }
         prio_alu();
@@ -587,7 +607,7 @@ __device__ __forceinline__ void tile_fwd(const u64 *__restrict__ src, u64 *lds, 
         const int pos = j * 256 + t;
         // ragged last tile (TW only): out-of-range lanes re-read the last valid coefficient; their results belong to ring
         // elements that do not exist and are never stored, and no pass mixes ring elements, so no branch is needed
-        x[j] = ld_stream(src + ((!TW || pos < nvalid) ? pos : nvalid - 1));
+        x[j] = TW ? ld_stream(src + (pos < nvalid ? pos : nvalid - 1)) : ld_scratch(src + pos);  // TW: operands; else column-pass output
     }
     if (TW) twist_rows<Q, false>(x, std::make_integer_sequence<int, 16>{});
     dft16_fwd_q<Q>(x);
@@ -639,7 +659,8 @@ __device__ __forceinline__ void tile_inv(u64 *x, u64 *lds, const int t, const Ta
 #pragma unroll
     for (int j = 0; j < 16; j++) {
         const int pos = j * 256 + t;
-        if (!TW || pos < nvalid) st_stream(dst + pos, x[j]);
+        if (!TW) st_scratch(dst + pos, x[j]);  // goes on to the inverse column pass
+        else if (pos < nvalid) st_stream(dst + pos, x[j]);
     }
 }
 
@@ -716,7 +737,7 @@ __device__ __forceinline__ void tile256_load(const u64 *__restrict__ src, const 
     const int i0 = t & 15, base2 = (t >> 4) * 256 + i0;
     prio_mem();
 #pragma unroll
-    for (int j = 0; j < 16; j++) x[j] = ld_stream(src + base2 + j * 16);
+    for (int j = 0; j < 16; j++) x[j] = ld_scratch(src + base2 + j * 16);
     prio_alu();
 }
 // x holds the lane's 16 coefficients (tile256_load) on entry, its 16 consecutive NTT slots on return
@@ -748,7 +769,7 @@ __device__ __forceinline__ void tile256_inv(u64 *x, u64 *lds, const int t, const
     for (int s = 1; s < 16; s++) x[s] = G::mul(x[s], T.w2i[s * 16 + i0]);
     dft16_inv(x);
 #pragma unroll
-    for (int j = 0; j < 16; j++) st_stream(dst + base2 + j * 16, x[j]);
+    for (int j = 0; j < 16; j++) st_scratch(dst + base2 + j * 16, x[j]);
 }
 // SR_ROWS256_PREFETCH_B = 1: the fused product requests b's tile together with a's (16 more registers in flight) instead of
 // after a's transform
@@ -1100,6 +1121,44 @@ inline int gl_fast_ring_mul(const GoldilocksFastTables &f, uint64_t *out, const 
         if (gl_strided_inv(f, o, n, true, st)) return 1;
     }
     return 0;
+}
+
+// The same product on LANES streams (cols256 plans: 2^16 <= D <= 2^20).  Chunks of `chunk` ring elements are dealt round-robin to
+// the lanes; a lane runs a chunk's four launches through ITS OWN scratch pair (sa: a's column-pass output, rows output; sb: b's), so
+// that (i) a chunk's intermediates -- 2 x chunk x D x 8 bytes, 128 MB at the default chunk -- are re-read from the Infinity Cache
+// instead of HBM (61 against ~100 pJ per byte on a step that runs at the socket's power cap: tools/ubench/l2_power.hip), and (ii)
+// the other lane's kernels fill the tail of every small launch (one stream at this chunk size: 21.5 ms per config-2 batch; two:
+// 16.3-16.9 ms against 17.3-17.6 ms for the former eight large chunks on one stream).  fork / join: events owned by the caller.
+struct GlLanes {
+    int n = 0;                       // streams in use (<= 2)
+    hipStream_t st[2] = {nullptr, nullptr};
+    hipEvent_t fork = nullptr, join[2] = {nullptr, nullptr};
+    uint64_t *sa[2] = {nullptr, nullptr}, *sb[2] = {nullptr, nullptr};
+    size_t chunk = 0;                // ring elements per chunk (each of sa[i], sb[i] holds that many)
+};
+inline int gl_fast_ring_mul_lanes(const GoldilocksFastTables &f, uint64_t *out, const uint64_t *a, const uint64_t *b, const GlLanes &L,
+                                  size_t batch, hipStream_t st) {
+    if (batch == 0) return 0;
+    if (!f.cols256 || L.n < 1 || L.chunk == 0) return 1;
+    if (hipEventRecord(L.fork, st) != hipSuccess) return 1;
+    for (int i = 0; i < L.n; i++)
+        if (hipStreamWaitEvent(L.st[i], L.fork, 0) != hipSuccess) return 1;
+    const size_t stride = (size_t)1 << f.k;
+    int rc = 0;
+    size_t c = 0;
+    for (size_t e = 0; e < batch && !rc; e += L.chunk, c++) {
+        const int i = (int)(c % (size_t)L.n);
+        const size_t n = batch - e < L.chunk ? batch - e : L.chunk;
+        rc = gl_launch_cols256<0>(f, L.sa[i], a + e * stride, n, f.t.wcf, f.t.twist_f, L.st[i]);
+        if (!rc) rc = gl_launch_cols256<0>(f, L.sb[i], b + e * stride, n, f.t.wcf, f.t.twist_f, L.st[i]);
+        if (!rc) rc = gl_launch_rows<2>(f, L.sa[i], L.sb[i], L.sa[i], n, true, L.st[i]);
+        if (!rc) rc = gl_launch_cols256<1>(f, out + e * stride, L.sa[i], n, f.t.wci, f.t.twist_i_mul, L.st[i]);
+    }
+    for (int i = 0; i < L.n; i++) {  // join even after a failed launch: the caller's stream must not run ahead of the lanes
+        if (hipEventRecord(L.join[i], L.st[i]) != hipSuccess) rc = 1;
+        if (hipStreamWaitEvent(st, L.join[i], 0) != hipSuccess) rc = 1;
+    }
+    return rc;
 }
 
 // out = icrt(crt(a) (.) b_ntt), b_ntt = crt(b) as sr_ntt_fwd leaves it: a's column stages go straight to out, the rows kernel

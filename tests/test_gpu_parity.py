@@ -1483,6 +1483,45 @@ def test_column_pass_tile_order_covers_every_tile(torch_cuda, name, k, batch):
     ring.close()
 
 
+@pytest.mark.parametrize("k,batch,plan_kw", [(16, 300, {}), (16, 300, {"chunk_polys": 64}), (16, 131, {"chunk_polys": 1}), (17, 7, {"chunk_polys": 2}),
+                                             (20, 3, {"chunk_polys": 1}), (16, 300, {"lanes": 1}), (16, 129, {"scratch_limit_bytes": 16 << 20})])
+def test_goldilocks_product_on_two_lanes(torch_cuda, k, batch, plan_kw):
+    """Tuned Goldilocks product above one chunk: chunks dealt to two internal streams, each with its own scratch pair (gl_fast_ring_mul_lanes);
+    ragged last chunks, chunk of one element, a scratch cap that shrinks the chunk, and the one-stream plan (lanes = 1) for comparison.  Against the
+    oracle: out of place with operands intact, then in place over a (out == a) and squaring (a and b the same buffer), and a second call on ANOTHER
+    caller stream right behind the first (the scratch is ordered across streams by an event)."""
+    torch = torch_cuda
+    from stark_rings_amd import CyclotomicRing
+
+    F = O.GOLDILOCKS
+    n = batch << k
+    a = O.fill_uniform(F, 0x81, 0, n)
+    b = O.fill_uniform(F, 0x82, 0, n)
+    want = O.pow2_ring_mul(F, a, b, k, batch, 8)
+    ring = CyclotomicRing("goldilocks", k, device=0, plan=_plan(**plan_kw))
+    ta = torch.from_numpy(a.view(np.int64)).cuda()
+    tb = torch.from_numpy(b.view(np.int64)).cuda()
+    out = torch.empty_like(ta)
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    with torch.cuda.stream(s1):
+        ring.mul_dev(out, ta, tb, stream=s1)
+    with torch.cuda.stream(s2):
+        out2 = torch.empty_like(ta)
+        ring.mul_dev(out2, tb, ta, stream=s2)  # commutes; queued on another stream while the first call's lanes still run
+    s1.synchronize()
+    s2.synchronize()
+    assert np.array_equal(out.cpu().numpy().view(np.uint64), want)
+    assert np.array_equal(out2.cpu().numpy().view(np.uint64), want)
+    assert np.array_equal(ta.cpu().numpy().view(np.uint64), a) and np.array_equal(tb.cpu().numpy().view(np.uint64), b)
+    ring.mul_dev(ta, ta, tb)   # in place over a
+    torch.cuda.synchronize()
+    assert np.array_equal(ta.cpu().numpy().view(np.uint64), want)
+    ring.mul_dev(out, tb, tb)  # squaring (a and b the same buffer)
+    torch.cuda.synchronize()
+    assert np.array_equal(out.cpu().numpy().view(np.uint64), O.pow2_ring_mul(F, b, b, k, batch, 8))
+    ring.close()
+
+
 @pytest.mark.parametrize("name,k", [("stark", 3), ("goldilocks", 4), ("babybear", 3), ("frog16", 0)])
 @pytest.mark.parametrize("basis", [1 << 64, (1 << 64) + 2, 3 * (1 << 70) + 6, 1 << 100, (1 << 128) - 2])
 def test_decomposition_with_u128_bases(torch_cuda, name, k, basis):

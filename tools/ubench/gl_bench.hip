@@ -4,6 +4,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
+#include <chrono>
 #include "../../stark_rings_amd/csrc/ntt_goldilocks.hpp"
 #ifdef PERSIST
 #include "cols256p_experiment.hpp"
@@ -117,6 +118,37 @@ int main(int argc, char **argv) {
         float ms; CK(hipEventElapsedTime(&ms, cev[0], cev[nch * 5 - 1])); wall += ms;
     }
     printf("chunks of %zu: wall %.3f ms per batch; ", ch, wall / reps);
+#ifdef STREAMS
+    {   // the same chunks dealt round-robin to STREAMS streams, each with its own scratch pair: another stream's kernels fill a launch's tail
+        hipStream_t st[STREAMS];
+        u64 *ssa[STREAMS], *ssb[STREAMS];
+        for (int i = 0; i < STREAMS; i++) { CK(hipStreamCreate(&st[i])); CK(hipMalloc(&ssa[i], ch << (k + 3))); CK(hipMalloc(&ssb[i], ch << (k + 3))); }
+        double tot = 0;
+        for (int r = -1; r < reps; r++) {
+            CK(hipDeviceSynchronize());
+            auto t0 = std::chrono::steady_clock::now();
+            for (size_t c = 0; c < nch; c++) {
+                const int si = (int)(c % STREAMS);
+                const size_t np = (c + 1) * ch <= npoly ? ch : npoly - c * ch;
+                u64 *ac = a + ((c * ch) << k), *bc = b + ((c * ch) << k);
+                const unsigned cb = (unsigned)(np << (k - 8 - LCV));
+                const unsigned grp = sr::xcd_grouped_tiles(cb, SR_COLS_XCD_GROUP);
+#ifdef LIBFLOW  // the library's flow for a *= b: a's intermediates live in a itself, only b's go through the lane's scratch
+                u64 *ia = ac;
+#else
+                u64 *ia = ssa[si];
+#endif
+                hipLaunchKernelGGL((cols256_kernel<0, LCV>), dim3(cb), dim3(16 << LCV), 0, st[si], ia, ac, k, T.wcf, T.twist_f, grp);
+                hipLaunchKernelGGL((cols256_kernel<0, LCV>), dim3(cb), dim3(16 << LCV), 0, st[si], ssb[si], bc, k, T.wcf, T.twist_f, grp);
+                hipLaunchKernelGGL((rows256_kernel<2>), dim3((unsigned)(np << (k - 12))), dim3(256), 0, st[si], ia, ssb[si], ia, T);
+                hipLaunchKernelGGL((cols256_kernel<1, LCV>), dim3(cb), dim3(16 << LCV), 0, st[si], ac, ia, k, T.wci, T.twist_i_mul, grp);
+            }
+            CK(hipDeviceSynchronize());
+            if (r >= 0) tot += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        }
+        printf("[%d streams: %.3f ms per batch] ", STREAMS, tot / reps);
+    }
+#endif
 #endif
 #ifdef MIXED
     {   // the same four phases as ONE mixed-role launch (junk data: the roles work on four independent buffers)
