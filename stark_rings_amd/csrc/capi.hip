@@ -629,11 +629,51 @@ size_t rt_chunk_polys(const sr_ctx *c, size_t batch) {
     if (c->plan.chunk_polys) return c->plan.chunk_polys < batch ? c->plan.chunk_polys : batch;
     return batch >= 64 ? (batch + 7) / 8 : batch;
 }
+// two-lane plan of the register-tiled product, as for the tuned Goldilocks path (gl_lane_chunk / gl_fast_ring_mul_lanes): chunks of
+// 64 MiB of packed words per scratch buffer on the context's two streams, each lane with its own pair of packed buffers
+template <class F>
+size_t rt_lane_chunk(const sr_ctx *c) {
+    const size_t elem = sizeof(typename F::elem) << c->k;
+    size_t chunk = c->plan.chunk_polys ? (size_t)c->plan.chunk_polys : (((size_t)64 << 20) / elem);
+    const size_t cap = c->plan.scratch_limit_bytes ? (size_t)c->plan.scratch_limit_bytes : ((size_t)16 << 30);
+    if (chunk > cap / (4 * elem)) chunk = cap / (4 * elem);
+    return chunk ? chunk : 1;
+}
+template <class F>
+bool rt_use_lanes(const sr_ctx *c, size_t batch, hipStream_t st) {
+    return c->plan.lanes != 1 && c->k > 12 && batch > rt_lane_chunk<F>(c) && st != c->stream && st != c->out_stream;
+}
 template <class F>
 int rt_ring_mul(sr_ctx *c, uint64_t *out, const uint64_t *a, const uint64_t *b, size_t batch, hipStream_t st) {
     using S = typename F::storage;
     using E = typename F::elem;
     if (batch == 0) return SR_OK;
+    if (rt_use_lanes<F>(c, batch, st)) {
+        const size_t chunk = rt_lane_chunk<F>(c), words = chunk << c->k;
+        if (int rc = ensure_scratch(c, 1, 4 * words * sizeof(E))) return rc;
+        if (int rc = gl_lanes_init(c)) return rc;
+        if (int rc = rt_scratch_acquire(c, st)) return rc;
+        sr::GlLanes &L = c->gl_lanes;
+        E *base = reinterpret_cast<E *>(c->rt_scratch[0]);
+        HIP_TRY(hipEventRecord(L.fork, st));
+        for (int i = 0; i < 2; i++) HIP_TRY(hipStreamWaitEvent(L.st[i], L.fork, 0));
+        int rc = 0;
+        size_t ci = 0;
+        for (size_t e = 0; e < batch && !rc; e += chunk, ci++) {
+            const int i = (int)(ci & 1);
+            const size_t n = batch - e < chunk ? batch - e : chunk;
+            const size_t off = e << c->k;
+            rc = sr::rt::ring_mul<F>(c->rt_hooks, reinterpret_cast<S *>(out) + off, reinterpret_cast<const S *>(a) + off,
+                                     reinterpret_cast<const S *>(b) + off, n, make_rt_params<F>(c, true), base + (size_t)(2 * i) * words,
+                                     base + (size_t)(2 * i + 1) * words, L.st[i]);
+        }
+        for (int i = 0; i < 2; i++) {  // join even after a failed launch
+            if (hipEventRecord(L.join[i], L.st[i]) != hipSuccess) rc = 1;
+            if (hipStreamWaitEvent(st, L.join[i], 0) != hipSuccess) rc = 1;
+        }
+        if (int r2 = rt_scratch_release(c, st)) return r2;
+        return rc ? fail(SR_E_HIP, "register-tiled launch failed") : SR_OK;
+    }
     const size_t chunk = c->k > 12 ? rt_chunk_polys(c, batch) : batch;
     if (int rc = rt_ensure_scratch(c, 2, (chunk << c->k) * sizeof(E))) return rc;
     if (int rc = rt_scratch_acquire(c, st)) return rc;
@@ -1580,6 +1620,12 @@ int sr_ctx_reserve_scratch(sr_ctx *c, size_t batch) {
     const size_t elem = c->degree * c->limbs * 8;
     if (c->regtile) {
         const size_t w = c->ring == SR_RING_BABYBEAR_POW2 ? 4 : 8;
+        const bool lanes = c->ring == SR_RING_BABYBEAR_POW2 ? rt_use_lanes<sr::BabyBear>(c, batch, nullptr) : rt_use_lanes<sr::Goldilocks>(c, batch, nullptr);
+        if (lanes) {
+            const size_t chunk = c->ring == SR_RING_BABYBEAR_POW2 ? rt_lane_chunk<sr::BabyBear>(c) : rt_lane_chunk<sr::Goldilocks>(c);
+            if (int rc = gl_lanes_init(c)) return rc;
+            return ensure_scratch(c, 1, 4 * (chunk << c->k) * w);
+        }
         return rt_ensure_scratch(c, 2, ((c->k > 12 ? rt_chunk_polys(c, batch) : batch) << c->k) * w);
     }
     const bool one_launch = c->ring == SR_RING_GOLDILOCKS_POW2 && c->fast_goldilocks && sr::gl_fast_supported(c->gl_fast)

@@ -66,17 +66,22 @@ template <class F> struct View<F, Boundary> {
 #endif
     }
 };
+// The packed scratch holds a chunk's intermediates; without the hint they allocate in the Infinity Cache, which is what the two-lane
+// ring product wants (capi.hip: rt_ring_mul).  SR_RT_NT_SCRATCH = 1: non-temporal like the boundary words (A/B switch).
+#ifndef SR_RT_NT_SCRATCH
+#define SR_RT_NT_SCRATCH 0
+#endif
 template <class F> struct View<F, Packed> {
     typedef typename F::elem T;
     static __device__ __forceinline__ typename F::elem ld(const T *p) {
-#if SR_RT_NT
+#if SR_RT_NT_SCRATCH
         return __builtin_nontemporal_load(p);
 #else
         return *p;
 #endif
     }
     static __device__ __forceinline__ void st(T *p, const typename F::elem &v) {
-#if SR_RT_NT
+#if SR_RT_NT_SCRATCH
         __builtin_nontemporal_store(v, p);
 #else
         *p = v;

@@ -1522,6 +1522,41 @@ def test_goldilocks_product_on_two_lanes(torch_cuda, k, batch, plan_kw):
     ring.close()
 
 
+@pytest.mark.parametrize("name,k,batch,plan_kw", [("babybear", 16, 600, {}), ("babybear", 16, 300, {"chunk_polys": 64}), ("babybear", 14, 70, {"chunk_polys": 8}),
+                                                  ("babybear", 20, 3, {"chunk_polys": 1}), ("babybear", 16, 300, {"lanes": 1}),
+                                                  ("goldilocks", 16, 300, {"flags": 8, "chunk_polys": 64})])  # 8 = SR_PLAN_GL_REGTILE
+def test_register_tiled_product_on_two_lanes(torch_cuda, name, k, batch, plan_kw):
+    """The register-tiled product (BabyBear; Goldilocks by plan flag) in chunks on the context's two streams, each lane with its own pair of
+    packed scratch buffers: against the oracle, operands intact, in place over a, and a second call queued on another stream."""
+    torch = torch_cuda
+    from stark_rings_amd import CyclotomicRing
+
+    F = O.FIELD_ID[name]
+    n = batch << k
+    a = O.fill_uniform(F, 0x91, 0, n)
+    b = O.fill_uniform(F, 0x92, 0, n)
+    want = O.pow2_ring_mul(F, a, b, k, batch, 8)
+    ring = CyclotomicRing(name, k, device=0, plan=_plan(**plan_kw))
+    ta = torch.from_numpy(a.view(np.int64)).cuda()
+    tb = torch.from_numpy(b.view(np.int64)).cuda()
+    out = torch.empty_like(ta)
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    with torch.cuda.stream(s1):
+        ring.mul_dev(out, ta, tb, stream=s1)
+    with torch.cuda.stream(s2):
+        out2 = torch.empty_like(ta)
+        ring.mul_dev(out2, tb, ta, stream=s2)
+    s1.synchronize()
+    s2.synchronize()
+    assert np.array_equal(out.cpu().numpy().view(np.uint64), want)
+    assert np.array_equal(out2.cpu().numpy().view(np.uint64), want)
+    assert np.array_equal(ta.cpu().numpy().view(np.uint64), a) and np.array_equal(tb.cpu().numpy().view(np.uint64), b)
+    ring.mul_dev(ta, ta, tb)
+    torch.cuda.synchronize()
+    assert np.array_equal(ta.cpu().numpy().view(np.uint64), want)
+    ring.close()
+
+
 @pytest.mark.parametrize("name,k", [("stark", 3), ("goldilocks", 4), ("babybear", 3), ("frog16", 0)])
 @pytest.mark.parametrize("basis", [1 << 64, (1 << 64) + 2, 3 * (1 << 70) + 6, 1 << 100, (1 << 128) - 2])
 def test_decomposition_with_u128_bases(torch_cuda, name, k, basis):
