@@ -204,7 +204,10 @@ def readme(outdir):
             cfg, w, r["kernel"], per_launch / 1e9, ("%.3f" % avg_ms) if avg_ms else "n/a", ach, ach / 8000.0, r["frac"],
             pj["bytes_per_launch"].get(r["kernel"], 0) / 1e9))
     md.append("\nThe trace run and the stand-alone bench run are different launches on (possibly) different boxes: the two fractions agree within the")
-    md.append("box-to-box spread (a few percent).  PMC bytes per launch equal the algorithmic bytes of each kernel (no re-reads).\n")
+    md.append("box-to-box spread (a few percent).  PMC bytes per launch equal the algorithmic bytes of each kernel (no re-reads).")
+    md.append("Configs 2, 3 and 4 run their chunks on two internal streams (DESIGN.md section 3): a launch's duration in the trace is time in flight")
+    md.append("beside the other stream's kernels, so these per-launch fractions are about half of what the same kernel reaches alone; bench.py's")
+    md.append("`roofline.single_stream` block (a one-stream calibration in the same run) and `whole_step_frac` are the figures to compare with earlier rounds.\n")
     for w in names:
         sp = os.path.join(outdir, "summary_%s.md" % w)
         if os.path.exists(sp):
