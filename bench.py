@@ -108,6 +108,8 @@ def main():
     ap.add_argument("--workload", default="goldilocks_d65536_b16384", choices=sorted(WORKLOADS))
     ap.add_argument("--batch", type=int, default=0, help="override the per-GPU batch (debug only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-calibration", action="store_true",
+                    help="skip the one-stream calibration after the timed region (profile runs: only the timed configuration's launches)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo for rehearsals)")
     ap.add_argument("--variant", default="mul", choices=("mul", "mul_ntt_rhs"),
@@ -224,7 +226,7 @@ def main():
     # a calibration outside the timed region, reported separately as roofline.single_stream, never as the headline.
     prof_single = single_ms = None
     in_flight = sum(v["ms"] for v in prof.values() if v["launches"]) / args.steps
-    if rank == 0 and args.variant == "mul" and in_flight > 1.2 * (elapsed / args.steps * 1e3):
+    if rank == 0 and args.variant == "mul" and not args.no_calibration and in_flight > 1.2 * (elapsed / args.steps * 1e3):
         from stark_rings_amd._lib import plan_from_env
 
         plan1 = plan_from_env()

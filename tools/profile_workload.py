@@ -41,7 +41,7 @@ def collect(workload, outdir, steps):
         d = os.path.join(outdir, name)
         shutil.rmtree(d, ignore_errors=True)
         cmd = ["rocprofv3"] + flags + ["--output-format", "csv", "-d", d, "-o", "p", "--", "python3", os.path.join(ROOT, "bench.py"),
-               "--workload", workload, "--steps", str(steps if name == "trace" else 2), "--warmup", "1", "--no-cpu-baseline"]
+               "--workload", workload, "--steps", str(steps if name == "trace" else 2), "--warmup", "1", "--no-cpu-baseline", "--no-calibration"]
         print("+", " ".join(cmd), flush=True)
         with open(os.path.join(outdir, name + ".bench.json"), "w") as fo, open(os.path.join(outdir, name + ".err"), "w") as fe:
             rc = subprocess.call(cmd, env=env, stdout=fo, stderr=fe, cwd="/tmp")
@@ -85,6 +85,19 @@ def tag_of(kernel):
     return None
 
 
+MAX_ROWS = 4000  # rows of a raw CSV kept in profiles/ (the two-lane plans launch hundreds of chunk kernels per step)
+
+
+def copy_csv(src, dst):
+    """copy a rocprofv3 CSV, keeping the header and the first MAX_ROWS rows (a truncated copy says so in its last line)"""
+    with open(src) as fi, open(dst, "w") as fo:
+        for i, line in enumerate(fi):
+            if i > MAX_ROWS:
+                fo.write("# truncated: the summary (pmc_*.json, summary_*.md) was computed from the complete file on the GPU box\n")
+                break
+            fo.write(line)
+
+
 def full_batch(rows, grid_key):
     """keep the full-batch launches only (bench.py's property gate also runs a few tiny ones)."""
     full = collections.defaultdict(int)
@@ -101,7 +114,7 @@ def summarize(indir, workload, outdir):
     md = ["## %s\n" % workload]
     # kernel durations (trace pass)
     shutil.copy(os.path.join(indir, "trace.kernel_stats.csv"), os.path.join(outdir, "kernel_stats_%s.csv" % workload))
-    shutil.copy(os.path.join(indir, "trace.kernel_trace.csv"), os.path.join(outdir, "kernel_trace_%s.csv" % workload))
+    copy_csv(os.path.join(indir, "trace.kernel_trace.csv"), os.path.join(outdir, "kernel_trace_%s.csv" % workload))
     trace = list(csv.DictReader(open(os.path.join(indir, "trace.kernel_trace.csv"))))
     gk = "Grid_Size_X" if "Grid_Size_X" in trace[0] else "Grid_Size"
     dur = collections.defaultdict(list)
@@ -120,12 +133,12 @@ def summarize(indir, workload, outdir):
             if r["Counter_Name"] == cn:
                 dd[r["Kernel_Name"]].append(float(r["Counter_Value"]))
         agg[cn] = {k: sum(v) / len(v) for k, v in dd.items()}
-        shutil.copy(os.path.join(indir, "pmc_%s.counters.csv" % cn), os.path.join(outdir, "pmc_%s_%s.csv" % (cn, workload)))
+        copy_csv(os.path.join(indir, "pmc_%s.counters.csv" % cn), os.path.join(outdir, "pmc_%s_%s.csv" % (cn, workload)))
     sq = collections.defaultdict(lambda: collections.defaultdict(list))
     rows = list(csv.DictReader(open(os.path.join(indir, "pmc_SQ.counters.csv"))))
     for r in full_batch(rows, "Grid_Size"):
         sq[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
-    shutil.copy(os.path.join(indir, "pmc_SQ.counters.csv"), os.path.join(outdir, "pmc_SQ_%s.csv" % workload))
+    copy_csv(os.path.join(indir, "pmc_SQ.counters.csv"), os.path.join(outdir, "pmc_SQ_%s.csv" % workload))
     # a tag's figures come from its full-batch kernels only: the property gate of bench.py also runs 2-tile launches of the
     # forward-only / inverse-only rows kernels, which carry the same tag
     grid = collections.defaultdict(int)
@@ -213,6 +226,9 @@ def readme(outdir):
         if os.path.exists(sp):
             md.append(open(sp).read())
     md.append("## other files\n")
+    md.append("* `kernel_stats_goldilocks_d65536_b16384_one_stream.csv`, `bench_one_stream_under_trace.json` -- the headline workload with `sr_plan.lanes = 1`")
+    md.append("  (one stream, eight large chunks) under `rocprofv3 --kernel-trace --stats`: the kernels' exclusive durations (tools/collect_profiles.sh).")
+    md.append("* raw CSVs are cut to their first 4000 rows (the two-lane plans launch hundreds of chunk kernels per step); summaries were computed on the GPU box from the complete files.")
     md.append("* `bench_default.json` -- plain `python bench.py --steps 10 --warmup 3` (with the CPU baseline leg); `bench_ntt_rhs.json` -- `--variant mul_ntt_rhs`;")
     md.append("  `bench_babybear.json`, `bench_stark.json`, `bench_c4_shard.json` -- the other BASELINE configs; `bench_2rank_gloo.json` -- `python bench.py --gpus 2 --backend gloo --batch 4096`")
     md.append("  (bench.py launching its own two ranks on the one GPU of the box).")
