@@ -100,6 +100,7 @@ def copy_csv(src, dst):
 
 def full_batch(rows, grid_key):
     """keep the full-batch launches only (bench.py's property gate also runs a few tiny ones)."""
+    rows = [r for r in rows if r.get(grid_key) is not None]  # (the marker line of a truncated copy has no columns)
     full = collections.defaultdict(int)
     for r in rows:
         full[r["Kernel_Name"]] = max(full[r["Kernel_Name"]], int(r[grid_key]))
