@@ -1054,8 +1054,25 @@ int dev_ring_mul(sr_ctx *c, uint64_t *out, const uint64_t *a, const uint64_t *b,
 // Goldilocks tuned path fuses them: gl_fast_ring_mul_rhs)
 int dev_ring_mul_ntt_rhs(sr_ctx *c, uint64_t *out, const uint64_t *a, const uint64_t *b_ntt, size_t batch, hipStream_t st) {
     if (batch == 0) return SR_OK;
-    if (c->ring == SR_RING_GOLDILOCKS_POW2 && !c->regtile && c->fast_goldilocks && sr::gl_fast_supported(c->gl_fast) && c->k >= 8)
+    if (c->ring == SR_RING_GOLDILOCKS_POW2 && !c->regtile && c->fast_goldilocks && sr::gl_fast_supported(c->gl_fast) && c->k >= 8) {
+        if (gl_use_lanes(c, batch) && st != c->stream && st != c->out_stream) {  // as dev_ring_mul: chunks on the two lanes
+            const size_t chunk = gl_lane_chunk(c), words = chunk << c->k;
+            if (int rc = ensure_scratch(c, 1, 4 * words * 8)) return rc;
+            if (int rc = gl_lanes_init(c)) return rc;
+            if (int rc = rt_scratch_acquire(c, st)) return rc;
+            sr::GlLanes &L = c->gl_lanes;
+            uint64_t *base = reinterpret_cast<uint64_t *>(c->rt_scratch[0]);
+            L.chunk = chunk;
+            for (int i = 0; i < 2; i++) {
+                L.sa[i] = base + (size_t)(2 * i) * words;
+                L.sb[i] = base + (size_t)(2 * i + 1) * words;
+            }
+            const int rc = sr::gl_fast_ring_mul_rhs_lanes(c->gl_fast, out, a, b_ntt, L, batch, st);
+            if (int r2 = rt_scratch_release(c, st)) return r2;
+            return rc ? fail(SR_E_HIP, "goldilocks fast-path launch failed") : SR_OK;
+        }
         return sr::gl_fast_ring_mul_rhs(c->gl_fast, out, a, b_ntt, batch, st) ? fail(SR_E_HIP, "goldilocks fast-path launch failed") : SR_OK;
+    }
     if (out != a) HIP_TRY(hipMemcpyAsync(out, a, batch * c->degree * c->limbs * 8, hipMemcpyDeviceToDevice, st));
     if (int rc = dev_fwd(c, out, batch, st)) return rc;
     if (int rc = dev_pointwise(c, out, b_ntt, batch, st)) return rc;

@@ -1161,6 +1161,31 @@ inline int gl_fast_ring_mul_lanes(const GoldilocksFastTables &f, uint64_t *out, 
     return rc;
 }
 
+// the constant-operand product (b already in NTT form) on the same lanes: three launches per chunk, one scratch buffer per lane
+inline int gl_fast_ring_mul_rhs_lanes(const GoldilocksFastTables &f, uint64_t *out, const uint64_t *a, const uint64_t *b_ntt, const GlLanes &L,
+                                      size_t batch, hipStream_t st) {
+    if (batch == 0) return 0;
+    if (!f.cols256 || L.n < 1 || L.chunk == 0) return 1;
+    if (hipEventRecord(L.fork, st) != hipSuccess) return 1;
+    for (int i = 0; i < L.n; i++)
+        if (hipStreamWaitEvent(L.st[i], L.fork, 0) != hipSuccess) return 1;
+    const size_t stride = (size_t)1 << f.k;
+    int rc = 0;
+    size_t c = 0;
+    for (size_t e = 0; e < batch && !rc; e += L.chunk, c++) {
+        const int i = (int)(c % (size_t)L.n);
+        const size_t n = batch - e < L.chunk ? batch - e : L.chunk;
+        rc = gl_launch_cols256<0>(f, L.sa[i], a + e * stride, n, f.t.wcf, f.t.twist_f, L.st[i]);
+        if (!rc) rc = gl_launch_rows<3>(f, L.sa[i], b_ntt + e * stride, L.sa[i], n, true, L.st[i]);
+        if (!rc) rc = gl_launch_cols256<1>(f, out + e * stride, L.sa[i], n, f.t.wci, f.t.twist_i_mul, L.st[i]);
+    }
+    for (int i = 0; i < L.n; i++) {
+        if (hipEventRecord(L.join[i], L.st[i]) != hipSuccess) rc = 1;
+        if (hipStreamWaitEvent(st, L.join[i], 0) != hipSuccess) rc = 1;
+    }
+    return rc;
+}
+
 // out = icrt(crt(a) (.) b_ntt), b_ntt = crt(b) as sr_ntt_fwd leaves it: a's column stages go straight to out, the rows kernel
 // transforms a's tile only and reads b's slots in NTT order, the inverse column stages finish in place.  No scratch.
 inline int gl_fast_ring_mul_rhs(const GoldilocksFastTables &f, uint64_t *out, const uint64_t *a, const uint64_t *b_ntt, size_t batch,
