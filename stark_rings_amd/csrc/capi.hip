@@ -938,6 +938,11 @@ int dev_fwd(sr_ctx *c, uint64_t *d, size_t batch, hipStream_t st) {
         return rt_fwd<sr::Goldilocks>(c, d, batch, st);
     }
     if (c->ring == SR_RING_GOLDILOCKS_POW2 && c->fast_goldilocks && sr::gl_fast_supported(c->gl_fast)) {
+        if (gl_use_lanes(c, batch) && st != c->stream && st != c->out_stream) {  // chunks on the two lanes, in place (no scratch)
+            if (int rc = gl_lanes_init(c)) return rc;
+            c->gl_lanes.chunk = gl_lane_chunk(c);
+            return sr::gl_fast_transform_lanes<0>(c->gl_fast, d, c->gl_lanes, batch, st) ? fail(SR_E_HIP, "goldilocks fast-path launch failed") : SR_OK;
+        }
         return sr::gl_fast_fwd(c->gl_fast, d, batch, st) ? fail(SR_E_HIP, "goldilocks fast-path launch failed") : SR_OK;
     }
     if (c->stark_tuned) return st_fwd(c, d, batch, st);
@@ -953,6 +958,11 @@ int dev_inv(sr_ctx *c, uint64_t *d, size_t batch, hipStream_t st) {
         return rt_inv<sr::Goldilocks>(c, d, batch, st);
     }
     if (c->ring == SR_RING_GOLDILOCKS_POW2 && c->fast_goldilocks && sr::gl_fast_supported(c->gl_fast)) {
+        if (gl_use_lanes(c, batch) && st != c->stream && st != c->out_stream) {
+            if (int rc = gl_lanes_init(c)) return rc;
+            c->gl_lanes.chunk = gl_lane_chunk(c);
+            return sr::gl_fast_transform_lanes<1>(c->gl_fast, d, c->gl_lanes, batch, st) ? fail(SR_E_HIP, "goldilocks fast-path launch failed") : SR_OK;
+        }
         return sr::gl_fast_inv(c->gl_fast, d, batch, st) ? fail(SR_E_HIP, "goldilocks fast-path launch failed") : SR_OK;
     }
     if (c->stark_tuned) return st_inv(c, d, batch, st);

@@ -1161,6 +1161,37 @@ inline int gl_fast_ring_mul_lanes(const GoldilocksFastTables &f, uint64_t *out, 
     return rc;
 }
 
+// the stand-alone transforms (elementwise_crt / elementwise_icrt) in the same chunks on the same lanes: in place, no scratch; the chunk
+// written by the first launch is re-read by the second from the Infinity Cache
+template <int DIR>
+inline int gl_fast_transform_lanes(const GoldilocksFastTables &f, uint64_t *d, const GlLanes &L, size_t batch, hipStream_t st) {
+    if (batch == 0) return 0;
+    if (!f.cols256 || L.n < 1 || L.chunk == 0) return 1;
+    if (hipEventRecord(L.fork, st) != hipSuccess) return 1;
+    for (int i = 0; i < L.n; i++)
+        if (hipStreamWaitEvent(L.st[i], L.fork, 0) != hipSuccess) return 1;
+    const size_t stride = (size_t)1 << f.k;
+    int rc = 0;
+    size_t c = 0;
+    for (size_t e = 0; e < batch && !rc; e += L.chunk, c++) {
+        const int i = (int)(c % (size_t)L.n);
+        const size_t n = batch - e < L.chunk ? batch - e : L.chunk;
+        uint64_t *dc = d + e * stride;
+        if (DIR == 0) {
+            rc = gl_launch_cols256<0>(f, dc, dc, n, f.t.wcf, f.t.twist_f, L.st[i]);
+            if (!rc) rc = gl_launch_rows<0>(f, dc, nullptr, dc, n, false, L.st[i]);
+        } else {
+            rc = gl_launch_rows<1>(f, dc, nullptr, dc, n, false, L.st[i]);
+            if (!rc) rc = gl_launch_cols256<1>(f, dc, dc, n, f.t.wci, f.t.twist_i_plain, L.st[i]);
+        }
+    }
+    for (int i = 0; i < L.n; i++) {
+        if (hipEventRecord(L.join[i], L.st[i]) != hipSuccess) rc = 1;
+        if (hipStreamWaitEvent(st, L.join[i], 0) != hipSuccess) rc = 1;
+    }
+    return rc;
+}
+
 // the constant-operand product (b already in NTT form) on the same lanes: three launches per chunk, one scratch buffer per lane
 inline int gl_fast_ring_mul_rhs_lanes(const GoldilocksFastTables &f, uint64_t *out, const uint64_t *a, const uint64_t *b_ntt, const GlLanes &L,
                                       size_t batch, hipStream_t st) {

@@ -1519,6 +1519,15 @@ def test_goldilocks_product_on_two_lanes(torch_cuda, k, batch, plan_kw):
     ring.mul_dev(out, tb, tb)  # squaring (a and b the same buffer)
     torch.cuda.synchronize()
     assert np.array_equal(out.cpu().numpy().view(np.uint64), O.pow2_ring_mul(F, b, b, k, batch, 8))
+    # the stand-alone transforms take the same lanes (in place, two launches per chunk)
+    tt = torch.from_numpy(a.view(np.int64)).cuda()
+    ring.elementwise_crt_dev(tt)
+    torch.cuda.synchronize()
+    assert np.array_equal(tt.cpu().numpy().view(np.uint64), O.pow2_fwd(F, a, k, batch, 8))
+    ring.elementwise_icrt_dev(tt)
+    torch.cuda.synchronize()
+    assert np.array_equal(tt.cpu().numpy().view(np.uint64), a)
+    del tt
     # the constant-operand product takes the same lanes (three launches per chunk)
     ta = torch.from_numpy(a.view(np.int64)).cuda()
     tbn = tb.clone()
