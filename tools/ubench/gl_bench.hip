@@ -138,8 +138,12 @@ int main(int argc, char **argv) {
 #else
                 u64 *ia = ssa[si];
 #endif
+#ifdef PAIR
+                hipLaunchKernelGGL(cols256_pair_kernel, dim3(2 * cb), dim3(256), 0, st[si], ia, ac, ssb[si], bc, k, T.wcf, T.twist_f, cb, grp);
+#else
                 hipLaunchKernelGGL((cols256_kernel<0, LCV>), dim3(cb), dim3(16 << LCV), 0, st[si], ia, ac, k, T.wcf, T.twist_f, grp);
                 hipLaunchKernelGGL((cols256_kernel<0, LCV>), dim3(cb), dim3(16 << LCV), 0, st[si], ssb[si], bc, k, T.wcf, T.twist_f, grp);
+#endif
                 hipLaunchKernelGGL((rows256_kernel<2>), dim3((unsigned)(np << (k - 12))), dim3(256), 0, st[si], ia, ssb[si], ia, T);
                 hipLaunchKernelGGL((cols256_kernel<1, LCV>), dim3(cb), dim3(16 << LCV), 0, st[si], ac, ia, k, T.wci, T.twist_i_mul, grp);
             }
