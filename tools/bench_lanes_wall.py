@@ -10,6 +10,6 @@ ring.reserve_scratch(batch)
 for _ in range(3): ring.mul_dev(a, a, b)
 torch.cuda.synchronize()
 t0 = time.perf_counter()
-for _ in range(10): ring.mul_dev(a, a, b)
+for _ in range(int(os.environ.get("SR_STEPS", "10"))): ring.mul_dev(a, a, b)
 torch.cuda.synchronize()
-print("SR_LANES=%s: %.3f ms per batch" % (os.environ.get("SR_LANES", "default"), (time.perf_counter() - t0) * 100))
+print("SR_LANES=%s: %.3f ms per batch" % (os.environ.get("SR_LANES", "default"), (time.perf_counter() - t0) * 1e3 / int(os.environ.get("SR_STEPS", "10"))))
