@@ -99,3 +99,30 @@ def test_bench_launches_its_own_ranks_and_checks_every_shard():
     assert d["multi_gpu"]["twiddle_broadcast_bytes"] > 0
     assert "6 sampled elements per rank (2 ranks)" in d["parity"]
     assert d["value"] > 0
+
+
+@pytest.mark.gpu
+def test_bench_single_rank_probes_the_plan_and_reports_the_overlap():
+    """`python bench.py` on a batch of several chunks: the untimed probe chooses between the two-lane and the one-stream plan (config.plan says
+    which), the sampled elements are bit-exact against the oracle, and when the lanes are in use the line carries the overlap note and the
+    labelled one-stream calibration next to the live roofline figures."""
+    import json
+    import subprocess
+
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "SR_LANES")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--batch", "600", "--steps", "3", "--warmup", "1", "--parity-sample", "5",
+           "--cpu-seconds", "0.5"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["config"]["global_batch"] == 600
+    assert "5 sampled elements per rank" in d["parity"]
+    plan = d["config"]["plan"]
+    assert plan.startswith("two lanes") or plan.startswith("one stream")
+    roof = d["roofline"]
+    assert 0 < roof["frac"] < 1 and 0 < roof["whole_step_frac"] < 1
+    if plan.startswith("two lanes"):
+        assert roof["overlap"]["internal_streams"] == 2 and roof["overlap"]["factor"] > 1.2
+        assert roof["single_stream"]["frac"] > roof["frac"]  # the same kernel alone is faster per launch than beside the other lane
