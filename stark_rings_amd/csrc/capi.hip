@@ -602,9 +602,43 @@ int rt_scratch_release(sr_ctx *c, hipStream_t st) {
     c->rt_scratch_used = true;
     return SR_OK;
 }
+template <class F> size_t rt_lane_chunk(const sr_ctx *c);
+template <class F> bool rt_use_lanes(const sr_ctx *c, size_t batch, hipStream_t st);
+int gl_lanes_init(sr_ctx *c);
+// stand-alone transform in chunks on the context's two streams, each lane with its own packed scratch (the two-lane plan of
+// rt_ring_mul below; the scratch has the product's size, so one allocation serves both)
+template <class F, int DIR>
+int rt_transform_lanes(sr_ctx *c, uint64_t *d, size_t batch, hipStream_t st) {
+    using E = typename F::elem;
+    using S = typename F::storage;
+    const size_t chunk = rt_lane_chunk<F>(c), words = chunk << c->k;
+    if (int rc = ensure_scratch(c, 1, 4 * words * sizeof(E))) return rc;
+    if (int rc = gl_lanes_init(c)) return rc;
+    if (int rc = rt_scratch_acquire(c, st)) return rc;
+    sr::GlLanes &L = c->gl_lanes;
+    E *base = reinterpret_cast<E *>(c->rt_scratch[0]);
+    HIP_TRY(hipEventRecord(L.fork, st));
+    for (int i = 0; i < 2; i++) HIP_TRY(hipStreamWaitEvent(L.st[i], L.fork, 0));
+    int rc = 0;
+    size_t ci = 0;
+    for (size_t e = 0; e < batch && !rc; e += chunk, ci++) {
+        const int i = (int)(ci & 1);
+        const size_t n = batch - e < chunk ? batch - e : chunk;
+        S *dc = reinterpret_cast<S *>(d) + (e << c->k);
+        rc = DIR == 0 ? sr::rt::fwd<F>(c->rt_hooks, dc, n, make_rt_params<F>(c, false), base + (size_t)(2 * i) * words, L.st[i])
+                      : sr::rt::inv<F>(c->rt_hooks, dc, n, make_rt_params<F>(c, false), base + (size_t)(2 * i) * words, L.st[i]);
+    }
+    for (int i = 0; i < 2; i++) {  // join even after a failed launch
+        if (hipEventRecord(L.join[i], L.st[i]) != hipSuccess) rc = 1;
+        if (hipStreamWaitEvent(st, L.join[i], 0) != hipSuccess) rc = 1;
+    }
+    if (int r2 = rt_scratch_release(c, st)) return r2;
+    return rc ? fail(SR_E_HIP, "register-tiled launch failed") : SR_OK;
+}
 template <class F>
 int rt_fwd(sr_ctx *c, uint64_t *d, size_t batch, hipStream_t st) {
     using E = typename F::elem;
+    if (rt_use_lanes<F>(c, batch, st)) return rt_transform_lanes<F, 0>(c, d, batch, st);
     if (int rc = rt_ensure_scratch(c, 1, (batch << c->k) * sizeof(E))) return rc;
     if (int rc = rt_scratch_acquire(c, st)) return rc;
     if (sr::rt::fwd<F>(c->rt_hooks, reinterpret_cast<typename F::storage *>(d), batch, make_rt_params<F>(c, false),
@@ -615,6 +649,7 @@ int rt_fwd(sr_ctx *c, uint64_t *d, size_t batch, hipStream_t st) {
 template <class F>
 int rt_inv(sr_ctx *c, uint64_t *d, size_t batch, hipStream_t st) {
     using E = typename F::elem;
+    if (rt_use_lanes<F>(c, batch, st)) return rt_transform_lanes<F, 1>(c, d, batch, st);
     if (int rc = rt_ensure_scratch(c, 1, (batch << c->k) * sizeof(E))) return rc;
     if (int rc = rt_scratch_acquire(c, st)) return rc;
     if (sr::rt::inv<F>(c->rt_hooks, reinterpret_cast<typename F::storage *>(d), batch, make_rt_params<F>(c, false),

@@ -1572,6 +1572,14 @@ def test_register_tiled_product_on_two_lanes(torch_cuda, name, k, batch, plan_kw
     ring.mul_dev(ta, ta, tb)
     torch.cuda.synchronize()
     assert np.array_equal(ta.cpu().numpy().view(np.uint64), want)
+    # the stand-alone transforms take the same lanes (a packed scratch buffer per lane)
+    tt = torch.from_numpy(a.view(np.int64)).cuda()
+    ring.elementwise_crt_dev(tt)
+    torch.cuda.synchronize()
+    assert np.array_equal(tt.cpu().numpy().view(np.uint64), O.pow2_fwd(F, a, k, batch, 8))
+    ring.elementwise_icrt_dev(tt)
+    torch.cuda.synchronize()
+    assert np.array_equal(tt.cpu().numpy().view(np.uint64), a)
     ring.close()
 
 
