@@ -109,7 +109,7 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="override the per-GPU batch (debug only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-calibration", action="store_true",
-                    help="skip the one-stream calibration after the timed region (profile runs: only the timed configuration's launches)")
+                    help="skip the untimed plan probe and the one-stream calibration (profile runs: only the timed configuration's launches)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo for rehearsals)")
     ap.add_argument("--variant", default="mul", choices=("mul", "mul_ntt_rhs"),
@@ -187,7 +187,8 @@ def main():
     # end up with both on one queue, and then the one-stream plan is the faster one).  Two untimed steps of each plan decide which
     # context the timed region uses; the choice is reported in config.plan.
     plan_used = "default"
-    if args.variant == "mul" and k > 12 and ring_name in ("goldilocks", "babybear") and not os.environ.get("SR_LANES"):
+    if (args.variant == "mul" and k > 12 and ring_name in ("goldilocks", "babybear") and not os.environ.get("SR_LANES")
+            and not args.no_calibration):  # profile runs carry the timed configuration's launches only
         from stark_rings_amd._lib import plan_from_env
 
         def two_steps(r):
