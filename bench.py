@@ -12,6 +12,10 @@ synthetic coefficient vectors already resident in HBM.  Default workload = BASEL
 Goldilocks, D = 2^16, batch = 2^14 per GPU (weak scaling: the batch shards by element, no data-path
 collective; the only collective is one RCCL broadcast of the twiddle block at start-up).
 
+  python bench.py --force-dist     N = 1 with the multi-GPU code path switched on: a ONE-rank `nccl` (RCCL) process group, the twiddle
+      broadcast on the device view, the rank count and the parity all-reduce on device tensors -- the path the 8-GPU run takes,
+      executed on the one GPU at hand.
+
 Prints ONE JSON line on rank 0 (contract in the task description) with `roofline` (dominant kernel, HIP
 events on the launch stream) and `cpu_baseline` (the oracle -- a C restatement of the reference's CPU
 path -- timed on this host's cores over a bounded sample; rank 0, N = 1 only).
@@ -37,6 +41,7 @@ WORKLOADS = {
     "goldilocks_d65536_b16384": ("goldilocks", 16, 1 << 14, 8),   # BASELINE configs[1] (metric config)
     "babybear_d65536_b16384": ("babybear", 16, 1 << 14, 8),       # configs[2], reference 8-byte layout
     "goldilocks_d1048576_b8192": ("goldilocks", 20, 1 << 13, 8),  # configs[3] per-GPU shard (2^16 / 8)
+    "babybear_d65536_b16384_packed": ("babybear", 16, 1 << 14, 4),  # configs[2] on the opt-in packed-u32 boundary (w = 4)
     "stark_d4096_b4096": ("stark", 12, 1 << 12, 32),              # configs[4]
     "goldilocks_d1024_b1": ("goldilocks", 10, 1, 8),              # configs[0] plumbing
     "goldilocks_d1024_b1048576": ("goldilocks", 10, 1 << 20, 8),  # configs[0]'s degree at a GPU-sized batch (informational)
@@ -108,8 +113,15 @@ def main():
     ap.add_argument("--workload", default="goldilocks_d65536_b16384", choices=sorted(WORKLOADS))
     ap.add_argument("--batch", type=int, default=0, help="override the per-GPU batch (debug only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-calibration", action="store_true",
-                    help="skip the untimed plan probe and the one-stream calibration (profile runs: only the timed configuration's launches)")
+    ap.add_argument("--calibrate", action="store_true",
+                    help="after the timed region, also time the one-stream plan (sr_plan.lanes = 1) on a second context and report it as "
+                         "roofline.single_stream -- context only, never the headline (off by default: profile runs and the driver's run "
+                         "carry the timed configuration's launches only)")
+    ap.add_argument("--no-calibration", action="store_true", help="(accepted for older scripts; calibration is off unless --calibrate)")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise the process group and run every collective of the N > 1 path even at N = 1 (a one-rank nccl group)")
+    ap.add_argument("--lanes", type=int, default=0, choices=(0, 1, 2),
+                    help="sr_plan.lanes: 0 = the library's own choice (default), 1 = one stream, 2 = two lanes (A/B runs)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo for rehearsals)")
     ap.add_argument("--variant", default="mul", choices=("mul", "mul_ntt_rhs"),
@@ -136,8 +148,16 @@ def main():
     dev_index = local_rank % ndev  # one rank per GPU on a full node; a 1-GPU rehearsal folds ranks onto device 0
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
-    if world > 1:
+    dist_on = world > 1 or args.force_dist
+    if dist_on:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if "MASTER_PORT" not in os.environ:  # --force-dist outside torchrun: a one-rank rendezvous on a free local port
+            import socket
+
+            sk = socket.socket()
+            sk.bind(("127.0.0.1", 0))
+            os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
+            sk.close()
         if args.backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
@@ -147,28 +167,51 @@ def main():
     if args.batch:
         batch = args.batch
     d = 1 << k
-    ring = CyclotomicRing(ring_name, k, device=dev_index)
+    from stark_rings_amd._lib import plan_from_env
+
+    plan = plan_from_env({"goldilocks": 0, "babybear": 1, "stark": 2}[ring_name])
+    if args.lanes:
+        plan.lanes = args.lanes
+    ring = CyclotomicRing(ring_name, k, device=dev_index, plan=plan)
     words = batch * ring.words_per_elem
+    packed = args.workload.endswith("_packed")  # operands and results are uint32 words (low half of the reference's Fp64 limb)
+    if packed and args.variant != "mul":
+        raise SystemExit("--variant %s has no packed form" % args.variant)
 
     # ---- shared twiddles: rank 0's tables broadcast once over RCCL/xGMI, adopted by every rank ----
     bcast_bytes = bcast_ms = ranks_seen = None
-    if world > 1:
+    if dist_on:
         from stark_rings_amd.sharding import share_twiddles
 
         t_b = time.perf_counter()
         bcast_bytes = share_twiddles(ring, dev)  # non-zero ranks zero their block first: the tables really come from rank 0
         bcast_ms = (time.perf_counter() - t_b) * 1e3
-        seen = torch.ones(1, dtype=torch.int64, device=dev if args.backend == "nccl" else "cpu")
+        seen = torch.ones(1, dtype=torch.int64, device=dev if args.backend == "nccl" else "cpu")  # a DEVICE tensor under RCCL
         dist.all_reduce(seen)  # every rank counted once: the process group really spans `world` ranks
         ranks_seen = int(seen.item())
 
     # ---- synthetic inputs generated on device (counter-based PRNG; rank-disjoint coefficient ranges) ----
-    a = torch.empty(words, dtype=torch.int64, device=dev)
-    b = torch.empty(words, dtype=torch.int64, device=dev)
     first = rank * batch * d
-    ring.fill_uniform_dev(a, 0x5EED0001, first)
-    ring.fill_uniform_dev(b, 0x5EED0002, first)
-    torch.cuda.synchronize()
+    if packed:
+        a = torch.empty(words, dtype=torch.int32, device=dev)
+        b = torch.empty(words, dtype=torch.int32, device=dev)
+        wide = torch.empty(words, dtype=torch.int64, device=dev)  # generator output in the reference layout, narrowed by the library
+        for t32, seed in ((a, 0x5EED0001), (b, 0x5EED0002)):
+            ring.fill_uniform_dev(wide, seed, first)
+            ring.pack32_dev(t32, wide)
+        torch.cuda.synchronize()
+        del wide
+
+        mul_fn, crt_fn, icrt_fn, add_fn = ring.mul_packed32_dev, ring.elementwise_crt_packed32_dev, ring.elementwise_icrt_packed32_dev, ring.add_packed32_dev
+        noncanonical = lambda t: int(((t < 0) | (t >= ring.modulus)).sum().item())
+    else:
+        a = torch.empty(words, dtype=torch.int64, device=dev)
+        b = torch.empty(words, dtype=torch.int64, device=dev)
+        ring.fill_uniform_dev(a, 0x5EED0001, first)
+        ring.fill_uniform_dev(b, 0x5EED0002, first)
+        torch.cuda.synchronize()
+        mul_fn, crt_fn, icrt_fn, add_fn = ring.mul_dev, ring.elementwise_crt_dev, ring.elementwise_icrt_dev, ring.add_dev
+        noncanonical = ring.count_noncanonical_dev
 
     # ---- property gate (no oracle here: the oracle is only used inside the cpu_baseline leg below): one untimed step,
     #      outputs canonical, icrt(crt(c)) == c on the result, sampled outputs kept for the cpu_baseline leg's bit-exact check
@@ -178,68 +221,37 @@ def main():
         ring.elementwise_crt_dev(b_ntt)   # once, outside every timed region: the constant operand lives in NTT form
         step = lambda: ring.mul_ntt_rhs_dev(a, a, b_ntt)
     else:
-        step = lambda: ring.mul_dev(a, a, b)
+        step = lambda: mul_fn(a, a, b)
     ring.reserve_scratch(batch)           # no _dev call blocks after this
     step()
     torch.cuda.synchronize()
-    # Plan check before anything is timed: the default plan runs the product on two internal streams, which only pays when the HIP
-    # runtime gives them a hardware queue each (a process that holds many streams -- RCCL's, a framework's -- can
-    # end up with both on one queue, and then the one-stream plan is the faster one).  Two untimed steps of each plan decide which
-    # context the timed region uses; the choice is reported in config.plan.
-    plan_used = "default"
-    if (args.variant == "mul" and k > 12 and ring_name in ("goldilocks", "babybear") and not os.environ.get("SR_LANES")
-            and not args.no_calibration):  # profile runs carry the timed configuration's launches only
-        from stark_rings_amd._lib import plan_from_env
-
-        def two_steps(r):
-            r.mul_dev(a, a, b)
-            torch.cuda.synchronize()
-            t = time.perf_counter()
-            r.mul_dev(a, a, b)
-            r.mul_dev(a, a, b)
-            torch.cuda.synchronize()
-            return (time.perf_counter() - t) / 2
-
-        plan1 = plan_from_env()
-        plan1.lanes = 1
-        ring_one = CyclotomicRing(ring_name, k, device=dev_index, plan=plan1)
-        if world > 1:  # the tables every rank computes with come from rank 0: hand this context the block `ring` adopted
-            from stark_rings_amd.sharding import DeviceBytes
-
-            (p0, n0), (p1, n1) = ring.twiddle_block(), ring_one.twiddle_block()
-            assert n0 == n1
-            torch.as_tensor(DeviceBytes(p1, n1), device=dev).copy_(torch.as_tensor(DeviceBytes(p0, n0), device=dev))
-            torch.cuda.synchronize()
-            ring_one.twiddles_updated()
-        ring_one.reserve_scratch(batch)
-        t_two, t_one = two_steps(ring), two_steps(ring_one)
-        plan_used = "two lanes (default): %.2f ms per step against %.2f ms on one stream, untimed probe" % (t_two * 1e3, t_one * 1e3)
-        if t_one < 0.97 * t_two:
-            plan_used = "one stream (sr_plan.lanes = 1): %.2f ms per step against %.2f ms on two lanes, untimed probe" % (t_one * 1e3, t_two * 1e3)
-            ring.close()
-            ring = ring_one
-            step = lambda: ring.mul_dev(a, a, b)
-        else:
-            ring_one.close()
-        # a and b went through six more products: start the checked first step from fresh inputs
-        ring.fill_uniform_dev(a, 0x5EED0001, first)
-        step()
-        torch.cuda.synchronize()
-    assert ring.count_noncanonical_dev(a) == 0, "non-canonical outputs"
+    # Which plan runs is the LIBRARY's decision (sr_plan.lanes = 0: it timed two lanes against one stream inside reserve_scratch, on this
+    # process's real stream-to-queue mapping, and kept the winner); bench.py only reports it.
+    plan_now, probe = ring.plan_in_use()
+    lanes_now = int(plan_now.lanes)
+    if args.lanes:
+        plan_used = "sr_plan.lanes = %d given on the command line (A/B run)" % args.lanes
+    elif probe:
+        plan_used = ("library default (sr_plan.lanes = 0, auto): %s -- its probe took %.2f ms on two lanes against %.2f ms on one stream for %d ring products"
+                     % ("two lanes" if lanes_now == 2 else "one stream", probe["two_lanes_ms"], probe["one_stream_ms"], probe["elems"]))
+    else:
+        plan_used = "library default (no chunked plan applies to this ring / degree / batch)"
+    assert noncanonical(a) == 0, "non-canonical outputs"
     n_sample = args.parity_sample if args.parity_sample >= 0 else (64 if k >= 20 else 3)
     n_sample = min(n_sample, batch)
     sample = sorted({(i * (batch - 1)) // max(n_sample - 1, 1) for i in range(n_sample)}) if n_sample else []
-    sample_out = {e: a[e * wpe:(e + 1) * wpe].cpu().numpy().view(np.uint64).copy() for e in sample}
+    as_u64 = (lambda t: t.cpu().numpy().view(np.uint32).astype(np.uint64)) if packed else (lambda t: t.cpu().numpy().view(np.uint64).copy())
+    sample_out = {e: as_u64(a[e * wpe:(e + 1) * wpe]) for e in sample}
     rt = a[:min(batch, 8) * wpe].clone()
-    ring.elementwise_crt_dev(rt)
-    ring.elementwise_icrt_dev(rt)
+    crt_fn(rt)
+    icrt_fn(rt)
     if not torch.equal(rt, a[:rt.numel()]):
         raise SystemExit("PROPERTY FAILURE rank %d: icrt(crt(c)) != c" % rank)
     del rt
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if dist_on:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -251,9 +263,14 @@ def main():
         step()
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    rank_ms = None
+    if dist_on:  # max over ranks is the job's time; min next to it makes a straggler visible
+        cdev = dev if args.backend == "nccl" else "cpu"
+        t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
+        tmin = t.clone()
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tmin, op=dist.ReduceOp.MIN)
+        rank_ms = {"min": float(tmin.item()) / args.steps * 1e3, "max": float(t.item()) / args.steps * 1e3}
         elapsed = float(t.item())
 
     # ---- per-kernel durations over the same K steps, HIP events on the launch stream ----
@@ -269,9 +286,7 @@ def main():
     # a calibration outside the timed region, reported separately as roofline.single_stream, never as the headline.
     prof_single = single_ms = None
     in_flight = sum(v["ms"] for v in prof.values() if v["launches"]) / args.steps
-    if rank == 0 and args.variant == "mul" and not args.no_calibration and in_flight > 1.2 * (elapsed / args.steps * 1e3):
-        from stark_rings_amd._lib import plan_from_env
-
+    if rank == 0 and args.variant == "mul" and args.calibrate and not packed and in_flight > 1.2 * (elapsed / args.steps * 1e3):
         plan1 = plan_from_env()
         plan1.lanes = 1
         ring1 = CyclotomicRing(ring_name, k, device=dev_index, plan=plan1)
@@ -293,11 +308,11 @@ def main():
         ring1.close()
     # the timed steps kept multiplying a by the (unchanged) b: the final state must still be a batch of canonical ring elements
     # whose transform round-trips -- outputs after the warm-up are checked, not only the first step
-    if ring.count_noncanonical_dev(a) != 0:
+    if noncanonical(a) != 0:
         raise SystemExit("PROPERTY FAILURE rank %d: non-canonical outputs after the timed steps" % rank)
     rt = a[-min(batch, 8) * wpe:].clone()
-    ring.elementwise_crt_dev(rt)
-    ring.elementwise_icrt_dev(rt)
+    crt_fn(rt)
+    icrt_fn(rt)
     if not torch.equal(rt, a[-rt.numel():]):
         raise SystemExit("PROPERTY FAILURE rank %d: icrt(crt(c)) != c after the timed steps" % rank)
     del rt
@@ -318,9 +333,9 @@ def main():
             torch.cuda.synchronize()
             return 4 * nbytes / (ev0.elapsed_time(ev1) * 1e-3) / 1e9
 
-        nb = a.numel() * 8
+        nb = a.numel() * a.element_size()
         rates = {"hipMemcpy device-to-device (1 read + 1 write stream)": stream_rate(lambda: b.copy_(a), 2 * nb),
-                 "element-wise ring add a += b (2 read + 1 write streams)": stream_rate(lambda: ring.add_dev(b, a), 3 * nb)}
+                 "element-wise ring add a += b (2 read + 1 write streams)": stream_rate(lambda: add_fn(b, a), 3 * nb)}
         copy_kind = max(rates, key=rates.get)
         copy_gbs = rates[copy_kind]
 
@@ -336,8 +351,8 @@ def main():
         eb = np.concatenate([O.fill_uniform(F, 0x5EED0002, first + e * d, d) for e in sample])
         want = O.pow2_ring_mul(F, ea, eb, k, len(sample), threads)
         bad = [e for i, e in enumerate(sample) if not np.array_equal(sample_out[e], want[i * wpe:(i + 1) * wpe])]
-        ok = torch.tensor([0 if bad else 1], dtype=torch.int64, device=dev if (world > 1 and args.backend == "nccl") else "cpu")
-        if world > 1:
+        ok = torch.tensor([0 if bad else 1], dtype=torch.int64, device=dev if (dist_on and args.backend == "nccl") else "cpu")
+        if dist_on:
             dist.all_reduce(ok, op=dist.ReduceOp.MIN)
         if bad:
             print("PARITY FAILURE rank %d: elements %s differ from the oracle" % (rank, bad[:8]), file=sys.stderr)
@@ -348,7 +363,7 @@ def main():
         del ea, eb, want
 
     if rank != 0:
-        if world > 1:
+        if dist_on:
             dist.destroy_process_group()
         return
 
@@ -371,7 +386,7 @@ def main():
     if dom_tag == "rows":
         kernel_bytes_per_elem = 3 * d * wk
     elif ring_name == "babybear":
-        kernel_bytes_per_elem = d * (coeff_bytes + wk)
+        kernel_bytes_per_elem = d * (coeff_bytes + wk)  # (packed boundary: 4 + 4)
     else:
         kernel_bytes_per_elem = 2 * d * wk
     if k <= 12 and ring_name != "stark" or launches_per_step == 0:
@@ -394,8 +409,15 @@ def main():
                 break
         pj = json.load(open(pj_path))
         here = source_hash()
+        lps_now = {t: kern[t]["launches"] / args.steps for t in kern}
+        lps_then = pj.get("launches_per_step")
         if pj.get("batch") != batch:
             traffic_source = "dropped: %s was collected at batch %s" % (os.path.relpath(pj_path, ROOT), pj.get("batch"))
+        elif lps_then is None or any(abs(lps_then.get(t, -1) - v) > 1e-6 for t, v in lps_now.items()):
+            # per-launch bytes and waves only mean something for launches of the same size: another plan (one stream against two
+            # lanes, another chunk) cuts the batch into other launches
+            traffic_source = "dropped (other plan): %s was collected with %s launches per step, this run has %s" % (
+                os.path.relpath(pj_path, ROOT), lps_then, lps_now)
         elif pj.get("source_sha256") != here:
             traffic_source = "dropped (stale): %s was collected at source hash %s, this build is %s" % (
                 os.path.relpath(pj_path, ROOT), pj.get("source_sha256"), here)
@@ -431,7 +453,9 @@ def main():
         "dtype": {"goldilocks": "u64", "babybear": "u32", "stark": "u256"}[ring_name],
         "data": "synthetic",
         "config": {"workload": args.workload, "ring": ring_name, "degree": d, "batch_per_gpu": batch,
-                   "global_batch": batch * world, "layout": "ark-ff Montgomery u64 limbs, in place (a *= b), b read-only",
+                   "global_batch": batch * world,
+                   "layout": ("packed uint32 = low half of the ark-ff Fp64 Montgomery limb (opt-in sr_*_packed32_* entry points), in place (a *= b), b read-only"
+                              if packed else "ark-ff Montgomery u64 limbs, in place (a *= b), b read-only"),
                    "variant": args.variant, "plan": plan_used,
                    "parallelism": "batch-sharded x%d, twiddle broadcast only" % world},
         "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -439,6 +463,7 @@ def main():
                      "copy_measured": copy_gbs, "copy_measured_kind": copy_kind,
                      "frac_of_copy_measured": achieved_gbs / copy_gbs if copy_gbs else None,
                      "kernel": dom_tag, "kernel_avg_ms": dom_avg_ms, "launches_per_step": launches_per_step,
+                     "launches_per_step_by_kernel": {t: v["launches"] / args.steps for t, v in kern.items()},
                      "algorithmic_bytes_per_ring_mul": bytes_per_mul,
                      "dominant_kernel_bytes_per_ring_mul": kernel_bytes_per_elem,
                      "whole_step_achieved_per_gpu": step_gbs, "whole_step_frac": step_gbs / HBM_PEAK_GBS,
@@ -470,10 +495,12 @@ def main():
         out["integer_valu"] = valu
     if parity:
         out["parity"] = parity
-    if world > 1:
+    if dist_on:
         out["multi_gpu"] = {"backend": args.backend + (" (RCCL)" if args.backend == "nccl" else ""), "ranks_seen": ranks_seen,
                             "devices_visible": ndev, "twiddle_broadcast_bytes": bcast_bytes, "twiddle_broadcast_ms": bcast_ms,
-                            "data_path_collectives": 0}
+                            "data_path_collectives": 0, "rank_ms_per_step": rank_ms,
+                            "collectives_run": ["broadcast(twiddle block, device view)", "all_reduce(rank count)",
+                                                "all_reduce(step time: max, min)"] + (["all_reduce(parity: min)"] if parity else [])}
 
     if world == 1 and not args.no_cpu_baseline:
         import oracle_lib as O  # the timed CPU baseline (the parity check above used it as the checker)
@@ -513,7 +540,7 @@ def main():
         out["cpu_baseline"]["schoolbook"] = {"degree": ds, "seconds_per_product": sb,
                                              "ring_muls_per_s_scaled_to_workload_degree": 1.0 / (sb * (d / ds) ** 2)}
     print(json.dumps(out))
-    if world > 1:
+    if dist_on:
         dist.destroy_process_group()
 
 

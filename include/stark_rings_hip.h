@@ -90,9 +90,12 @@ typedef struct sr_plan {
                                      as the operand scratch holds; the tuned Goldilocks path: see lanes)                       */
     uint64_t scratch_limit_bytes; /* cap of the operand scratch (0 = default 16 GiB); larger batches run in chunks             */
     uint32_t host_chunk_mb;       /* chunk of the host-pointer pipeline in MiB (0 = default 128)                               */
-    uint32_t lanes;               /* tuned Goldilocks product, 2^16 <= D <= 2^20: 0 = default (two internal streams, chunks of
-                                     chunk_polys or 64 MiB of coefficients each, intermediates in per-lane scratch so that they are
-                                     re-read from the Infinity Cache), 1 = one stream (eight large chunks, or chunk_polys)       */
+    uint32_t lanes;               /* chunked products (tuned Goldilocks 2^16 <= D <= 2^20, register-tiled BabyBear): 0 = AUTO -- the
+                                     library times both plans once on this process's real stream-to-hardware-queue mapping (inside
+                                     sr_ctx_reserve_scratch, or the first product large enough to be chunked) and keeps the winner;
+                                     2 = two internal streams ("lanes"), chunks of chunk_polys or 64 MiB of coefficients each,
+                                     intermediates in per-lane scratch so that they are re-read from the Infinity Cache;
+                                     1 = one stream (eight large chunks, or chunk_polys).  sr_ctx_plan_in_use tells which.     */
 } sr_plan;
 int sr_ctx_create_ex(int ring, int log2_degree, int device, const sr_plan *plan, sr_ctx **out);
 /* Pre-sizes the context's operand scratch for fused ring products of up to `batch` elements (capped by the plan's
@@ -100,6 +103,11 @@ int sr_ctx_create_ex(int ring, int log2_degree, int device, const sr_plan *plan,
  * scratch has to grow first blocks (hipDeviceSynchronize + hipFree + hipMalloc) -- call this once after creating the context
  * (or accept that the first product of a new size blocks) and no _dev call blocks afterwards. */
 int sr_ctx_reserve_scratch(sr_ctx *ctx, size_t batch);
+/* The plan the context runs: *plan = the sr_plan it was created with, with lanes resolved to 1 or 2 once the library has settled it
+ * (lanes stays 0 while sr_plan.lanes = 0 and no chunked product or sr_ctx_reserve_scratch has run yet).  probe_ms (optional):
+ * what the probe measured, [0] two lanes, [1] one stream, milliseconds for probe_elems ring products (0 = not measured: the plan
+ * was given explicitly, the ring has no chunked product, or the probe's temporaries could not be allocated). */
+int sr_ctx_plan_in_use(sr_ctx *ctx, sr_plan *plan, double probe_ms[2], size_t *probe_elems);
 int sr_ctx_destroy(sr_ctx *ctx);
 /* D, u64 limbs per coefficient, u64 words per ring element */
 int sr_ctx_degree(const sr_ctx *ctx, size_t *degree);
@@ -143,8 +151,9 @@ int sr_add_batch_dev(sr_ctx *ctx, uint64_t *d_lhs_inout, const uint64_t *d_rhs, 
 int sr_sub_batch_dev(sr_ctx *ctx, uint64_t *d_lhs_inout, const uint64_t *d_rhs, size_t batch, void *stream);
 /* First "next" row: y = M * v for a dense nrows x ncols matrix of ring elements in CRT/NTT form
  * (row-major, each entry one ring element) and a vector of ncols elements -- Matrix<RqNTT>::checked_mul_vec,
- * crates/linear_algebra/src/matrix.rs:168-178 -- as one fused multiply-accumulate pass over M.  Power-of-two
- * (fully split) rings only; d_y must not alias d_m or d_v. */
+ * crates/linear_algebra/src/matrix.rs:168-178 -- as one fused multiply-accumulate pass over M.  Every ring id: the fully
+ * split power-of-two rings (lane = slot) and the reference's own Goldilocks-24 / BabyBear-72 / Frog-16 (Fq3 / Fq9 / Fq4 slot
+ * products, csrc/small_linalg.hpp); d_y must not alias d_m or d_v. */
 int sr_matvec_ntt_dev(sr_ctx *ctx, uint64_t *d_y, const uint64_t *d_m, const uint64_t *d_v, size_t nrows, size_t ncols, void *stream);
 /* y = S * v for a sparse nrows x ncols matrix in CSR form: d_vals[j] one ring element (CRT/NTT form), d_cols[j] its column,
  * d_row_ptr[r] .. d_row_ptr[r+1] the stored entries of row r -- SparseMatrix<RqNTT>::checked_mul_vec,
@@ -220,7 +229,8 @@ int sr_deserialize_batch(sr_ctx *ctx, uint64_t *out, const uint8_t *wire, size_t
  * be multiplied into many a.  d_out may alias d_a; d_b must not alias d_out.  Above one LDS tile the intermediates go
  * through the context's operand scratch (sr_ctx_reserve_scratch).  Stream semantics: one stream-ordered operation on `stream`;
  * a batch of more than one chunk (sr_plan.chunk_polys, 64 MiB of coefficients by default) is forked onto the context's two
- * internal streams and joined back onto `stream` before the call returns (sr_plan.lanes = 1: everything on `stream` itself). */
+ * internal streams and joined back onto `stream` before the call returns (sr_plan.lanes = 1, or the library's own choice when
+ * lanes = 0 and its probe found one stream faster: everything on `stream` itself). */
 int sr_ring_mul_batch_dev(sr_ctx *ctx, uint64_t *d_out, const uint64_t *d_a, const uint64_t *d_b, size_t batch, void *stream);
 /* The constant-operand case: d_b_ntt already holds crt(b) (sr_ntt_fwd_batch_dev), e.g. the rows of a commitment matrix that
  * stay in NTT form (matrix.rs:168-178) while fresh coefficient-form elements arrive: d_out = icrt(crt(d_a) (.) d_b_ntt),
@@ -230,6 +240,26 @@ int sr_ring_mul_ntt_rhs_batch_dev(sr_ctx *ctx, uint64_t *d_out, const uint64_t *
 /* host-pointer form (staged through device memory like sr_ring_mul_batch) */
 int sr_ring_mul_ntt_rhs_batch(sr_ctx *ctx, uint64_t *out, const uint64_t *a, const uint64_t *b_ntt, size_t batch);
 int sr_reduce_batch_dev(sr_ctx *ctx, const uint64_t *d_in, size_t in_len_per_elem, uint64_t *d_out, size_t batch, void *stream);
+/* ---- packed-u32 boundary, SR_RING_BABYBEAR_POW2 only (opt-in; BASELINE configs[2] "packed 32-bit modmul") -------------------------
+ * The reference keeps a BabyBear coefficient in an ark-ff Fp64: one u64 limb holding a * 2^64 mod p with p < 2^31
+ * (crates/ring/src/cyclotomic_ring/models/babybear/mod.rs:18-26), i.e. the upper 32 bits of every word are zero.  The PACKED image
+ * of a coefficient is the low half of that limb: the uint32_t (a * 2^64 mod p), canonical in [0, p) -- the same Montgomery residue
+ * (R = 2^64, not 2^32) in four bytes.  A packed batch is batch * D such words, element-major like everything else.  These entry
+ * points are the packed twins of sr_ntt_fwd/inv_batch_dev (CRT::elementwise_crt / ICRT::elementwise_icrt, crt.rs:10-49),
+ * sr_ring_mul_batch_dev (RqPoly * &RqPoly, coeff_form.rs:250-258; operands only read, d_out may alias d_a, not d_b),
+ * sr_pointwise_mul_batch_dev (ntt_form.rs:213-225) and sr_add/sub_batch_dev, value for value: unpack32(f_packed(pack32(x))) ==
+ * f(x) bit for bit.  For D >= 4096 the register-tiled kernels read and write the packed words directly (half the boundary
+ * bytes of the 8-byte layout); smaller degrees are widened into context-owned staging, computed and narrowed again.
+ * sr_pack32_batch_dev takes the low word of every limb (the caller guarantees canonical images, whose high word is zero);
+ * sr_unpack32_batch_dev zero-extends.  Neither may run in place. */
+int sr_pack32_batch_dev(sr_ctx *ctx, uint32_t *d_out, const uint64_t *d_in, size_t batch, void *stream);
+int sr_unpack32_batch_dev(sr_ctx *ctx, uint64_t *d_out, const uint32_t *d_in, size_t batch, void *stream);
+int sr_ntt_fwd_packed32_batch_dev(sr_ctx *ctx, uint32_t *d_data, size_t batch, void *stream);
+int sr_ntt_inv_packed32_batch_dev(sr_ctx *ctx, uint32_t *d_data, size_t batch, void *stream);
+int sr_ring_mul_packed32_batch_dev(sr_ctx *ctx, uint32_t *d_out, const uint32_t *d_a, const uint32_t *d_b, size_t batch, void *stream);
+int sr_pointwise_mul_packed32_batch_dev(sr_ctx *ctx, uint32_t *d_lhs_inout, const uint32_t *d_rhs, size_t batch, void *stream);
+int sr_add_packed32_batch_dev(sr_ctx *ctx, uint32_t *d_lhs_inout, const uint32_t *d_rhs, size_t batch, void *stream);
+int sr_sub_packed32_batch_dev(sr_ctx *ctx, uint32_t *d_lhs_inout, const uint32_t *d_rhs, size_t batch, void *stream);
 /* Synthetic coefficients, uniform in [0,p), counter-based (same definition as the oracle's
  * sro_fill_uniform): fills n_coeffs coefficients starting at flat coefficient index first_coeff. */
 int sr_fill_uniform_dev(sr_ctx *ctx, uint64_t seed, uint64_t first_coeff, size_t n_coeffs, uint64_t *d_out, void *stream);

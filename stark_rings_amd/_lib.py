@@ -19,6 +19,7 @@ SYMBOLS = {
     "sr_ctx_create_group": (_c.c_int, [_c.c_int, _c.c_int, _c.POINTER(_c.c_int), _c.c_int, _c.c_void_p, _c.POINTER(_c.c_void_p)]),
     "sr_shard_range": (_c.c_int, [_c.c_size_t, _c.c_int, _c.c_int, _c.POINTER(_c.c_size_t), _c.POINTER(_c.c_size_t)]),
     "sr_ctx_reserve_scratch": (_c.c_int, [_c.c_void_p, _c.c_size_t]),
+    "sr_ctx_plan_in_use": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.POINTER(_c.c_double), _c.POINTER(_c.c_size_t)]),
     "sr_ctx_destroy": (_c.c_int, [_c.c_void_p]),
     "sr_ctx_degree": (_c.c_int, [_c.c_void_p, _c.POINTER(_c.c_size_t)]),
     "sr_ctx_limbs": (_c.c_int, [_c.c_void_p, _c.POINTER(_c.c_int)]),
@@ -63,6 +64,14 @@ SYMBOLS = {
     "sr_ring_mul_batch_dev": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_size_t, _c.c_void_p]),
     "sr_ring_mul_ntt_rhs_batch": (_c.c_int, [_c.c_void_p, u64p, u64p, u64p, _c.c_size_t]),
     "sr_ring_mul_ntt_rhs_batch_dev": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_size_t, _c.c_void_p]),
+    "sr_pack32_batch_dev": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_size_t, _c.c_void_p]),
+    "sr_unpack32_batch_dev": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_size_t, _c.c_void_p]),
+    "sr_ntt_fwd_packed32_batch_dev": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_size_t, _c.c_void_p]),
+    "sr_ntt_inv_packed32_batch_dev": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_size_t, _c.c_void_p]),
+    "sr_ring_mul_packed32_batch_dev": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_size_t, _c.c_void_p]),
+    "sr_pointwise_mul_packed32_batch_dev": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_size_t, _c.c_void_p]),
+    "sr_add_packed32_batch_dev": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_size_t, _c.c_void_p]),
+    "sr_sub_packed32_batch_dev": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_size_t, _c.c_void_p]),
     "sr_reduce_batch_dev": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_size_t, _c.c_void_p, _c.c_size_t, _c.c_void_p]),
     "sr_fill_uniform_dev": (_c.c_int, [_c.c_void_p, _c.c_uint64, _c.c_uint64, _c.c_size_t, _c.c_void_p, _c.c_void_p]),
     "sr_count_noncanonical_dev": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_size_t, _c.POINTER(_c.c_uint64), _c.c_void_p]),

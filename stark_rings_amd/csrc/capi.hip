@@ -26,6 +26,7 @@
 #include "wire.hpp"
 #include "frog_ring.hpp"
 #include "ntt_stark.hpp"
+#include "packed32.hpp"
 
 namespace {
 
@@ -84,8 +85,17 @@ struct sr_ctx {
     bool stark_lazy = false;  // Stark rings: transforms run on StarkL (nine 28-bit limbs, lazy carries; stark_lazy.hpp)
     // staging for host-pointer entry points
     sr::GlLanes gl_lanes;  // tuned Goldilocks ring product on two internal streams (streams and events created on first use)
-    void *host_tmp[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // device temporaries of the host-pointer linear-algebra /
-    size_t host_tmp_bytes[5] = {0, 0, 0, 0, 0};                         // decomposition calls (grow-only, see DevBuf)
+    // sr_plan.lanes = 0 (auto): the plan the context settled on -- 0 undecided, 1 one stream, 2 two lanes -- measured ONCE on this
+    // process's actual stream-to-hardware-queue mapping (lanes_autoselect); lanes_probe_ms = what the two plans took ([0] two lanes,
+    // [1] one stream; 0 = not measured).  probe_chunk != 0 only while the probe runs: the one-stream plan's chunk for that run.
+    int lanes_choice = 0;
+    double lanes_probe_ms[2] = {0, 0};
+    size_t lanes_probe_elems = 0;
+    size_t probe_chunk = 0;
+    bool probing = false;
+    void *host_tmp[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // device temporaries of the host-pointer
+    size_t host_tmp_bytes[7] = {0, 0, 0, 0, 0, 0, 0};  // linear-algebra / decomposition calls (grow-only, see DevBuf); [5], [6]: the
+                                                       // widened operands of packed-u32 calls below D = 4096 (DevBufLite)
     void *stage[4] = {nullptr, nullptr, nullptr, nullptr};  // [2], [3]: second lane of the chunked host pipeline
     size_t stage_bytes[4] = {0, 0, 0, 0};
     hipStream_t stream = nullptr;
@@ -436,6 +446,27 @@ int matmul_dev(sr_ctx *c, uint64_t *y, const uint64_t *a, const uint64_t *b, siz
 int ensure_scratch(sr_ctx *c, int n_buffers, size_t bytes);
 int rt_scratch_acquire(sr_ctx *c, hipStream_t st);
 int rt_scratch_release(sr_ctx *c, hipStream_t st);
+// One use of the shared operand scratch by a call on stream st.  The release (an event recorded on st, which the next user on another
+// stream waits for) happens on EVERY exit path once acquire() succeeded -- also after a failed launch, when earlier launches of the
+// same call may still be using the scratch.
+struct ScratchUse {
+    sr_ctx *c;
+    hipStream_t st;
+    bool held = false;
+    ScratchUse(sr_ctx *ctx, hipStream_t s) : c(ctx), st(s) {}
+    int acquire() {
+        const int rc = rt_scratch_acquire(c, st);
+        held = rc == SR_OK;
+        return rc;
+    }
+    int release() {
+        held = false;
+        return rt_scratch_release(c, st);
+    }
+    ~ScratchUse() {
+        if (held) (void)rt_scratch_release(c, st);
+    }
+};
 // ring elements of elem_bytes each the operand scratch may hold for a batch (plan cap; at least one element)
 size_t scratch_polys(const sr_ctx *c, size_t batch, size_t elem_bytes) {
     const size_t cap = c->plan.scratch_limit_bytes ? (size_t)c->plan.scratch_limit_bytes : ((size_t)16 << 30);
@@ -447,7 +478,10 @@ size_t scratch_polys(const sr_ctx *c, size_t batch, size_t elem_bytes) {
 // tuned Goldilocks path: a large batch runs as eight chunks of launches (unless the plan fixes chunk_polys) -- measured on config 2:
 // 18.6 ms as one set of launches, 18.27 / 18.3 / 18.5 ms in chunks of 2048 / 4096 / 1024 ring elements (the inverse column pass
 // finds part of the rows kernel's output still in the Infinity Cache), and the operand scratch is an eighth of the batch
+// lanes the context runs its chunked products on: the plan's explicit choice, else what the probe settled on (two until it has run)
+int effective_lanes(const sr_ctx *c) { return c->plan.lanes ? (int)c->plan.lanes : (c->lanes_choice ? c->lanes_choice : 2); }
 size_t gl_chunk_polys(const sr_ctx *c, size_t batch) {
+    if (c->probe_chunk) return c->probe_chunk < batch ? c->probe_chunk : batch;  // the probe times ONE set of launches of the real chunk size
     size_t chunk = scratch_polys(c, batch, (size_t)8 << c->k);
     if (!c->plan.chunk_polys && batch >= 64 && chunk > (batch + 7) / 8) chunk = (batch + 7) / 8;
     return chunk;
@@ -464,7 +498,7 @@ size_t gl_lane_chunk(const sr_ctx *c) {
     return chunk ? chunk : 1;
 }
 bool gl_use_lanes(const sr_ctx *c, size_t batch) {
-    return c->plan.lanes != 1 && c->k > 12 && c->gl_fast.cols256 && batch > gl_lane_chunk(c);
+    return effective_lanes(c) != 1 && c->k > 12 && c->gl_fast.cols256 && batch > gl_lane_chunk(c);
 }
 int gl_lanes_init(sr_ctx *c) {
     sr::GlLanes &L = c->gl_lanes;
@@ -498,7 +532,8 @@ int ring_mul_dev(sr_ctx *c, uint64_t *out, const uint64_t *a, const uint64_t *b,
         const size_t elem = sizeof(S) << c->k;
         const size_t chunk = scratch_polys(c, batch, elem);
         if (int rc = ensure_scratch(c, 1, chunk * elem)) return rc;
-        if (int rc = rt_scratch_acquire(c, st)) return rc;
+        ScratchUse su(c, st);
+        if (int rc = su.acquire()) return rc;
         S *sb = reinterpret_cast<S *>(c->rt_scratch[0]);
         for (size_t e = 0; e < batch; e += chunk) {
             const size_t n = batch - e < chunk ? batch - e : chunk;
@@ -512,7 +547,7 @@ int ring_mul_dev(sr_ctx *c, uint64_t *out, const uint64_t *a, const uint64_t *b,
             rc = launch_cols<F, sr::MODE_INV>(c, o, o, n, true, st);
             if (rc) return rc;
         }
-        return rt_scratch_release(c, st);
+        return su.release();
     }
     return launch_rows<F, sr::MODE_MUL>(c, reinterpret_cast<S *>(const_cast<uint64_t *>(a)),
                                         reinterpret_cast<const S *>(b), reinterpret_cast<S *>(out), batch, true, st);
@@ -607,17 +642,18 @@ template <class F> bool rt_use_lanes(const sr_ctx *c, size_t batch, hipStream_t 
 int gl_lanes_init(sr_ctx *c);
 // stand-alone transform in chunks on the context's two streams, each lane with its own packed scratch (the two-lane plan of
 // rt_ring_mul below; the scratch has the product's size, so one allocation serves both)
-template <class F, int DIR>
-int rt_transform_lanes(sr_ctx *c, uint64_t *d, size_t batch, hipStream_t st) {
+template <class F, int DIR, class VB = sr::rt::Boundary>
+int rt_transform_lanes(sr_ctx *c, void *d, size_t batch, hipStream_t st) {
     using E = typename F::elem;
-    using S = typename F::storage;
+    using S = typename sr::rt::View<F, VB>::T;
     const size_t chunk = rt_lane_chunk<F>(c), words = chunk << c->k;
     if (int rc = ensure_scratch(c, 1, 4 * words * sizeof(E))) return rc;
     if (int rc = gl_lanes_init(c)) return rc;
-    if (int rc = rt_scratch_acquire(c, st)) return rc;
+    ScratchUse su(c, st);
+    if (int rc = su.acquire()) return rc;
     sr::GlLanes &L = c->gl_lanes;
     E *base = reinterpret_cast<E *>(c->rt_scratch[0]);
-    HIP_TRY(hipEventRecord(L.fork, st));
+    HIP_TRY(hipEventRecord(L.fork, st));  // (nothing is in flight on the lanes yet if one of these three fails)
     for (int i = 0; i < 2; i++) HIP_TRY(hipStreamWaitEvent(L.st[i], L.fork, 0));
     int rc = 0;
     size_t ci = 0;
@@ -625,42 +661,46 @@ int rt_transform_lanes(sr_ctx *c, uint64_t *d, size_t batch, hipStream_t st) {
         const int i = (int)(ci & 1);
         const size_t n = batch - e < chunk ? batch - e : chunk;
         S *dc = reinterpret_cast<S *>(d) + (e << c->k);
-        rc = DIR == 0 ? sr::rt::fwd<F>(c->rt_hooks, dc, n, make_rt_params<F>(c, false), base + (size_t)(2 * i) * words, L.st[i])
-                      : sr::rt::inv<F>(c->rt_hooks, dc, n, make_rt_params<F>(c, false), base + (size_t)(2 * i) * words, L.st[i]);
+        rc = DIR == 0 ? sr::rt::fwd<F, VB>(c->rt_hooks, dc, n, make_rt_params<F>(c, false), base + (size_t)(2 * i) * words, L.st[i])
+                      : sr::rt::inv<F, VB>(c->rt_hooks, dc, n, make_rt_params<F>(c, false), base + (size_t)(2 * i) * words, L.st[i]);
     }
     for (int i = 0; i < 2; i++) {  // join even after a failed launch
         if (hipEventRecord(L.join[i], L.st[i]) != hipSuccess) rc = 1;
         if (hipStreamWaitEvent(st, L.join[i], 0) != hipSuccess) rc = 1;
     }
-    if (int r2 = rt_scratch_release(c, st)) return r2;
+    if (int r2 = su.release()) return r2;
     return rc ? fail(SR_E_HIP, "register-tiled launch failed") : SR_OK;
 }
-template <class F>
-int rt_fwd(sr_ctx *c, uint64_t *d, size_t batch, hipStream_t st) {
+// VB: the view of the caller's words -- sr::rt::Boundary (the reference's 8-byte limbs) or sr::rt::PackedStream (the packed-u32 entry points)
+template <class F, class VB = sr::rt::Boundary>
+int rt_fwd(sr_ctx *c, void *d, size_t batch, hipStream_t st) {
     using E = typename F::elem;
-    if (rt_use_lanes<F>(c, batch, st)) return rt_transform_lanes<F, 0>(c, d, batch, st);
+    if (rt_use_lanes<F>(c, batch, st)) return rt_transform_lanes<F, 0, VB>(c, d, batch, st);
     if (int rc = rt_ensure_scratch(c, 1, (batch << c->k) * sizeof(E))) return rc;
-    if (int rc = rt_scratch_acquire(c, st)) return rc;
-    if (sr::rt::fwd<F>(c->rt_hooks, reinterpret_cast<typename F::storage *>(d), batch, make_rt_params<F>(c, false),
-                       (E *)c->rt_scratch[0], st))
+    ScratchUse su(c, st);
+    if (int rc = su.acquire()) return rc;
+    if (sr::rt::fwd<F, VB>(c->rt_hooks, reinterpret_cast<typename sr::rt::View<F, VB>::T *>(d), batch, make_rt_params<F>(c, false),
+                           (E *)c->rt_scratch[0], st))
         return fail(SR_E_HIP, "register-tiled launch failed");
-    return rt_scratch_release(c, st);
+    return su.release();
 }
-template <class F>
-int rt_inv(sr_ctx *c, uint64_t *d, size_t batch, hipStream_t st) {
+template <class F, class VB = sr::rt::Boundary>
+int rt_inv(sr_ctx *c, void *d, size_t batch, hipStream_t st) {
     using E = typename F::elem;
-    if (rt_use_lanes<F>(c, batch, st)) return rt_transform_lanes<F, 1>(c, d, batch, st);
+    if (rt_use_lanes<F>(c, batch, st)) return rt_transform_lanes<F, 1, VB>(c, d, batch, st);
     if (int rc = rt_ensure_scratch(c, 1, (batch << c->k) * sizeof(E))) return rc;
-    if (int rc = rt_scratch_acquire(c, st)) return rc;
-    if (sr::rt::inv<F>(c->rt_hooks, reinterpret_cast<typename F::storage *>(d), batch, make_rt_params<F>(c, false),
-                       (E *)c->rt_scratch[0], st))
+    ScratchUse su(c, st);
+    if (int rc = su.acquire()) return rc;
+    if (sr::rt::inv<F, VB>(c->rt_hooks, reinterpret_cast<typename sr::rt::View<F, VB>::T *>(d), batch, make_rt_params<F>(c, false),
+                           (E *)c->rt_scratch[0], st))
         return fail(SR_E_HIP, "register-tiled launch failed");
-    return rt_scratch_release(c, st);
+    return su.release();
 }
 // a large batch runs as eight chunks of launches (unless the plan fixes chunk_polys), like the tuned Goldilocks path: measured on
 // config 3 (BabyBear D = 2^16, batch 2^14): 11.68 ms as one set of launches, 11.38 / 11.41 / 11.56 ms in chunks of 2048 / 4096 / 1024
 // ring elements, 12.4 ms and worse below 512 -- and the packed scratch is an eighth of the batch
 size_t rt_chunk_polys(const sr_ctx *c, size_t batch) {
+    if (c->probe_chunk) return c->probe_chunk < batch ? c->probe_chunk : batch;
     if (c->plan.chunk_polys) return c->plan.chunk_polys < batch ? c->plan.chunk_polys : batch;
     return batch >= 64 ? (batch + 7) / 8 : batch;
 }
@@ -676,21 +716,22 @@ size_t rt_lane_chunk(const sr_ctx *c) {
 }
 template <class F>
 bool rt_use_lanes(const sr_ctx *c, size_t batch, hipStream_t st) {
-    return c->plan.lanes != 1 && c->k > 12 && batch > rt_lane_chunk<F>(c) && st != c->stream && st != c->out_stream;
+    return effective_lanes(c) != 1 && c->k > 12 && batch > rt_lane_chunk<F>(c) && st != c->stream && st != c->out_stream;
 }
-template <class F>
-int rt_ring_mul(sr_ctx *c, uint64_t *out, const uint64_t *a, const uint64_t *b, size_t batch, hipStream_t st) {
-    using S = typename F::storage;
+template <class F, class VB = sr::rt::Boundary>
+int rt_ring_mul(sr_ctx *c, void *out, const void *a, const void *b, size_t batch, hipStream_t st) {
+    using S = typename sr::rt::View<F, VB>::T;
     using E = typename F::elem;
     if (batch == 0) return SR_OK;
     if (rt_use_lanes<F>(c, batch, st)) {
         const size_t chunk = rt_lane_chunk<F>(c), words = chunk << c->k;
         if (int rc = ensure_scratch(c, 1, 4 * words * sizeof(E))) return rc;
         if (int rc = gl_lanes_init(c)) return rc;
-        if (int rc = rt_scratch_acquire(c, st)) return rc;
+        ScratchUse su(c, st);
+        if (int rc = su.acquire()) return rc;
         sr::GlLanes &L = c->gl_lanes;
         E *base = reinterpret_cast<E *>(c->rt_scratch[0]);
-        HIP_TRY(hipEventRecord(L.fork, st));
+        HIP_TRY(hipEventRecord(L.fork, st));  // (nothing is in flight on the lanes yet if one of these three fails)
         for (int i = 0; i < 2; i++) HIP_TRY(hipStreamWaitEvent(L.st[i], L.fork, 0));
         int rc = 0;
         size_t ci = 0;
@@ -698,29 +739,30 @@ int rt_ring_mul(sr_ctx *c, uint64_t *out, const uint64_t *a, const uint64_t *b, 
             const int i = (int)(ci & 1);
             const size_t n = batch - e < chunk ? batch - e : chunk;
             const size_t off = e << c->k;
-            rc = sr::rt::ring_mul<F>(c->rt_hooks, reinterpret_cast<S *>(out) + off, reinterpret_cast<const S *>(a) + off,
-                                     reinterpret_cast<const S *>(b) + off, n, make_rt_params<F>(c, true), base + (size_t)(2 * i) * words,
-                                     base + (size_t)(2 * i + 1) * words, L.st[i]);
+            rc = sr::rt::ring_mul<F, VB>(c->rt_hooks, reinterpret_cast<S *>(out) + off, reinterpret_cast<const S *>(a) + off,
+                                         reinterpret_cast<const S *>(b) + off, n, make_rt_params<F>(c, true), base + (size_t)(2 * i) * words,
+                                         base + (size_t)(2 * i + 1) * words, L.st[i]);
         }
         for (int i = 0; i < 2; i++) {  // join even after a failed launch
             if (hipEventRecord(L.join[i], L.st[i]) != hipSuccess) rc = 1;
             if (hipStreamWaitEvent(st, L.join[i], 0) != hipSuccess) rc = 1;
         }
-        if (int r2 = rt_scratch_release(c, st)) return r2;
+        if (int r2 = su.release()) return r2;
         return rc ? fail(SR_E_HIP, "register-tiled launch failed") : SR_OK;
     }
     const size_t chunk = c->k > 12 ? rt_chunk_polys(c, batch) : batch;
     if (int rc = rt_ensure_scratch(c, 2, (chunk << c->k) * sizeof(E))) return rc;
-    if (int rc = rt_scratch_acquire(c, st)) return rc;
+    ScratchUse su(c, st);
+    if (int rc = su.acquire()) return rc;
     for (size_t e = 0; e < batch; e += chunk) {
         const size_t n = batch - e < chunk ? batch - e : chunk;
         const size_t off = e << c->k;
-        if (sr::rt::ring_mul<F>(c->rt_hooks, reinterpret_cast<S *>(out) + off, reinterpret_cast<const S *>(a) + off,
-                                reinterpret_cast<const S *>(b) + off, n, make_rt_params<F>(c, true), (E *)c->rt_scratch[0],
-                                (E *)c->rt_scratch[1], st))
+        if (sr::rt::ring_mul<F, VB>(c->rt_hooks, reinterpret_cast<S *>(out) + off, reinterpret_cast<const S *>(a) + off,
+                                    reinterpret_cast<const S *>(b) + off, n, make_rt_params<F>(c, true), (E *)c->rt_scratch[0],
+                                    (E *)c->rt_scratch[1], st))
             return fail(SR_E_HIP, "register-tiled launch failed");
     }
-    return rt_scratch_release(c, st);
+    return su.release();
 }
 
 // ---- Stark rings, k >= 4: ntt_stark.hpp ----
@@ -761,7 +803,8 @@ int st_ring_mul(sr_ctx *c, uint64_t *out, const uint64_t *a, const uint64_t *b, 
     const size_t elem = sizeof(S) << c->k;
     const size_t chunk = scratch_polys(c, batch, elem);
     if (int rc = ensure_scratch(c, 1, chunk * elem)) return rc;
-    if (int rc = rt_scratch_acquire(c, st)) return rc;
+    ScratchUse su(c, st);
+    if (int rc = su.acquire()) return rc;
     S *sb = reinterpret_cast<S *>(c->rt_scratch[0]);
     auto hook_f = [&](bool begin) { begin ? gl_prof_begin(c, 0, st) : gl_prof_end(c, st); };
     auto hook_i = [&](bool begin) { begin ? gl_prof_begin(c, 2, st) : gl_prof_end(c, st); };
@@ -776,7 +819,7 @@ int st_ring_mul(sr_ctx *c, uint64_t *out, const uint64_t *a, const uint64_t *b, 
         }
         if (sr::st::inv_cols(o, n, p, false, st, hook_i)) return fail(SR_E_HIP, "stark strided launch failed");
     }
-    return rt_scratch_release(c, st);
+    return su.release();
 }
 
 bool is_pow2_ring(int ring) { return ring >= SR_RING_GOLDILOCKS_POW2 && ring <= SR_RING_STARK_POW2; }
@@ -929,6 +972,8 @@ int dev_recompose_wide(sr_ctx *c, uint64_t *out, const uint64_t *in, uint64_t lo
 }
 int check_basis_wide(uint64_t lo, uint64_t hi) {
     if (hi == 0) return check_basis(lo);
+    // decompose_balanced_in_place casts `b as i128` (mod.rs:73): 2^127 and above would be a negative basis there
+    if (hi >> 63) return fail(SR_E_INVALID, "decomposition basis >= 2^127 (negative after the reference's cast to i128)");
     if (lo & 1) return fail(SR_E_INVALID, "decomposition basis must be even");
     return SR_OK;
 }
@@ -964,7 +1009,9 @@ int check_count(const sr_ctx *c, size_t n_elems, size_t per_elem = 1) {
 }
 
 // ---- per-ring device dispatch (pow2 rings and the reference-native small rings) --------------
+int lanes_autoselect(sr_ctx *c, size_t batch);  // sr_plan.lanes = 0: measure once which plan this process's queues favour (below)
 int dev_fwd(sr_ctx *c, uint64_t *d, size_t batch, hipStream_t st) {
+    if (st != c->stream && st != c->out_stream) (void)lanes_autoselect(c, batch);
     if (c->ring == SR_RING_FROG_16) return sr::frog_launch(c->frog, sr::FROG_CRT, d, nullptr, 0, d, batch, st) ? fail(SR_E_HIP, "frog-ring launch failed") : SR_OK;
     if (c->ring == SR_RING_GOLDILOCKS_24) return sr::small_launch(c->small, sr::SMALL_G24_CRT, d, nullptr, 0, d, batch, st) ? fail(SR_E_HIP, "small-ring launch failed") : SR_OK;
     if (c->ring == SR_RING_BABYBEAR_72) return sr::small_launch(c->small, sr::SMALL_B72_CRT, d, nullptr, 0, d, batch, st) ? fail(SR_E_HIP, "small-ring launch failed") : SR_OK;
@@ -985,6 +1032,7 @@ int dev_fwd(sr_ctx *c, uint64_t *d, size_t batch, hipStream_t st) {
     DISPATCH_POW2(c, (fwd_dev<F>(c, d, batch, st)));
 }
 int dev_inv(sr_ctx *c, uint64_t *d, size_t batch, hipStream_t st) {
+    if (st != c->stream && st != c->out_stream) (void)lanes_autoselect(c, batch);
     if (c->ring == SR_RING_FROG_16) return sr::frog_launch(c->frog, sr::FROG_ICRT, d, nullptr, 0, d, batch, st) ? fail(SR_E_HIP, "frog-ring launch failed") : SR_OK;
     if (c->ring == SR_RING_GOLDILOCKS_24) return sr::small_launch(c->small, sr::SMALL_G24_ICRT, d, nullptr, 0, d, batch, st) ? fail(SR_E_HIP, "small-ring launch failed") : SR_OK;
     if (c->ring == SR_RING_BABYBEAR_72) return sr::small_launch(c->small, sr::SMALL_B72_ICRT, d, nullptr, 0, d, batch, st) ? fail(SR_E_HIP, "small-ring launch failed") : SR_OK;
@@ -1053,7 +1101,124 @@ int dev_matvec(sr_ctx *c, uint64_t *y, const uint64_t *m, const uint64_t *v, siz
     if (c->stark_lazy) return matvec_dev<sr::StarkL>(c, y, m, v, nrows, ncols, st);  // sums of products on 28-bit lazy limbs (stark_lazy.hpp)
     DISPATCH_POW2(c, (matvec_dev<F>(c, y, m, v, nrows, ncols, st)));
 }
+// device temporary in slot `slot` of the context's grow-only set (see DevBuf below; this one is usable from the internal helpers)
+struct DevBufLite {
+    sr_ctx *c;
+    int slot;
+    void *p = nullptr;
+    DevBufLite(sr_ctx *c_, int slot_) : c(c_), slot(slot_) {}
+    int alloc(size_t bytes) {
+        if (bytes == 0) bytes = 8;
+        if (c->host_tmp_bytes[slot] < bytes) {
+            if (c->host_tmp[slot]) {
+                HIP_TRY(hipDeviceSynchronize());  // a _dev call on another stream may still be using the smaller buffer
+                (void)hipFree(c->host_tmp[slot]);
+                c->host_tmp[slot] = nullptr;
+                c->host_tmp_bytes[slot] = 0;
+            }
+            hipError_t e = hipMalloc(&c->host_tmp[slot], bytes);
+            if (e != hipSuccess) return fail(SR_E_ALLOC, std::string("hipMalloc: ") + hipGetErrorString(e));
+            c->host_tmp_bytes[slot] = bytes;
+        }
+        p = c->host_tmp[slot];
+        return SR_OK;
+    }
+};
+// ---- plan selection: sr_plan.lanes = 0 means "measure once, keep the winner" ------------------------------------------------
+// The two-lane plans (tuned Goldilocks cols256 product, register-tiled product) only pay when the HIP runtime gives each of the
+// context's two streams its own hardware queue; which queue a stream gets is decided when the stream is created (GPU_MAX_HW_QUEUES,
+// the streams the process already holds), so a host that runs RCCL or a framework beside this library can end up with both lanes
+// on one queue -- and then the one-stream plan is the faster one (20.4 against 17.9 ms per config-2 batch).  The library
+// therefore times both plans itself, once per context, on the context's real streams: up to 16 lane chunks of device-generated
+// uniform operands in temporary buffers, each plan warmed once and timed twice (best of two), on the legacy default stream as the
+// caller's stream (no stream is created for the probe).  Runs inside sr_ctx_reserve_scratch or, failing that, inside the first
+// product large enough to be chunked (which blocks anyway while the scratch is allocated).  sr_ctx_plan_in_use reports the outcome.
+int dev_ring_mul(sr_ctx *c, uint64_t *out, const uint64_t *a, const uint64_t *b, size_t batch, hipStream_t st);
+size_t lanes_chunk_of(const sr_ctx *c) {
+    if (c->regtile) return c->ring == SR_RING_BABYBEAR_POW2 ? rt_lane_chunk<sr::BabyBear>(c) : rt_lane_chunk<sr::Goldilocks>(c);
+    return gl_lane_chunk(c);
+}
+bool lanes_candidate(const sr_ctx *c, size_t batch) {
+    if (!is_pow2_ring(c->ring) || c->k <= 12) return false;
+    const bool gl = c->ring == SR_RING_GOLDILOCKS_POW2 && !c->regtile && c->fast_goldilocks && sr::gl_fast_supported(c->gl_fast) && c->gl_fast.cols256;
+    if (!gl && !c->regtile) return false;
+    return batch > lanes_chunk_of(c);
+}
+int lanes_autoselect(sr_ctx *c, size_t batch) {
+    if (c->plan.lanes || c->lanes_choice || c->probing || !lanes_candidate(c, batch)) return SR_OK;
+    const size_t chunk = lanes_chunk_of(c);
+    size_t n = batch < 16 * chunk ? batch : 16 * chunk;
+    const size_t elem = c->degree * c->limbs * 8, bytes = n * elem;
+    void *buf[3] = {nullptr, nullptr, nullptr};
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    auto cleanup = [&]() {
+        (void)hipDeviceSynchronize();
+        for (auto &p : buf)
+            if (p) (void)hipFree(p);
+        for (auto &e : ev)
+            if (e) (void)hipEventDestroy(e);
+        // the probe sized the operand scratch for ITS one-stream run: drop it, the plan that won allocates what it needs
+        for (int i = 0; i < 2; i++) {
+            if (c->rt_scratch[i]) (void)hipFree(c->rt_scratch[i]);
+            c->rt_scratch[i] = nullptr;
+            c->rt_scratch_bytes[i] = 0;
+        }
+        c->rt_scratch_used = false;
+        c->probe_chunk = 0;
+        c->probing = false;
+    };
+    c->probing = true;
+    const bool prof_was = c->prof.on;
+    c->prof.on = false;
+    bool ok = true;
+    for (auto &p : buf) ok = ok && hipMalloc(&p, bytes) == hipSuccess;
+    for (auto &e : ev) ok = ok && hipEventCreate(&e) == hipSuccess;
+    hipStream_t st = nullptr;  // the legacy default stream stands in for the caller's
+    double best[2] = {0, 0};   // [0] two lanes, [1] one stream
+    if (ok) {
+        const size_t words = n * c->degree;
+        auto fill = [&](void *p, uint64_t seed) {
+            switch (c->ring) {
+                case SR_RING_GOLDILOCKS_POW2: return fill_dev<sr::Goldilocks>(c, seed, 0, words, (uint64_t *)p, st);
+                default: return fill_dev<sr::BabyBear>(c, seed, 0, words, (uint64_t *)p, st);
+            }
+        };
+        ok = fill(buf[1], 0x9E3779B97F4A7C15ull) == SR_OK && fill(buf[2], 0xD1B54A32D192ED03ull) == SR_OK;
+        for (int plan = 0; plan < 2 && ok; plan++) {
+            c->lanes_choice = plan == 0 ? 2 : 1;
+            c->probe_chunk = plan == 0 ? 0 : n;  // one stream: one set of launches, as the real plan runs its 1/8-batch chunks
+            for (int rep = 0; rep < 3 && ok; rep++) {
+                if (rep) ok = hipEventRecord(ev[0], st) == hipSuccess;
+                ok = ok && dev_ring_mul(c, (uint64_t *)buf[0], (const uint64_t *)buf[1], (const uint64_t *)buf[2], n, st) == SR_OK;
+                if (rep) {
+                    float ms = 0;
+                    ok = ok && hipEventRecord(ev[1], st) == hipSuccess && hipEventSynchronize(ev[1]) == hipSuccess &&
+                         hipEventElapsedTime(&ms, ev[0], ev[1]) == hipSuccess;
+                    if (ok && (best[plan] == 0 || ms < best[plan])) best[plan] = ms;
+                } else {
+                    ok = ok && hipStreamSynchronize(st) == hipSuccess;
+                }
+            }
+        }
+    }
+    cleanup();
+    c->prof.on = prof_was;
+    if (ok && best[0] > 0 && best[1] > 0) {
+        c->lanes_probe_ms[0] = best[0];
+        c->lanes_probe_ms[1] = best[1];
+        c->lanes_probe_elems = n;
+        c->lanes_choice = best[1] < best[0] ? 1 : 2;
+    } else {
+        // no memory for the probe's temporaries (or a launch failed: the real call will report that): keep the default, unmeasured
+        (void)hipGetLastError();
+        c->lanes_choice = 2;
+        g_err.clear();
+    }
+    return SR_OK;
+}
+
 int dev_ring_mul(sr_ctx *c, uint64_t *out, const uint64_t *a, const uint64_t *b, size_t batch, hipStream_t st) {
+    if (st != c->stream && st != c->out_stream) (void)lanes_autoselect(c, batch);  // (the host pipeline never uses the lanes)
     if (c->ring == SR_RING_FROG_16) return sr::frog_launch(c->frog, sr::FROG_RINGMUL, a, b, 0, out, batch, st) ? fail(SR_E_HIP, "frog-ring launch failed") : SR_OK;
     if (c->ring == SR_RING_GOLDILOCKS_24) return sr::small_launch(c->small, sr::SMALL_G24_RINGMUL, a, b, 0, out, batch, st) ? fail(SR_E_HIP, "small-ring launch failed") : SR_OK;
     if (c->ring == SR_RING_BABYBEAR_72) return sr::small_launch(c->small, sr::SMALL_B72_RINGMUL, a, b, 0, out, batch, st) ? fail(SR_E_HIP, "small-ring launch failed") : SR_OK;
@@ -1068,7 +1233,8 @@ int dev_ring_mul(sr_ctx *c, uint64_t *out, const uint64_t *a, const uint64_t *b,
             const size_t chunk = gl_lane_chunk(c), words = chunk << c->k;
             if (int rc = ensure_scratch(c, 1, 4 * words * 8)) return rc;
             if (int rc = gl_lanes_init(c)) return rc;
-            if (int rc = rt_scratch_acquire(c, st)) return rc;
+            ScratchUse su(c, st);
+            if (int rc = su.acquire()) return rc;
             sr::GlLanes &L = c->gl_lanes;
             uint64_t *base = reinterpret_cast<uint64_t *>(c->rt_scratch[0]);
             L.chunk = chunk;
@@ -1076,20 +1242,21 @@ int dev_ring_mul(sr_ctx *c, uint64_t *out, const uint64_t *a, const uint64_t *b,
                 L.sa[i] = base + (size_t)(2 * i) * words;
                 L.sb[i] = base + (size_t)(2 * i + 1) * words;
             }
-            const int rc = sr::gl_fast_ring_mul_lanes(c->gl_fast, out, a, b, L, batch, st);
-            if (int r2 = rt_scratch_release(c, st)) return r2;
+            const int rc = sr::gl_fast_ring_mul_lanes(c->gl_fast, out, a, b, L, batch, st);  // joins the lanes itself, also on failure
+            if (int r2 = su.release()) return r2;
             return rc ? fail(SR_E_HIP, "goldilocks fast-path launch failed") : SR_OK;
         }
         uint64_t *scratch = nullptr;
         size_t chunk = 0;
+        ScratchUse su(c, st);
         if (c->k > 12 && batch) {  // b's column stages go through the operand scratch
             chunk = gl_chunk_polys(c, batch);
             if (int rc = ensure_scratch(c, 1, chunk * ((size_t)8 << c->k))) return rc;
-            if (int rc = rt_scratch_acquire(c, st)) return rc;
+            if (int rc = su.acquire()) return rc;
             scratch = reinterpret_cast<uint64_t *>(c->rt_scratch[0]);
         }
         if (sr::gl_fast_ring_mul(c->gl_fast, out, a, b, scratch, chunk, batch, st)) return fail(SR_E_HIP, "goldilocks fast-path launch failed");
-        return scratch ? rt_scratch_release(c, st) : SR_OK;
+        return scratch ? su.release() : SR_OK;
     }
     if (c->stark_tuned) return st_ring_mul(c, out, a, b, batch, st);
     if (c->stark_lazy) return ring_mul_dev<sr::StarkL>(c, out, a, b, batch, st);
@@ -1099,12 +1266,14 @@ int dev_ring_mul(sr_ctx *c, uint64_t *out, const uint64_t *a, const uint64_t *b,
 // Goldilocks tuned path fuses them: gl_fast_ring_mul_rhs)
 int dev_ring_mul_ntt_rhs(sr_ctx *c, uint64_t *out, const uint64_t *a, const uint64_t *b_ntt, size_t batch, hipStream_t st) {
     if (batch == 0) return SR_OK;
+    if (st != c->stream && st != c->out_stream) (void)lanes_autoselect(c, batch);
     if (c->ring == SR_RING_GOLDILOCKS_POW2 && !c->regtile && c->fast_goldilocks && sr::gl_fast_supported(c->gl_fast) && c->k >= 8) {
         if (gl_use_lanes(c, batch) && st != c->stream && st != c->out_stream) {  // as dev_ring_mul: chunks on the two lanes
             const size_t chunk = gl_lane_chunk(c), words = chunk << c->k;
             if (int rc = ensure_scratch(c, 1, 4 * words * 8)) return rc;
             if (int rc = gl_lanes_init(c)) return rc;
-            if (int rc = rt_scratch_acquire(c, st)) return rc;
+            ScratchUse su(c, st);
+            if (int rc = su.acquire()) return rc;
             sr::GlLanes &L = c->gl_lanes;
             uint64_t *base = reinterpret_cast<uint64_t *>(c->rt_scratch[0]);
             L.chunk = chunk;
@@ -1113,7 +1282,7 @@ int dev_ring_mul_ntt_rhs(sr_ctx *c, uint64_t *out, const uint64_t *a, const uint
                 L.sb[i] = base + (size_t)(2 * i + 1) * words;
             }
             const int rc = sr::gl_fast_ring_mul_rhs_lanes(c->gl_fast, out, a, b_ntt, L, batch, st);
-            if (int r2 = rt_scratch_release(c, st)) return r2;
+            if (int r2 = su.release()) return r2;
             return rc ? fail(SR_E_HIP, "goldilocks fast-path launch failed") : SR_OK;
         }
         return sr::gl_fast_ring_mul_rhs(c->gl_fast, out, a, b_ntt, batch, st) ? fail(SR_E_HIP, "goldilocks fast-path launch failed") : SR_OK;
@@ -1244,7 +1413,7 @@ int sr_ctx_destroy(sr_ctx *c) {
         if (c->rt_scratch[i]) (void)hipFree(c->rt_scratch[i]);
     if (c->out_stream) (void)hipStreamDestroy(c->out_stream);
     if (c->rt_scratch_free) (void)hipEventDestroy(c->rt_scratch_free);
-    for (int i = 0; i < 5; i++)
+    for (int i = 0; i < 7; i++)
         if (c->host_tmp[i]) (void)hipFree(c->host_tmp[i]);
     if (c->gl_lanes.n) {
         for (int i = 0; i < 2; i++)
@@ -1679,6 +1848,7 @@ int sr_ctx_reserve_scratch(sr_ctx *c, size_t batch) {
     std::lock_guard<std::mutex> lk(c->mu);
     DeviceGuard g(c->device);
     if (!is_pow2_ring(c->ring) || batch == 0) return SR_OK;  // the small rings need no scratch
+    if (int rc = lanes_autoselect(c, batch)) return rc;      // sr_plan.lanes = 0: settle the plan now, then size the scratch for it
     const size_t elem = c->degree * c->limbs * 8;
     if (c->regtile) {
         const size_t w = c->ring == SR_RING_BABYBEAR_POW2 ? 4 : 8;
@@ -1700,6 +1870,141 @@ int sr_ctx_reserve_scratch(sr_ctx *c, size_t batch) {
         return ensure_scratch(c, 1, 4 * gl_lane_chunk(c) * elem);
     }
     return ensure_scratch(c, 1, (gl ? gl_chunk_polys(c, batch) : scratch_polys(c, batch, elem)) * elem);
+}
+// ---- packed-u32 boundary (BabyBear power-of-two rings; csrc/packed32.hpp) ----------------------------------------------------
+extern "C++" {
+namespace {
+int check_packed(sr_ctx *c) {
+    if (c->ring != SR_RING_BABYBEAR_POW2) return fail(SR_E_INVALID, "packed32 entry points: BabyBear power-of-two rings only");
+    return SR_OK;
+}
+int launch_pack32(sr_ctx *c, uint32_t *out, const uint64_t *in, size_t n, hipStream_t st) {
+    if (n == 0) return SR_OK;
+    ProfScope ps(c, st, K_OTHER);
+    hipLaunchKernelGGL(sr::p32::pack32_kernel, dim3(sr::p32::blocks_for(n)), dim3(256), 0, st, out, in, n);
+    HIP_TRY(hipGetLastError());
+    return SR_OK;
+}
+int launch_unpack32(sr_ctx *c, uint64_t *out, const uint32_t *in, size_t n, hipStream_t st) {
+    if (n == 0) return SR_OK;
+    ProfScope ps(c, st, K_OTHER);
+    hipLaunchKernelGGL(sr::p32::unpack32_kernel, dim3(sr::p32::blocks_for(n)), dim3(256), 0, st, out, in, n);
+    HIP_TRY(hipGetLastError());
+    return SR_OK;
+}
+// D < 4096 has no register-tiled path: such (small) batches are widened into the context's staging buffers, run through the 8-byte
+// kernels and narrowed again -- same values, only the traffic advantage is lost where it does not matter
+template <class Fn>
+int packed_via_wide(sr_ctx *c, uint32_t *out, const uint32_t *a, const uint32_t *b, size_t batch, hipStream_t st, Fn run) {
+    const size_t n = batch << c->k;
+    DevBufLite wa(c, 5), wb(c, 6);
+    if (int rc = wa.alloc(n * 8)) return rc;
+    if (b)
+        if (int rc = wb.alloc(n * 8)) return rc;
+    if (int rc = launch_unpack32(c, (uint64_t *)wa.p, a, n, st)) return rc;
+    if (b)
+        if (int rc = launch_unpack32(c, (uint64_t *)wb.p, b, n, st)) return rc;
+    if (int rc = run((uint64_t *)wa.p, (uint64_t *)wb.p)) return rc;
+    return launch_pack32(c, out, (const uint64_t *)wa.p, n, st);
+}
+}  // namespace
+}  // extern "C++"
+int sr_pack32_batch_dev(sr_ctx *c, uint32_t *d_out, const uint64_t *d_in, size_t batch, void *stream) {
+    if (int rc = check(c, d_out, d_in)) return rc;
+    if (int rc = check_packed(c)) return rc;
+    if (int rc = check_count(c, batch)) return rc;
+    std::lock_guard<std::mutex> lk(c->mu);
+    DeviceGuard g(c->device);
+    return launch_pack32(c, d_out, d_in, batch << c->k, (hipStream_t)stream);
+}
+int sr_unpack32_batch_dev(sr_ctx *c, uint64_t *d_out, const uint32_t *d_in, size_t batch, void *stream) {
+    if (int rc = check(c, d_out, d_in)) return rc;
+    if (int rc = check_packed(c)) return rc;
+    if (int rc = check_count(c, batch)) return rc;
+    std::lock_guard<std::mutex> lk(c->mu);
+    DeviceGuard g(c->device);
+    return launch_unpack32(c, d_out, d_in, batch << c->k, (hipStream_t)stream);
+}
+int sr_ntt_fwd_packed32_batch_dev(sr_ctx *c, uint32_t *d, size_t batch, void *stream) {
+    if (int rc = check(c, d)) return rc;
+    if (int rc = check_packed(c)) return rc;
+    if (int rc = check_count(c, batch)) return rc;
+    std::lock_guard<std::mutex> lk(c->mu);
+    DeviceGuard g(c->device);
+    hipStream_t st = (hipStream_t)stream;
+    if (batch == 0) return SR_OK;
+    if (c->regtile) {
+        if (st != c->stream && st != c->out_stream) (void)lanes_autoselect(c, batch);
+        return rt_fwd<sr::BabyBear, sr::rt::PackedStream>(c, d, batch, st);
+    }
+    return packed_via_wide(c, d, d, nullptr, batch, st, [&](uint64_t *wa, uint64_t *) { return dev_fwd(c, wa, batch, st); });
+}
+int sr_ntt_inv_packed32_batch_dev(sr_ctx *c, uint32_t *d, size_t batch, void *stream) {
+    if (int rc = check(c, d)) return rc;
+    if (int rc = check_packed(c)) return rc;
+    if (int rc = check_count(c, batch)) return rc;
+    std::lock_guard<std::mutex> lk(c->mu);
+    DeviceGuard g(c->device);
+    hipStream_t st = (hipStream_t)stream;
+    if (batch == 0) return SR_OK;
+    if (c->regtile) {
+        if (st != c->stream && st != c->out_stream) (void)lanes_autoselect(c, batch);
+        return rt_inv<sr::BabyBear, sr::rt::PackedStream>(c, d, batch, st);
+    }
+    return packed_via_wide(c, d, d, nullptr, batch, st, [&](uint64_t *wa, uint64_t *) { return dev_inv(c, wa, batch, st); });
+}
+int sr_ring_mul_packed32_batch_dev(sr_ctx *c, uint32_t *d_out, const uint32_t *d_a, const uint32_t *d_b, size_t batch, void *stream) {
+    if (int rc = check(c, d_out, d_a, d_b)) return rc;
+    if (int rc = check_packed(c)) return rc;
+    if (int rc = check_count(c, batch)) return rc;
+    if (d_b == d_out) return fail(SR_E_INVALID, "ring_mul: b must not alias out");
+    std::lock_guard<std::mutex> lk(c->mu);
+    DeviceGuard g(c->device);
+    hipStream_t st = (hipStream_t)stream;
+    if (batch == 0) return SR_OK;
+    if (c->regtile) {
+        if (st != c->stream && st != c->out_stream) (void)lanes_autoselect(c, batch);
+        return rt_ring_mul<sr::BabyBear, sr::rt::PackedStream>(c, d_out, d_a, d_b, batch, st);
+    }
+    return packed_via_wide(c, d_out, d_a, d_b, batch, st, [&](uint64_t *wa, uint64_t *wb) { return dev_ring_mul(c, wa, wa, wb, batch, st); });
+}
+static int packed_elementwise(sr_ctx *c, uint32_t *l, const uint32_t *r, size_t batch, void *stream, int op) {
+    if (int rc = check(c, l, r)) return rc;
+    if (int rc = check_packed(c)) return rc;
+    if (int rc = check_count(c, batch)) return rc;
+    std::lock_guard<std::mutex> lk(c->mu);
+    DeviceGuard g(c->device);
+    hipStream_t st = (hipStream_t)stream;
+    const size_t n = batch << c->k;
+    if (n == 0) return SR_OK;
+    ProfScope ps(c, st, K_POINTWISE);
+    const dim3 gr(sr::p32::blocks_for(n)), bl(256);
+    if (op == 0) hipLaunchKernelGGL(sr::p32::elementwise32_kernel<0>, gr, bl, 0, st, l, r, n);
+    else if (op == 1) hipLaunchKernelGGL(sr::p32::elementwise32_kernel<1>, gr, bl, 0, st, l, r, n);
+    else hipLaunchKernelGGL(sr::p32::elementwise32_kernel<2>, gr, bl, 0, st, l, r, n);
+    HIP_TRY(hipGetLastError());
+    return SR_OK;
+}
+int sr_pointwise_mul_packed32_batch_dev(sr_ctx *c, uint32_t *l, const uint32_t *r, size_t batch, void *stream) {
+    return packed_elementwise(c, l, r, batch, stream, 0);
+}
+int sr_add_packed32_batch_dev(sr_ctx *c, uint32_t *l, const uint32_t *r, size_t batch, void *stream) {
+    return packed_elementwise(c, l, r, batch, stream, 1);
+}
+int sr_sub_packed32_batch_dev(sr_ctx *c, uint32_t *l, const uint32_t *r, size_t batch, void *stream) {
+    return packed_elementwise(c, l, r, batch, stream, 2);
+}
+int sr_ctx_plan_in_use(sr_ctx *c, sr_plan *plan, double probe_ms[2], size_t *probe_elems) {
+    if (!c || !plan) return fail(SR_E_INVALID, "null argument");
+    std::lock_guard<std::mutex> lk(c->mu);
+    *plan = c->plan;
+    if (!plan->lanes) plan->lanes = (uint32_t)c->lanes_choice;  // 0 = auto and not settled yet (no chunked product seen)
+    if (probe_ms) {
+        probe_ms[0] = c->lanes_probe_ms[0];
+        probe_ms[1] = c->lanes_probe_ms[1];
+    }
+    if (probe_elems) *probe_elems = c->lanes_probe_elems;
+    return SR_OK;
 }
 int sr_reduce_batch_dev(sr_ctx *c, const uint64_t *in, size_t in_len, uint64_t *out, size_t batch, void *stream) {
     if (int rc = check(c, in, out)) return rc;

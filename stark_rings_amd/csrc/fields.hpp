@@ -346,8 +346,11 @@ struct Goldilocks {
         asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(p2), "=s"(c) : "v"(al), "v"(bh), "v"(p1));
         const uint64_t p3 = (uint64_t)ah * bh + (p2 >> 32);  // <= 2^64 - 2^32
         uint32_t r0, r1;
-        // the move and the mad that make p3 stand between the write of c and its use as a borrow-in (2 wait states)
-        asm("v_subb_co_u32_e64 %0, %2, %3, %5, %6\n\t"
+        // gfx950 wants 2 wait states between the VALU write of the SGPR pair c and its use as a borrow-in.  The mad that makes p3
+        // (an input of this statement, and itself dependent on p2) is always in between: one of the two; the s_nop 0 is the other,
+        // so the distance no longer rests on what the scheduler happens to put there (tests/test_inline_asm_clobbers.py checks it).
+        asm("s_nop 0\n\t"
+            "v_subb_co_u32_e64 %0, %2, %3, %5, %6\n\t"
             "s_nop 1\n\t"
             "v_subb_co_u32_e64 %1, %2, %4, 0, %2"
             : "=&v"(r0), "=&v"(r1), "=&s"(bo)

@@ -89,6 +89,28 @@ template <class F> struct View<F, Packed> {
     }
 };
 
+// Packed words at the BOUNDARY (the opt-in packed-u32 entry points, sr_*_packed32_*: the caller's operands and results are bare
+// F::elem words -- for BabyBear the low half of the reference's Fp64 limb, babybear/mod.rs:18-26, whose upper half is always zero):
+// same width as the scratch view, but read once / written once per call, hence the non-temporal hint of the boundary view.
+struct PackedStream {};
+template <class F> struct View<F, PackedStream> {
+    typedef typename F::elem T;
+    static __device__ __forceinline__ typename F::elem ld(const T *p) {
+#if SR_RT_NT
+        return __builtin_nontemporal_load(p);
+#else
+        return *p;
+#endif
+    }
+    static __device__ __forceinline__ void st(T *p, const typename F::elem &v) {
+#if SR_RT_NT
+        __builtin_nontemporal_store(v, p);
+#else
+        *p = v;
+#endif
+    }
+};
+
 // the 15 twiddles of four merged stages starting at global stage s0 for a lane working in block blk0 of stage s0:
 // w[(1 << u) - 1 + i] = table[2^(s0+u) + (blk0 << u) + i], u = 0..3, i < 2^u.  The 2^u entries of stage s0 + u are
 // contiguous and 2^u-aligned, so they are fetched as ONE vector per 16 bytes (4-byte elements: 1 + 1 + 1 + 2 loads instead
@@ -541,15 +563,17 @@ inline int launch_cols256(const Hooks &hk, const typename View<F, VI>::T *src, t
                        xcd_grouped_tiles(blocks, kXcdGroup));
     return hipGetLastError() != hipSuccess;
 }
+// VB = the view of the caller's operands and results: Boundary (the reference's 8-byte words; every sr_* entry point) or
+// PackedStream (bare F::elem words; the sr_*_packed32_* entry points).
 // forward strided stages: boundary words at `src` -> packed words at `dst` (c >= 1)
-template <class F>
-inline int strided_fwd(const Hooks &hk, const typename F::storage *src, typename F::elem *dst, size_t npoly,
+template <class F, class VB = Boundary>
+inline int strided_fwd(const Hooks &hk, const typename View<F, VB>::T *src, typename F::elem *dst, size_t npoly,
                        const Params<F> &p, hipStream_t st) {
-    if (use_cols256(p)) return launch_cols256<F, 0, Boundary, Packed>(hk, src, dst, npoly, p, st);
+    if (use_cols256(p)) return launch_cols256<F, 0, VB, Packed>(hk, src, dst, npoly, p, st);
     int ms[8], s_lo = 0;
     const int n = plan(p.c, ms);
     for (int i = 0; i < n; i++) {
-        int rc = i == 0 ? launch_strided<F, 0, Boundary, Packed>(hk, ms[i], src, dst, s_lo, npoly, p, st)
+        int rc = i == 0 ? launch_strided<F, 0, VB, Packed>(hk, ms[i], src, dst, s_lo, npoly, p, st)
                         : launch_strided<F, 0, Packed, Packed>(hk, ms[i], dst, dst, s_lo, npoly, p, st);
         if (rc) return rc;
         s_lo += ms[i];
@@ -557,15 +581,15 @@ inline int strided_fwd(const Hooks &hk, const typename F::storage *src, typename
     return 0;
 }
 // inverse strided stages: packed words at `src` (clobbered) -> boundary words at `dst`
-template <class F>
-inline int strided_inv(const Hooks &hk, typename F::elem *src, typename F::storage *dst, size_t npoly, const Params<F> &p,
+template <class F, class VB = Boundary>
+inline int strided_inv(const Hooks &hk, typename F::elem *src, typename View<F, VB>::T *dst, size_t npoly, const Params<F> &p,
                        hipStream_t st) {
-    if (use_cols256(p)) return launch_cols256<F, 1, Packed, Boundary>(hk, src, dst, npoly, p, st);
+    if (use_cols256(p)) return launch_cols256<F, 1, Packed, VB>(hk, src, dst, npoly, p, st);
     int ms[8], s_lo = p.c;
     const int n = plan(p.c, ms);
     for (int i = n - 1; i >= 0; i--) {
         s_lo -= ms[i];
-        int rc = i == 0 ? launch_strided<F, 1, Packed, Boundary>(hk, ms[i], src, dst, s_lo, npoly, p, st)
+        int rc = i == 0 ? launch_strided<F, 1, Packed, VB>(hk, ms[i], src, dst, s_lo, npoly, p, st)
                         : launch_strided<F, 1, Packed, Packed>(hk, ms[i], src, src, s_lo, npoly, p, st);
         if (rc) return rc;
     }
@@ -586,32 +610,32 @@ inline int launch_rows(const Hooks &hk, const typename View<F, VI>::T *a, const 
     return hipGetLastError() != hipSuccess;
 }
 // scratch0 / scratch1: library-owned device buffers of batch * D elems each (only touched when c > 0)
-template <class F>
-inline int fwd(const Hooks &hk, typename F::storage *d, size_t batch, const Params<F> &p, typename F::elem *scratch0,
+template <class F, class VB = Boundary>
+inline int fwd(const Hooks &hk, typename View<F, VB>::T *d, size_t batch, const Params<F> &p, typename F::elem *scratch0,
                hipStream_t st) {
     if (batch == 0) return 0;
-    if (p.c == 0) return launch_rows<F, 0, Boundary, Boundary>(hk, d, nullptr, d, batch, p, st);
-    if (strided_fwd<F>(hk, d, scratch0, batch, p, st)) return 1;
-    return launch_rows<F, 0, Packed, Boundary>(hk, scratch0, nullptr, d, batch, p, st);
+    if (p.c == 0) return launch_rows<F, 0, VB, VB>(hk, d, nullptr, d, batch, p, st);
+    if (strided_fwd<F, VB>(hk, d, scratch0, batch, p, st)) return 1;
+    return launch_rows<F, 0, Packed, VB>(hk, scratch0, nullptr, d, batch, p, st);
 }
-template <class F>
-inline int inv(const Hooks &hk, typename F::storage *d, size_t batch, const Params<F> &p, typename F::elem *scratch0,
+template <class F, class VB = Boundary>
+inline int inv(const Hooks &hk, typename View<F, VB>::T *d, size_t batch, const Params<F> &p, typename F::elem *scratch0,
                hipStream_t st) {
     if (batch == 0) return 0;
-    if (p.c == 0) return launch_rows<F, 1, Boundary, Boundary>(hk, d, nullptr, d, batch, p, st);
-    if (launch_rows<F, 1, Boundary, Packed>(hk, d, nullptr, scratch0, batch, p, st)) return 1;
-    return strided_inv<F>(hk, scratch0, d, batch, p, st);
+    if (p.c == 0) return launch_rows<F, 1, VB, VB>(hk, d, nullptr, d, batch, p, st);
+    if (launch_rows<F, 1, VB, Packed>(hk, d, nullptr, scratch0, batch, p, st)) return 1;
+    return strided_inv<F, VB>(hk, scratch0, d, batch, p, st);
 }
 // p must carry the FUSED stage-0 constants.  a and b are only read; out may alias a.
-template <class F>
-inline int ring_mul(const Hooks &hk, typename F::storage *out, const typename F::storage *a, const typename F::storage *b,
+template <class F, class VB = Boundary>
+inline int ring_mul(const Hooks &hk, typename View<F, VB>::T *out, const typename View<F, VB>::T *a, const typename View<F, VB>::T *b,
                     size_t batch, const Params<F> &p, typename F::elem *scratch0, typename F::elem *scratch1, hipStream_t st) {
     if (batch == 0) return 0;
-    if (p.c == 0) return launch_rows<F, 2, Boundary, Boundary>(hk, a, b, out, batch, p, st);
-    if (strided_fwd<F>(hk, a, scratch0, batch, p, st)) return 1;
-    if (strided_fwd<F>(hk, b, scratch1, batch, p, st)) return 1;
+    if (p.c == 0) return launch_rows<F, 2, VB, VB>(hk, a, b, out, batch, p, st);
+    if (strided_fwd<F, VB>(hk, a, scratch0, batch, p, st)) return 1;
+    if (strided_fwd<F, VB>(hk, b, scratch1, batch, p, st)) return 1;
     if (launch_rows<F, 2, Packed, Packed>(hk, scratch0, scratch1, scratch0, batch, p, st)) return 1;
-    return strided_inv<F>(hk, scratch0, out, batch, p, st);
+    return strided_inv<F, VB>(hk, scratch0, out, batch, p, st);
 }
 
 }  // namespace rt

@@ -54,6 +54,19 @@ def _np_ptr(a):
     return a.ctypes.data_as(_lib.u64p)
 
 
+def _basis_words(basis, decompose):
+    """(lo, hi) 64-bit words of a decomposition basis (the reference takes b: u128, balanced_decomposition/mod.rs:62).  Anything
+    outside [0, 2^128) is refused instead of being truncated by ctypes.  decompose_balanced_in_place casts `b as i128` (mod.rs:73),
+    so a basis of 2^127 or more would be a NEGATIVE basis there; that case is refused here (and by the C ABI) rather than computed
+    with unsigned semantics the reference does not have.  Recomposition (`R::from(b)`, mod.rs:105-117) has no such cast."""
+    basis = int(basis)
+    if not 0 <= basis < 1 << 128:
+        raise RingError("basis out of the u128 range")
+    if decompose and basis >= 1 << 127:
+        raise RingError("basis >= 2^127: negative after the reference's `b as i128` (balanced_decomposition/mod.rs:73); not supported")
+    return basis & (2**64 - 1), basis >> 64
+
+
 class CyclotomicRing:
     """One ring configuration bound to one HIP device (the analogue of a `CyclotomicConfig` impl)."""
 
@@ -218,10 +231,8 @@ class CyclotomicRing:
         batch = self._batch_of(a.size)
         out = np.empty(max(batch * padding_size * self.words_per_elem, 1), dtype=np.uint64)
         src = a if a.size else np.zeros(1, dtype=np.uint64)
-        if not 0 <= basis < 1 << 128:
-            raise RingError("basis out of the u128 range")
-        self._check(self._lib.sr_decompose_balanced_batch_wide(self._ctx, _np_ptr(out), _np_ptr(src), basis & (2**64 - 1), basis >> 64,
-                                                               padding_size, batch))
+        lo, hi = _basis_words(basis, True)
+        self._check(self._lib.sr_decompose_balanced_batch_wide(self._ctx, _np_ptr(out), _np_ptr(src), lo, hi, padding_size, batch))
         return out[:batch * padding_size * self.words_per_elem]
 
     def gadget_recompose(self, digits, basis, padding_size):
@@ -232,8 +243,8 @@ class CyclotomicRing:
         batch_out = n // padding_size
         out = np.empty(max(batch_out * self.words_per_elem, 1), dtype=np.uint64)
         src = digits if digits.size else np.zeros(1, dtype=np.uint64)
-        self._check(self._lib.sr_recompose_batch_wide(self._ctx, _np_ptr(out), _np_ptr(src), basis & (2**64 - 1), basis >> 64,
-                                                      padding_size, batch_out))
+        lo, hi = _basis_words(basis, False)
+        self._check(self._lib.sr_recompose_batch_wide(self._ctx, _np_ptr(out), _np_ptr(src), lo, hi, padding_size, batch_out))
         return out[:batch_out * self.words_per_elem]
 
     # -- GadgetDecompose / GadgetRecompose for Matrix<R> and SparseMatrix<R> (balanced_decomposition/mod.rs:276-352) ------------
@@ -350,9 +361,84 @@ class CyclotomicRing:
             raise RingError("stream belongs to cuda:%d, this context to cuda:%d" % (s.device.index, self.device))
         return ctypes.c_void_p(s.cuda_stream)
 
+    # -- packed-u32 boundary (BabyBear power-of-two rings; include/stark_rings_hip.h "packed-u32 boundary") ------------------------
+    # A packed tensor holds the LOW HALF of every reference limb: int32 / uint32 CUDA tensors of batch * D words, the uint32
+    # (a * 2^64 mod p) of babybear/mod.rs:18-26's Fp64 -- same Montgomery residue, four bytes.
+    def _dev32(self, t):
+        if not (t.is_cuda and t.is_contiguous() and t.element_size() == 4):
+            raise RingError("expected a contiguous CUDA tensor of 4-byte integers (packed-u32 image)")
+        if t.device.index != self.device:
+            raise RingError("tensor lives on cuda:%d, this context on cuda:%d" % (t.device.index, self.device))
+        return ctypes.c_void_p(t.data_ptr()), t.numel()
+
+    def pack32_dev(self, out32, in64, stream=None):
+        """8-byte reference image -> packed image (low word of every limb; the input must be canonical)."""
+        po, n = self._dev32(out32)
+        pi, m = self._dev(in64)
+        if n != m:
+            raise RingError("operand lengths differ")
+        self._check(self._lib.sr_pack32_batch_dev(self._ctx, po, pi, self._batch_of(n), self._stream(stream)))
+        return out32
+
+    def unpack32_dev(self, out64, in32, stream=None):
+        po, n = self._dev(out64)
+        pi, m = self._dev32(in32)
+        if n != m:
+            raise RingError("operand lengths differ")
+        self._check(self._lib.sr_unpack32_batch_dev(self._ctx, po, pi, self._batch_of(n), self._stream(stream)))
+        return out64
+
+    def elementwise_crt_packed32_dev(self, t, stream=None):
+        p, n = self._dev32(t)
+        self._check(self._lib.sr_ntt_fwd_packed32_batch_dev(self._ctx, p, self._batch_of(n), self._stream(stream)))
+        return t
+
+    def elementwise_icrt_packed32_dev(self, t, stream=None):
+        p, n = self._dev32(t)
+        self._check(self._lib.sr_ntt_inv_packed32_batch_dev(self._ctx, p, self._batch_of(n), self._stream(stream)))
+        return t
+
+    def mul_packed32_dev(self, out, a, b, stream=None):
+        """out = a * b on packed images (RqPoly * &RqPoly, coeff_form.rs:250-258); a and b are only read; out may be a."""
+        po, n = self._dev32(out)
+        pa, m = self._dev32(a)
+        pb, q = self._dev32(b)
+        if not (n == m == q):
+            raise RingError("operand lengths differ")
+        self._check(self._lib.sr_ring_mul_packed32_batch_dev(self._ctx, po, pa, pb, self._batch_of(n), self._stream(stream)))
+        return out
+
+    def _ew32(self, fn, lhs, rhs, stream):
+        pl, n = self._dev32(lhs)
+        pr, m = self._dev32(rhs)
+        if n != m:
+            raise RingError("operand lengths differ")
+        self._check(fn(self._ctx, pl, pr, self._batch_of(n), self._stream(stream)))
+        return lhs
+
+    def ntt_mul_packed32_dev(self, lhs, rhs, stream=None):
+        return self._ew32(self._lib.sr_pointwise_mul_packed32_batch_dev, lhs, rhs, stream)
+
+    def add_packed32_dev(self, lhs, rhs, stream=None):
+        return self._ew32(self._lib.sr_add_packed32_batch_dev, lhs, rhs, stream)
+
+    def sub_packed32_dev(self, lhs, rhs, stream=None):
+        return self._ew32(self._lib.sr_sub_packed32_batch_dev, lhs, rhs, stream)
+
     def reserve_scratch(self, batch):
-        """sr_ctx_reserve_scratch: pre-size the operand scratch so that no later mul_dev of up to `batch` elements blocks."""
+        """sr_ctx_reserve_scratch: pre-size the operand scratch so that no later mul_dev of up to `batch` elements blocks.  With
+        sr_plan.lanes = 0 (auto) this is also where the library times its two plans once and keeps the faster (plan_in_use)."""
         self._check(self._lib.sr_ctx_reserve_scratch(self._ctx, int(batch)))
+
+    def plan_in_use(self):
+        """sr_ctx_plan_in_use: (plan, probe) -- the context's sr_plan with `lanes` resolved to what the library settled on (0 = auto,
+        not settled yet) and, when the library measured, {"two_lanes_ms", "one_stream_ms", "elems"} of its probe (else None)."""
+        plan = _lib.Plan()
+        ms = (ctypes.c_double * 2)()
+        n = ctypes.c_size_t(0)
+        self._check(self._lib.sr_ctx_plan_in_use(self._ctx, ctypes.byref(plan), ms, ctypes.byref(n)))
+        probe = {"two_lanes_ms": ms[0], "one_stream_ms": ms[1], "elems": int(n.value)} if n.value else None
+        return plan, probe
 
     def elementwise_crt_dev(self, t, stream=None):
         p, n = self._dev(t)
@@ -450,7 +536,8 @@ class CyclotomicRing:
         pa, m = self._dev(a)
         if n != m * padding_size:
             raise RingError("decompose: out must hold len * padding_size elements")
-        self._check(self._lib.sr_decompose_balanced_batch_wide_dev(self._ctx, po, pa, basis & (2**64 - 1), basis >> 64, padding_size,
+        lo, hi = _basis_words(basis, True)
+        self._check(self._lib.sr_decompose_balanced_batch_wide_dev(self._ctx, po, pa, lo, hi, padding_size,
                                                                   self._batch_of(m), self._stream(stream)))
         return out
 
@@ -464,7 +551,8 @@ class CyclotomicRing:
         pd, m = self._dev(digits)
         if m != n * padding_size:
             raise RingError("recompose: digits must hold len(out) * padding_size elements")
-        self._check(self._lib.sr_recompose_batch_wide_dev(self._ctx, po, pd, basis & (2**64 - 1), basis >> 64, padding_size,
+        lo, hi = _basis_words(basis, False)
+        self._check(self._lib.sr_recompose_batch_wide_dev(self._ctx, po, pd, lo, hi, padding_size,
                                                          self._batch_of(n), self._stream(stream)))
         return out
 

@@ -1,7 +1,7 @@
 """Every word of the BASELINE-sized batches against the oracle, in the driver-run GPU suite.
 
   C2 Goldilocks D = 2^16, batch 2^14     C3 BabyBear D = 2^16, batch 2^14     C5 Stark D = 2^12, batch 2^12
-      a * b, crt(a), icrt(crt(a)): every output word compared (adversarial patterns mixed into the batch: constant polynomials of
+      a * b, crt(a), icrt(crt(a)) and a * b with b handed over in NTT form (sr_ring_mul_ntt_rhs_batch_dev) and, for BabyBear, the product on the opt-in packed-u32 boundary: every output word compared (adversarial patterns mixed into the batch: constant polynomials of
       p - 1, 2^32 +- 1, (p +- 1) / 2, monomials, alternating extremes), and neither operand may be written.
   C4 Goldilocks D = 2^20, the per-GPU shard of 8192 elements (64 GiB per operand, generated on device): the fused product in
       place, 64 sampled elements against the oracle, every output canonical, icrt(crt(c)) == c on a sub-range.
@@ -24,8 +24,8 @@ import oracle_lib as O
 def test_every_word_of_the_baseline_batch(name, k, batch):
     import fuzz_full_parity as fz
 
-    bad, bad_crt, bad_icrt, written, _ = fz.run(name, k, batch)
-    assert (bad, bad_crt, bad_icrt, written) == (0, 0, 0, 0)
+    bad, bad_crt, bad_icrt, written, _, bad_rhs, bad_packed = fz.run(name, k, batch)
+    assert (bad, bad_crt, bad_icrt, written, bad_rhs, bad_packed) == (0, 0, 0, 0, 0, 0)
 
 
 def test_config4_shard_sampled_against_the_oracle():

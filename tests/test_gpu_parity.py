@@ -4,6 +4,8 @@ Shapes follow the reference's tests: literal KATs (stark_prime/ntt.rs:377-545), 
 (crt.rs:85-147), NTT-mul == schoolbook (stark_prime/mod.rs:161-177), crt(1) = 1 (mod.rs:125-137),
 reduce (mod.rs:139-159), plus ragged/edge batches.
 """
+import ctypes
+
 import numpy as np
 import pytest
 
@@ -1584,7 +1586,7 @@ def test_register_tiled_product_on_two_lanes(torch_cuda, name, k, batch, plan_kw
 
 
 @pytest.mark.parametrize("name,k", [("stark", 3), ("goldilocks", 4), ("babybear", 3), ("frog16", 0)])
-@pytest.mark.parametrize("basis", [1 << 64, (1 << 64) + 2, 3 * (1 << 70) + 6, 1 << 100, (1 << 128) - 2])
+@pytest.mark.parametrize("basis", [1 << 64, (1 << 64) + 2, 3 * (1 << 70) + 6, 1 << 100, (1 << 127) - 2])
 def test_decomposition_with_u128_bases(torch_cuda, name, k, basis):
     """decompose_balanced_in_place takes b: u128 (balanced_decomposition/mod.rs:62-117).  Bases of 2^64 and more through the _wide entry
     points against the big-integer model (oracle/pyref.py): for the 252-bit prime a real multi-digit decomposition, for the one-limb
@@ -1624,3 +1626,219 @@ def test_decomposition_with_u128_bases(torch_cuda, name, k, basis):
         from stark_rings_amd import RingError
         with pytest.raises(RingError, match="more than padding_size"):
             ring.gadget_decompose(O.to_mont(F, [p - 1 - (1 << 200)] + [0] * (d - 1)), basis, 1)
+
+
+def test_decomposition_basis_range_is_validated(torch_cuda):
+    """The reference takes b: u128 and casts it `as i128` (balanced_decomposition/mod.rs:62, 73): a basis of 2^127 or more is negative
+    there, so decomposition refuses it (mirror and C ABI alike) instead of computing something the reference does not; nothing outside
+    [0, 2^128) is silently truncated on its way through ctypes; recomposition (no cast in the reference) takes the whole u128 range."""
+    torch = torch_cuda
+    from stark_rings_amd import RingError
+    ring = ring_for("goldilocks", 4)
+    F = O.FIELD_ID["goldilocks"]
+    a = O.to_mont(F, list(range(16)))
+    ta = torch.from_numpy(a.view(np.int64)).cuda()
+    tout = torch.empty(2 * 16, dtype=torch.int64, device="cuda")
+    for bad in (-2, 1 << 128, (1 << 128) + 2):
+        with pytest.raises(RingError, match="u128"):
+            ring.gadget_decompose(a, bad, 2)
+        with pytest.raises(RingError, match="u128"):
+            ring.gadget_recompose(np.concatenate([a, a]), bad, 2)
+        with pytest.raises(RingError, match="u128"):
+            ring.gadget_decompose_dev(tout, ta, bad, 2)
+        with pytest.raises(RingError, match="u128"):
+            ring.gadget_recompose_dev(ta, tout, bad, 2)
+    for neg in (1 << 127, (1 << 128) - 2):
+        with pytest.raises(RingError, match="2\\^127"):
+            ring.gadget_decompose(a, neg, 2)
+        with pytest.raises(RingError, match="2\\^127"):
+            ring.gadget_decompose_dev(tout, ta, neg, 2)
+    # the C ABI refuses it as well (a caller that bypasses the mirror)
+    lib = ring._lib
+    out = np.zeros(32, dtype=np.uint64)
+    rc = lib.sr_decompose_balanced_batch_wide(ring._ctx, out.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64)),
+                                              a.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64)), 0, 1 << 63, 2, 1)
+    assert rc != 0
+    # recomposition: basis (2^128 - 2) mod p through R::from(b)
+    digits = np.concatenate([a, a])
+    p = P.PRIMES["goldilocks"][0]
+    got = O.from_mont(F, ring.gadget_recompose(digits, (1 << 128) - 2, 2))
+    assert list(got) == [(i + ((1 << 128) - 2) % p * i) % p for i in range(16)]
+
+
+
+
+def test_baseline_config0_literally(torch_cuda):
+    """BASELINE.json configs[0]: Goldilocks, D = 2^10, batch = 1 -- one ring product through the HOST entry point
+    (sr_ring_mul_batch, the plumbing case) and through the device entry point, bit for bit against the oracle; crt / icrt of the
+    single element as well (crt.rs:58-74 on one element)."""
+    torch = torch_cuda
+    F = O.GOLDILOCKS
+    k, d = 10, 1024
+    ring = ring_for("goldilocks", k)
+    a = O.fill_uniform(F, 0x5EED0001, 0, d)
+    b = O.fill_uniform(F, 0x5EED0002, 0, d)
+    want = O.pow2_ring_mul(F, a, b, k, 1)
+    got = ring.mul(a.copy(), b)
+    assert np.array_equal(got, want)
+    ta, tb = torch.from_numpy(a.view(np.int64)).cuda(), torch.from_numpy(b.view(np.int64)).cuda()
+    out = torch.empty_like(ta)
+    ring.mul_dev(out, ta, tb)
+    torch.cuda.synchronize()
+    assert np.array_equal(out.cpu().numpy().view(np.uint64), want)
+    assert np.array_equal(ta.cpu().numpy().view(np.uint64), a) and np.array_equal(tb.cpu().numpy().view(np.uint64), b)
+    fa = ring.elementwise_crt(a.copy())
+    assert np.array_equal(fa, O.pow2_fwd(F, a, k, 1))
+    assert np.array_equal(ring.elementwise_icrt(fa), a)
+
+
+def test_library_settles_the_lanes_plan_itself(torch_cuda):
+    """sr_plan.lanes = 0 is AUTO: with six more streams alive in the process (what a framework or RCCL adds, and what used to push both
+    lanes onto one hardware queue) the library times two lanes against one stream inside sr_ctx_reserve_scratch, keeps the faster and
+    says so through sr_ctx_plan_in_use; the product then runs at the winner's pace and is bit-exact either way."""
+    torch = torch_cuda
+    import time
+    from stark_rings_amd import CyclotomicRing
+    from stark_rings_amd._lib import Plan
+
+    extra = [torch.cuda.Stream() for _ in range(6)]
+    x = torch.zeros(1 << 20, device="cuda")
+    for s in extra:       # make every one of them a live queue user
+        with torch.cuda.stream(s):
+            x.add_(1)
+    torch.cuda.synchronize()
+    k, batch = 16, 2048
+    ring = CyclotomicRing("goldilocks", k, plan=Plan())
+    plan0, probe0 = ring.plan_in_use()
+    assert plan0.lanes == 0 and probe0 is None           # not settled before the first chunked product / reserve
+    ring.reserve_scratch(batch)
+    plan, probe = ring.plan_in_use()
+    assert plan.lanes in (1, 2) and probe is not None and probe["elems"] == 2048
+    assert (plan.lanes == 2) == (probe["two_lanes_ms"] <= probe["one_stream_ms"])
+    F = O.GOLDILOCKS
+    d = 1 << k
+    ta = torch.empty(batch * d, dtype=torch.int64, device="cuda")
+    tb = torch.empty(batch * d, dtype=torch.int64, device="cuda")
+    ring.fill_uniform_dev(ta, 0x77, 0)
+    ring.fill_uniform_dev(tb, 0x78, 0)
+    out = torch.empty_like(ta)
+    ring.mul_dev(out, ta, tb)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(4):
+        ring.mul_dev(out, ta, tb)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / 4 * 1e3
+    best = min(probe["two_lanes_ms"], probe["one_stream_ms"])
+    worst = max(probe["two_lanes_ms"], probe["one_stream_ms"])
+    assert ms < 1.25 * best, (ms, probe)                 # the plan in use is the one the probe found faster ...
+    sample = [0, 1, 777, batch - 1]
+    ea = np.concatenate([O.fill_uniform(F, 0x77, e * d, d) for e in sample])
+    eb = np.concatenate([O.fill_uniform(F, 0x78, e * d, d) for e in sample])
+    want = O.pow2_ring_mul(F, ea, eb, k, len(sample), 4)
+    for i, e in enumerate(sample):
+        assert np.array_equal(out[e * d:(e + 1) * d].cpu().numpy().view(np.uint64), want[i * d:(i + 1) * d])
+    # ... and an explicit plan is honoured and reported without a probe
+    for lanes in (1, 2):
+        pl = Plan()
+        pl.lanes = lanes
+        r2 = CyclotomicRing("goldilocks", k, plan=pl)
+        r2.reserve_scratch(batch)
+        p2, pr2 = r2.plan_in_use()
+        assert p2.lanes == lanes and pr2 is None
+        o2 = torch.empty_like(ta)
+        r2.mul_dev(o2, ta, tb)
+        torch.cuda.synchronize()
+        assert torch.equal(o2, out)
+        r2.close()
+    ring.close()
+    del extra, worst
+
+
+@pytest.mark.parametrize("k,batch", [(0, 7), (4, 5), (10, 37), (12, 5), (13, 3), (14, 2), (16, 5), (17, 1)])
+def test_babybear_packed32_boundary_matches_the_oracle(torch_cuda, k, batch):
+    """BASELINE configs[2] says "packed 32-bit modmul": the opt-in sr_*_packed32_* entry points take the low half of the reference's
+    Fp64 limb (babybear/mod.rs:18-26: a * 2^64 mod p < 2^31 in a u64) as a uint32.  Against the oracle on the 8-byte images:
+    unpack(f_packed(pack(x))) == f(x) for the ring product, crt, icrt, slot product, add and sub; operands are never written;
+    pack / unpack are inverse on canonical images.  D < 4096 takes the widened route, D >= 4096 the register-tiled kernels on
+    packed words (k = 12 one launch, 13 / 14 / 17 strided passes, 16 the cols256 + rows256 pair)."""
+    torch = torch_cuda
+    F = O.BABYBEAR
+    ring = ring_for("babybear", k)
+    n = batch << k
+    a = edge_and_random(F, k, batch, 0xC0 + k)
+    b = O.fill_uniform(F, 0xD0 + k, 0, n)
+    assert int(a.max()) < (1 << 31) and int(b.max()) < (1 << 31)
+
+    def pack(x64):
+        t64 = torch.from_numpy(x64.view(np.int64)).cuda()
+        t32 = torch.full((x64.size,), -1, dtype=torch.int32, device="cuda")
+        ring.pack32_dev(t32, t64)
+        return t32
+
+    def unpack(t32):
+        t64 = torch.full((t32.numel(),), -1, dtype=torch.int64, device="cuda")
+        ring.unpack32_dev(t64, t32)
+        torch.cuda.synchronize()
+        return t64.cpu().numpy().view(np.uint64)
+
+    pa, pb = pack(a), pack(b)
+    assert np.array_equal(pa.cpu().numpy().view(np.uint32), a.astype(np.uint32))
+    assert np.array_equal(unpack(pa), a) and np.array_equal(unpack(pb), b)
+    # ring product, out of place and in place over a
+    out = torch.full_like(pa, -1)
+    ring.mul_packed32_dev(out, pa, pb)
+    want = O.pow2_ring_mul(F, a, b, k, batch)
+    assert np.array_equal(unpack(out), want), "packed ring product"
+    assert np.array_equal(unpack(pa), a) and np.array_equal(unpack(pb), b), "operands written"
+    pa2 = pa.clone()
+    ring.mul_packed32_dev(pa2, pa2, pb)
+    assert np.array_equal(unpack(pa2), want), "packed ring product in place"
+    # transforms
+    fa = pa.clone()
+    ring.elementwise_crt_packed32_dev(fa)
+    want_f = O.pow2_fwd(F, a, k, batch)
+    assert np.array_equal(unpack(fa), want_f), "packed crt"
+    back = fa.clone()
+    ring.elementwise_icrt_packed32_dev(back)
+    assert np.array_equal(unpack(back), a), "packed icrt(crt)"
+    ib = pb.clone()
+    ring.elementwise_icrt_packed32_dev(ib)
+    assert np.array_equal(unpack(ib), O.pow2_inv(F, b, k, batch)), "packed icrt"
+    # slot product and sums
+    fb = pack(O.pow2_fwd(F, b, k, batch))
+    prod = fa.clone()
+    ring.ntt_mul_packed32_dev(prod, fb)
+    assert np.array_equal(unpack(prod), O.pow2_pointwise(F, want_f, O.pow2_fwd(F, b, k, batch))), "packed slot product"
+    s_ = pa.clone()
+    ring.add_packed32_dev(s_, pb)
+    p = P.PRIMES["babybear"][0]
+    m = min(n, 2048)          # the oracle's integers on a prefix, the 8-byte entry points on everything
+    av, bv = O.from_mont(F, a[:m]), O.from_mont(F, b[:m])
+    assert np.array_equal(unpack(s_)[:m], O.to_mont(F, [(x + y) % p for x, y in zip(av, bv)])), "packed add vs integers"
+    d_ = pa.clone()
+    ring.sub_packed32_dev(d_, pb)
+    ta, tb = torch.from_numpy(a.view(np.int64)).cuda(), torch.from_numpy(b.view(np.int64)).cuda()
+    ring.add_dev(ta, tb)       # the 8-byte entry points (themselves checked against the oracle elsewhere) as the wide reference
+    torch.cuda.synchronize()
+    assert np.array_equal(unpack(s_), ta.cpu().numpy().view(np.uint64)), "packed add"
+    ta = torch.from_numpy(a.view(np.int64)).cuda()
+    ring.sub_dev(ta, tb)
+    torch.cuda.synchronize()
+    assert np.array_equal(unpack(d_), ta.cpu().numpy().view(np.uint64)), "packed sub"
+
+
+def test_packed32_entry_points_refuse_other_rings(torch_cuda):
+    torch = torch_cuda
+    from stark_rings_amd import RingError
+    ring = ring_for("goldilocks", 4)
+    t32 = torch.zeros(16, dtype=torch.int32, device="cuda")
+    t64 = torch.zeros(16, dtype=torch.int64, device="cuda")
+    with pytest.raises(RingError, match="BabyBear"):
+        ring.pack32_dev(t32, t64)
+    with pytest.raises(RingError, match="BabyBear"):
+        ring.mul_packed32_dev(t32, t32.clone(), t32.clone())
+    bb = ring_for("babybear", 4)
+    with pytest.raises(RingError, match="alias"):
+        bb.mul_packed32_dev(t32, t32.clone(), t32)
+

@@ -53,3 +53,54 @@ def test_inline_asm_declares_scc_and_vcc_clobbers():
     fields = open(os.path.join(ROOT, "stark_rings_amd", "csrc", "fields.hpp")).read()
     assert ': "scc");' in fields
     assert _violations(fields.replace(': "scc");', ');'))[0]
+
+
+def test_sgpr_carry_reaches_its_reader_after_two_wait_states(tmp_path):
+    """Goldilocks::mul hands the middle carry from a v_mad_u64_u32 (SGPR-pair carry-out) to a v_subb_co_u32 (borrow-in) in ANOTHER
+    asm statement; gfx950 wants 2 wait states between a VALU write of an SGPR and a VALU read of it, and the compiler's hazard
+    recogniser does not look inside inline asm.  Compile a kernel with sixteen independent products (room for the scheduler to
+    reorder), and measure the distance in the generated ISA: every SGPR pair written as a carry-out by v_mad_u64_u32 and read as a
+    borrow-in by v_subb_co_u32 must have two wait states (instructions, or s_nop N = N + 1) in between."""
+    import shutil
+    import subprocess
+
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        import pytest
+        pytest.skip("hipcc not available")
+    src = tmp_path / "mul16.hip"
+    src.write_text('#include "%s"\n'
+                   "__global__ void mul16(uint64_t *x, const uint64_t *w) {\n"
+                   "    uint64_t v[16];\n"
+                   "#pragma unroll\n"
+                   "    for (int i = 0; i < 16; i++) v[i] = x[threadIdx.x + 256 * i];\n"
+                   "#pragma unroll\n"
+                   "    for (int i = 0; i < 16; i++) v[i] = sr::Goldilocks::mul(v[i], w[16 * threadIdx.x + i]);\n"
+                   "#pragma unroll\n"
+                   "    for (int i = 0; i < 16; i++) x[threadIdx.x + 256 * i] = sr::Goldilocks::mul(v[i], v[(i + 1) & 15]);\n"
+                   "}\n" % os.path.join(ROOT, "stark_rings_amd", "csrc", "fields.hpp"))
+    out = tmp_path / "mul16.s"
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "--cuda-device-only", "-S", "-o", str(out), str(src)])
+    lines = []
+    for ln in out.read_text().split("\n"):
+        m = re.match(r"\s+([sv]_[a-z0-9_]+)\s*(.*?)(\s*;.*)?$", ln)
+        if m:
+            lines.append((m.group(1), m.group(2)))
+    pairs = 0
+    for i, (op, args) in enumerate(lines):
+        if op != "v_mad_u64_u32":
+            continue
+        m = re.match(r"v\[\d+:\d+\],\s*(s\[\d+:\d+\])", args)
+        if not m:
+            continue  # carry-out to vcc: compiler-generated, the compiler's own hazard handling applies
+        sg = m.group(1)
+        waits = 0
+        for op2, args2 in lines[i + 1:]:
+            if op2.startswith("v_subb_co_u32") and args2.rstrip().endswith(sg):
+                assert waits >= 2, "only %d wait state(s) between the write of %s and its use as a borrow-in" % (waits, sg)
+                pairs += 1
+                break
+            if re.search(r"\b%s\b" % re.escape(sg), args2) and not op2.startswith("s_nop"):
+                break  # the pair is re-used for something else first: not the pattern under test
+            waits += int(args2.strip() or 0) + 1 if op2 == "s_nop" else 1
+    assert pairs >= 32, "expected the 32 products' carries in the listing, found %d" % pairs

@@ -1,9 +1,10 @@
 #!/bin/bash
 # On the GPU box: the four rocprofv3 passes per workload, summarised THERE (the raw counter CSVs of the two-lane plans run to hundreds
 # of MB); only the summaries and truncated raw copies come back under gpurun_out/profiles_rNN/.
-#   gpurun -- 'bash tools/collect_profiles.sh r02'   then   cp gpurun_out/profiles_r02/* profiles/r02/
+#   gpurun -- 'bash tools/collect_profiles.sh r03'   then   cp gpurun_out/profiles_r03/* profiles/r03/
 set -e
-rnd=${1:-r02}
+export GPU_MAX_HW_QUEUES=${GPU_MAX_HW_QUEUES:-8}   # must be in the profiled process's environment before the profiler initialises HIP
+rnd=${1:-r03}
 root=$(pwd)
 out=$root/gpurun_out/profiles_$rnd
 rm -rf $out; mkdir -p $out
@@ -13,8 +14,8 @@ for w in goldilocks_d65536_b16384 babybear_d65536_b16384 stark_d4096_b4096 goldi
   python3 tools/profile_workload.py summarize /tmp/prof_$w $w $out | tail -3
   rm -rf /tmp/prof_$w
 done
-# the headline workload once more on ONE stream (sr_plan.lanes = 1 through the Python helper's SR_LANES): exclusive kernel durations
+# the headline workload once more on ONE stream (bench.py --lanes 1 = sr_plan.lanes = 1): exclusive kernel durations
 mkdir -p /tmp/prof_one && cd /tmp && export TMPDIR=/tmp
-SR_LANES=1 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_one/t -o p -- python3 $root/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-calibration > $out/bench_one_stream_under_trace.json 2> /tmp/prof_one/err.txt
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_one/t -o p -- python3 $root/bench.py --steps 3 --warmup 1 --no-cpu-baseline --lanes 1 > $out/bench_one_stream_under_trace.json 2> /tmp/prof_one/err.txt
 find /tmp/prof_one -name "*kernel_stats.csv" -exec cp {} $out/kernel_stats_goldilocks_d65536_b16384_one_stream.csv \;
 ls -la $out | head -40

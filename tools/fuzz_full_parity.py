@@ -47,7 +47,8 @@ def adversarial_batch(name, k, batch):
 
 
 def run(name, k, batch, threads=None):
-    """returns (mismatching words of a * b, of crt(a), of icrt(crt(a)), operands written?, oracle seconds)"""
+    """returns (mismatching words of a * b, of crt(a), of icrt(crt(a)), operands written?, oracle seconds, mismatching words of the
+    product with b handed over in NTT form, mismatching words of the packed-u32 product (BabyBear only))"""
     import numpy as np
     import torch
 
@@ -67,6 +68,29 @@ def run(name, k, batch, threads=None):
     ring.mul_dev(out, ta, tb)
     torch.cuda.synchronize()
     bad = int((out.cpu().numpy().view(np.uint64) != want).sum())
+    # the constant-operand product (b kept in NTT form: its own fused kernel and lanes path on the tuned Goldilocks plan): every word too
+    tbn = tb.clone()
+    ring.elementwise_crt_dev(tbn)
+    out.fill_(-1)
+    ring.mul_ntt_rhs_dev(out, ta, tbn)
+    torch.cuda.synchronize()
+    bad_rhs = int((out.cpu().numpy().view(np.uint64) != want).sum())
+    del tbn
+    bad_packed = 0
+    if name == "babybear":  # the opt-in packed-u32 boundary: pack, multiply on packed words, unpack -- every word again
+        pa = torch.empty(ta.numel(), dtype=torch.int32, device="cuda")
+        pb = torch.empty_like(pa)
+        ring.pack32_dev(pa, ta)
+        ring.pack32_dev(pb, tb)
+        po = torch.full_like(pa, -1)
+        ring.mul_packed32_dev(po, pa, pb)
+        ring.unpack32_dev(out, po)
+        torch.cuda.synchronize()
+        bad_packed = int((out.cpu().numpy().view(np.uint64) != want).sum())
+        ring.unpack32_dev(out, pa)      # the packed operands must come back untouched as well
+        torch.cuda.synchronize()
+        bad_packed += int((out.cpu().numpy().view(np.uint64) != a).sum())
+        del pa, pb, po
     del want, out
     written = int((tb.cpu().numpy().view(np.uint64) != b).sum()) + int((ta.cpu().numpy().view(np.uint64) != a).sum())
     del tb
@@ -77,14 +101,15 @@ def run(name, k, batch, threads=None):
     ring.elementwise_icrt_dev(ta)
     bad3 = int((ta.cpu().numpy().view(np.uint64) != a).sum())
     ring.close()
-    return bad, bad2, bad3, written, t1 - t0
+    return bad, bad2, bad3, written, t1 - t0, bad_rhs, bad_packed
 
 
 if __name__ == "__main__":
     name = sys.argv[1] if len(sys.argv) > 1 else "goldilocks"
     k = int(sys.argv[2]) if len(sys.argv) > 2 else 16
     batch = int(sys.argv[3]) if len(sys.argv) > 3 else 1 << 12
-    bad, bad2, bad3, written, secs = run(name, k, batch)
+    bad, bad2, bad3, written, secs, bad_rhs, bad_packed = run(name, k, batch)
     print("%s D=2^%d batch %d: oracle %.1f s; mismatching words: %d" % (name, k, batch, secs, bad))
-    print("crt mismatches %d, icrt(crt) mismatches %d, operand words written %d" % (bad2, bad3, written))
-    sys.exit(1 if (bad or bad2 or bad3 or written) else 0)
+    print("crt mismatches %d, icrt(crt) mismatches %d, operand words written %d, ntt-rhs product mismatches %d, packed-u32 mismatches %d"
+          % (bad2, bad3, written, bad_rhs, bad_packed))
+    sys.exit(1 if (bad or bad2 or bad3 or written or bad_rhs or bad_packed) else 0)

@@ -36,12 +36,28 @@ def collect(workload, outdir, steps):
     os.makedirs(outdir, exist_ok=True)
     for old in glob.glob(os.path.join(outdir, "*.csv")):  # never summarise a previous build's counters as this one's
         os.remove(old)
-    env = dict(os.environ, TMPDIR="/tmp")
+    # GPU_MAX_HW_QUEUES: bench.py's own os.environ.setdefault runs inside python3, AFTER the profiler's preloaded library has
+    # initialised the GPU (with --pmc it has), so the profiled process must find it in its environment already.
+    env = dict(os.environ, TMPDIR="/tmp", GPU_MAX_HW_QUEUES=os.environ.get("GPU_MAX_HW_QUEUES", "8"))
+    # The library picks its plan itself (sr_plan.lanes = 0) with a probe whose launches have other sizes than the timed ones.  Ask a
+    # plain run which plan that is, then pin it (--lanes) in the profiled runs: they carry the timed configuration's launches only.
+    lanes = []
+    try:
+        line = subprocess.run(["python3", os.path.join(ROOT, "bench.py"), "--workload", workload, "--steps", "1", "--warmup", "1",
+                               "--no-cpu-baseline"], env=env, capture_output=True, text=True, cwd="/tmp").stdout
+        plan = json.loads([ln for ln in line.splitlines() if ln.startswith("{")][-1])["config"]["plan"]
+        if "auto): two lanes" in plan:
+            lanes = ["--lanes", "2"]
+        elif "auto): one stream" in plan:
+            lanes = ["--lanes", "1"]
+        print("library plan: %s -> profiled with %s" % (plan, lanes or "no pin (no chunked plan)"), flush=True)
+    except (IndexError, ValueError, KeyError):
+        print("could not read the library's plan; profiling the default", flush=True)
     for name, flags in PASSES.items():
         d = os.path.join(outdir, name)
         shutil.rmtree(d, ignore_errors=True)
         cmd = ["rocprofv3"] + flags + ["--output-format", "csv", "-d", d, "-o", "p", "--", "python3", os.path.join(ROOT, "bench.py"),
-               "--workload", workload, "--steps", str(steps if name == "trace" else 2), "--warmup", "1", "--no-cpu-baseline", "--no-calibration"]
+               "--workload", workload, "--steps", str(steps if name == "trace" else 2), "--warmup", "1", "--no-cpu-baseline"] + lanes
         print("+", " ".join(cmd), flush=True)
         with open(os.path.join(outdir, name + ".bench.json"), "w") as fo, open(os.path.join(outdir, name + ".err"), "w") as fe:
             rc = subprocess.call(cmd, env=env, stdout=fo, stderr=fe, cwd="/tmp")
@@ -172,7 +188,15 @@ def summarize(indir, workload, outdir):
             valu.setdefault(t, []).append((waves, vpw))
         md.append("| `%s` | %s | %.2f | %.2f | %d | %.0f | %.0f |" % (kname.split("(")[0].replace("void ", ""), t, f / 2**30, w / 2**30, waves, vpw, spw))
     commit = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
-    pj = {"workload": workload, "batch": batch, "source_sha256": bench.source_hash(), "commit": commit,
+    # launches per step and tag of the run the counters come from (bench.py's own line from inside the SQ pass): per-launch figures are
+    # only replayed into a run that cuts its batch into the same launches (the same plan)
+    lps = None
+    try:
+        bl = json.load(open(os.path.join(indir, "pmc_SQ.bench.json")))
+        lps = bl["roofline"].get("launches_per_step_by_kernel")
+    except (OSError, ValueError, KeyError):
+        pass
+    pj = {"workload": workload, "batch": batch, "source_sha256": bench.source_hash(), "commit": commit, "launches_per_step": lps,
           "unit": "bytes of HBM traffic per launch, 2 * FETCH_SIZE + WRITE_SIZE (MI355X_MICROARCH.md: FETCH_SIZE counts half of a streaming read on gfx950); a tag with several passes per transform sums them",
           "bytes_per_launch": {t: int(sum(v)) if t != "rows" and len(v) > 1 else int(sum(v) / len(v)) for t, v in bytes_per_launch.items()},
           "valu": {t: {"waves_per_launch": int(sum(w for w, _ in v) / len(v)), "valu_per_wave": round(sum(x for _, x in v) / len(v), 1)}
