@@ -34,6 +34,17 @@
 //                                        sparse_matrix.rs:158-200      short input throw
 //   monomial / unit_monomial / psi /     crates/ring/src/            same names; BaseRing scalars are passed as their signed representative
 //     exp / exp_signed / psi_range_check monomial.rs:17-93             (Zq::center and sign, ring.rs:160-181) in an int64_t
+//   decompose basis `b: u128`            balanced_decomposition/     every gadget function takes `u128` (unsigned __int128); 2^127 and above
+//                                        mod.rs:62,73                  is refused for decomposition (negative after the reference's `as i128`)
+//   DecomposeToVec for &[R] / Vec<R>     mod.rs:119-161              decompose_to_vec(v, b, k) -> std::vector<RqPolyVec> (one Vec<R> per element)
+//   GadgetDecompose / GadgetRecompose    mod.rs:208-352              class MatrixPoly / SparseMatrixPoly: gadget_decompose (n x m -> n x k m;
+//     for &[(R, usize)], Matrix<R>,                                    sparse entries (e, c) -> (digit_i, c k + i), zero digits dropped),
+//     SparseMatrix<R>                                                  gadget_recompose; sparse_row_gadget_decompose / _recompose for one row
+//   Cyclotomic::rot / into_rot_iter /    traits.rs:54-91             rot(RqPolyVec&) (every element times X), Rotation, into_rot_iter(v)
+//     Rotation
+//   (one context per GPU of a node)      SURVEY 8b / 8e              class ContextGroup: sr_ctx_create_group + sr_shard_range
+//   (device-resident batches)            --                          CyclotomicConfig::*_dev(device pointers, stream), reserve_scratch,
+//                                                                      plan_in_use, and the packed-u32 BabyBear forms (*_packed32_dev)
 //
 // What is deliberately narrowed: ring elements of degree 2^16 are 512 KiB, so the per-element `Copy` value type of
 // the reference (ring.rs:13-15) is not mirrored; the drop-in seam is the batch (hard part 4).
@@ -62,6 +73,13 @@ public:
         check(sr_ctx_degree(c, &degree_), "sr_ctx_degree");
         check(sr_ctx_limbs(c, &limbs_), "sr_ctx_limbs");
     }
+    // adopts a context created elsewhere (ContextGroup); `owned` contexts are destroyed with the last copy
+    CyclotomicConfig(sr_ring ring, sr_ctx *adopt) : ring_(ring) {
+        ctx_.reset(adopt, [](sr_ctx *p) { sr_ctx_destroy(p); });
+        check(sr_ctx_degree(adopt, &degree_), "sr_ctx_degree");
+        check(sr_ctx_limbs(adopt, &limbs_), "sr_ctx_limbs");
+    }
+    sr_ring ring() const { return ring_; }
     size_t dimension() const { return degree_; }            // PolyRing::dimension()
     int limbs() const { return limbs_; }                    // N
     size_t words_per_elem() const { return degree_ * (size_t)limbs_; }
@@ -99,6 +117,51 @@ public:
     }
     static void check(int rc, const char *what) {
         if (rc != SR_OK) throw std::runtime_error(std::string(what) + ": " + sr_last_error_string());
+    }
+
+    // ---- device-resident batches: pointers are HIP device pointers, `stream` a hipStream_t (as void *: no HIP header needed here),
+    //      every call is asynchronous on that stream (include/stark_rings_hip.h, "device-resident entry points") ----
+    void reserve_scratch(size_t batch) const { check(sr_ctx_reserve_scratch(raw(), batch), "reserve_scratch"); }
+    // the plan the library settled on (lanes: 0 = auto and not settled yet, 1 = one stream, 2 = two lanes); probe_ms / probe_elems optional
+    sr_plan plan_in_use(double probe_ms[2] = nullptr, size_t *probe_elems = nullptr) const {
+        sr_plan p{};
+        check(sr_ctx_plan_in_use(raw(), &p, probe_ms, probe_elems), "plan_in_use");
+        return p;
+    }
+    void elementwise_crt_dev(uint64_t *d, size_t batch, void *stream) const { check(sr_ntt_fwd_batch_dev(raw(), d, batch, stream), "elementwise_crt_dev"); }
+    void elementwise_icrt_dev(uint64_t *d, size_t batch, void *stream) const { check(sr_ntt_inv_batch_dev(raw(), d, batch, stream), "elementwise_icrt_dev"); }
+    void ntt_mul_dev(uint64_t *lhs, const uint64_t *rhs, size_t batch, void *stream) const {
+        check(sr_pointwise_mul_batch_dev(raw(), lhs, rhs, batch, stream), "ntt_mul_dev");
+    }
+    void add_dev(uint64_t *lhs, const uint64_t *rhs, size_t batch, void *stream) const { check(sr_add_batch_dev(raw(), lhs, rhs, batch, stream), "add_dev"); }
+    void sub_dev(uint64_t *lhs, const uint64_t *rhs, size_t batch, void *stream) const { check(sr_sub_batch_dev(raw(), lhs, rhs, batch, stream), "sub_dev"); }
+    // out = a * b (RqPoly * &RqPoly); a, b only read; out may alias a
+    void mul_dev(uint64_t *out, const uint64_t *a, const uint64_t *b, size_t batch, void *stream) const {
+        check(sr_ring_mul_batch_dev(raw(), out, a, b, batch, stream), "mul_dev");
+    }
+    void mul_ntt_rhs_dev(uint64_t *out, const uint64_t *a, const uint64_t *b_ntt, size_t batch, void *stream) const {
+        check(sr_ring_mul_ntt_rhs_batch_dev(raw(), out, a, b_ntt, batch, stream), "mul_ntt_rhs_dev");
+    }
+    void rot_dev(uint64_t *out, const uint64_t *in, size_t batch, void *stream) const { check(sr_rot_batch_dev(raw(), out, in, batch, stream), "rot_dev"); }
+    void matvec_dev(uint64_t *y, const uint64_t *m, const uint64_t *v, size_t nrows, size_t ncols, void *stream) const {
+        check(sr_matvec_ntt_dev(raw(), y, m, v, nrows, ncols, stream), "matvec_dev");
+    }
+    void matmul_dev(uint64_t *y, const uint64_t *a, const uint64_t *b, size_t n, size_t m, size_t p, void *stream) const {
+        check(sr_matmul_ntt_dev(raw(), y, a, b, n, m, p, stream), "matmul_dev");
+    }
+    void gadget_decompose_dev(uint64_t *out, const uint64_t *in, unsigned __int128 b, size_t padding_size, size_t batch, void *stream) const {
+        check(sr_decompose_balanced_batch_wide_dev(raw(), out, in, (uint64_t)b, (uint64_t)(b >> 64), padding_size, batch, stream), "gadget_decompose_dev");
+    }
+    void gadget_recompose_dev(uint64_t *out, const uint64_t *in, unsigned __int128 b, size_t padding_size, size_t batch_out, void *stream) const {
+        check(sr_recompose_batch_wide_dev(raw(), out, in, (uint64_t)b, (uint64_t)(b >> 64), padding_size, batch_out, stream), "gadget_recompose_dev");
+    }
+    // packed-u32 BabyBear boundary (the low half of the reference's Fp64 limb, babybear/mod.rs:18-26)
+    void pack32_dev(uint32_t *out, const uint64_t *in, size_t batch, void *stream) const { check(sr_pack32_batch_dev(raw(), out, in, batch, stream), "pack32_dev"); }
+    void unpack32_dev(uint64_t *out, const uint32_t *in, size_t batch, void *stream) const { check(sr_unpack32_batch_dev(raw(), out, in, batch, stream), "unpack32_dev"); }
+    void elementwise_crt_packed32_dev(uint32_t *d, size_t batch, void *stream) const { check(sr_ntt_fwd_packed32_batch_dev(raw(), d, batch, stream), "crt_packed32"); }
+    void elementwise_icrt_packed32_dev(uint32_t *d, size_t batch, void *stream) const { check(sr_ntt_inv_packed32_batch_dev(raw(), d, batch, stream), "icrt_packed32"); }
+    void mul_packed32_dev(uint32_t *out, const uint32_t *a, const uint32_t *b, size_t batch, void *stream) const {
+        check(sr_ring_mul_packed32_batch_dev(raw(), out, a, b, batch, stream), "mul_packed32_dev");
     }
 
 private:
@@ -205,27 +268,181 @@ inline RqNTTVec RqPolyVec::elementwise_crt() && {
 // GadgetDecompose for &[R] / Vec<R> (balanced_decomposition/mod.rs:163-175, 192-198): len * padding_size elements, digit j of
 // element e at index e * padding_size + j.  The reference panics on basis 0, 1 or odd and when padding_size digits do not
 // suffice; std::runtime_error here.
-inline RqPolyVec gadget_decompose(const RqPolyVec &v, uint64_t b, size_t padding_size) {
+typedef unsigned __int128 u128;  // the reference's basis type (decompose_balanced_in_place(v, b: u128, ..), mod.rs:62)
+inline RqPolyVec gadget_decompose(const RqPolyVec &v, u128 b, size_t padding_size) {
     const CyclotomicConfig &cfg = v.config();
     std::vector<uint64_t> out(v.len() * padding_size * cfg.words_per_elem());
     std::vector<uint64_t> dummy(1);
-    CyclotomicConfig::check(sr_decompose_balanced_batch(cfg.raw(), out.empty() ? dummy.data() : out.data(),
-                                                        v.words().empty() ? dummy.data() : v.words().data(), b, padding_size, v.len()),
+    CyclotomicConfig::check(sr_decompose_balanced_batch_wide(cfg.raw(), out.empty() ? dummy.data() : out.data(),
+                                                             v.words().empty() ? dummy.data() : v.words().data(), (uint64_t)b,
+                                                             (uint64_t)(b >> 64), padding_size, v.len()),
                             "gadget_decompose");
     return RqPolyVec(cfg, std::move(out));
 }
 // GadgetRecompose (mod.rs:177-189, 200-206): len / padding_size elements
-inline RqPolyVec gadget_recompose(const RqPolyVec &digits, uint64_t b, size_t padding_size) {
+inline RqPolyVec gadget_recompose(const RqPolyVec &digits, u128 b, size_t padding_size) {
     const CyclotomicConfig &cfg = digits.config();
     if (padding_size == 0 || digits.len() % padding_size) throw std::length_error("length is not a multiple of padding_size");
     const size_t n = digits.len() / padding_size;
     std::vector<uint64_t> out(n * cfg.words_per_elem());
     std::vector<uint64_t> dummy(1);
-    CyclotomicConfig::check(sr_recompose_batch(cfg.raw(), out.empty() ? dummy.data() : out.data(),
-                                               digits.words().empty() ? dummy.data() : digits.words().data(), b, padding_size, n),
+    CyclotomicConfig::check(sr_recompose_batch_wide(cfg.raw(), out.empty() ? dummy.data() : out.data(),
+                                                    digits.words().empty() ? dummy.data() : digits.words().data(), (uint64_t)b,
+                                                    (uint64_t)(b >> 64), padding_size, n),
                             "gadget_recompose");
     return RqPolyVec(cfg, std::move(out));
 }
+// DecomposeToVec for &[R] / Vec<R> (mod.rs:119-161): one Vec<R> of padding_size digits per element of v
+inline std::vector<RqPolyVec> decompose_to_vec(const RqPolyVec &v, u128 b, size_t padding_size) {
+    const CyclotomicConfig &cfg = v.config();
+    const RqPolyVec all = gadget_decompose(v, b, padding_size);   // digit j of element e at e * padding_size + j
+    const size_t w = cfg.words_per_elem();
+    std::vector<RqPolyVec> out;
+    out.reserve(v.len());
+    for (size_t e = 0; e < v.len(); e++)
+        out.emplace_back(cfg, std::vector<uint64_t>(all.words().begin() + e * padding_size * w, all.words().begin() + (e + 1) * padding_size * w));
+    return out;
+}
+
+// Cyclotomic::rot (traits.rs:54-66): every element of the batch times X modulo the ring, in place
+inline void rot(RqPolyVec &v) {
+    if (v.len() == 0) return;
+    CyclotomicConfig::check(sr_rot_batch(v.config().raw(), v.element(0), v.len()), "rot");
+}
+// Rotation / into_rot_iter (traits.rs:68-91): an endless iterator x, X x, X^2 x, ... (next() returns the current value, then rotates)
+class Rotation {
+public:
+    explicit Rotation(RqPolyVec curr) : curr_(std::move(curr)) {}
+    RqPolyVec next() {
+        RqPolyVec out = curr_;
+        rot(curr_);
+        return out;
+    }
+
+private:
+    RqPolyVec curr_;
+};
+inline Rotation into_rot_iter(RqPolyVec v) { return Rotation(std::move(v)); }
+
+// GadgetDecompose / GadgetRecompose for &[(R, usize)] (mod.rs:208-275): one sparse row of (element, column) pairs
+using SparseRow = std::vector<std::pair<std::vector<uint64_t>, size_t>>;
+inline SparseRow sparse_row_gadget_decompose(const CyclotomicConfig &cfg, const SparseRow &row, u128 b, size_t padding_size) {
+    const size_t w = cfg.words_per_elem();
+    std::vector<uint64_t> flat;
+    for (const auto &e : row) {
+        if (e.first.size() != w) throw std::length_error("Wrong length");
+        flat.insert(flat.end(), e.first.begin(), e.first.end());
+    }
+    const RqPolyVec digits = gadget_decompose(RqPolyVec(cfg, std::move(flat)), b, padding_size);
+    SparseRow out;
+    for (size_t i = 0; i < row.size(); i++)
+        for (size_t j = 0; j < padding_size; j++) {
+            const uint64_t *d = digits.words().data() + (i * padding_size + j) * w;
+            bool zero = true;
+            for (size_t q = 0; q < w && zero; q++) zero = d[q] == 0;
+            if (!zero) out.emplace_back(std::vector<uint64_t>(d, d + w), row[i].second * padding_size + j);  // "Maintain full sparsity"
+        }
+    return out;
+}
+inline SparseRow sparse_row_gadget_recompose(const CyclotomicConfig &cfg, const SparseRow &row, u128 b, size_t padding_size) {
+    if (padding_size == 0) throw std::length_error("padding_size is zero");
+    const size_t w = cfg.words_per_elem();
+    // consecutive entries with the same index / padding_size form one chunk (mod.rs:241-256); missing digits are zero
+    std::vector<size_t> index;
+    std::vector<uint64_t> flat;
+    for (size_t i = 0; i < row.size(); i++) {
+        const size_t idx = row[i].second / padding_size;
+        if (i == 0 || idx != row[i - 1].second / padding_size) {
+            index.push_back(idx);
+            flat.resize(flat.size() + padding_size * w, 0);
+        }
+        if (row[i].first.size() != w) throw std::length_error("Wrong length");
+        std::copy(row[i].first.begin(), row[i].first.end(), flat.end() - padding_size * w + (row[i].second % padding_size) * w);
+    }
+    const RqPolyVec vals = gadget_recompose(RqPolyVec(cfg, std::move(flat)), b, padding_size);
+    SparseRow out;
+    for (size_t i = 0; i < index.size(); i++)
+        out.emplace_back(std::vector<uint64_t>(vals.words().begin() + i * w, vals.words().begin() + (i + 1) * w), index[i]);
+    return out;
+}
+
+// Matrix<R> in coefficient form (the decompositions work coefficient-wise): GadgetDecompose / GadgetRecompose for Matrix<R>
+// (mod.rs:276-313): n x m -> n x (k m), row by row; entry (r, c) -> (r, c k .. c k + k - 1)
+class MatrixPoly {
+public:
+    MatrixPoly(CyclotomicConfig cfg, size_t nrows, size_t ncols, std::vector<uint64_t> words)
+        : cfg_(std::move(cfg)), nrows_(nrows), ncols_(ncols), w_(std::move(words)) {
+        if (w_.size() != nrows_ * ncols_ * cfg_.words_per_elem()) throw std::length_error("Wrong length");
+    }
+    size_t nrows() const { return nrows_; }
+    size_t ncols() const { return ncols_; }
+    const std::vector<uint64_t> &words() const { return w_; }
+    bool operator==(const MatrixPoly &o) const { return nrows_ == o.nrows_ && ncols_ == o.ncols_ && w_ == o.w_; }
+    MatrixPoly gadget_decompose(u128 b, size_t padding_size) const {   // row-major storage: the flat batch IS row after row
+        RqPolyVec d = stark_rings::gadget_decompose(RqPolyVec(cfg_, w_), b, padding_size);
+        return MatrixPoly(cfg_, nrows_, ncols_ * padding_size, std::move(d).into_words());
+    }
+    MatrixPoly gadget_recompose(u128 b, size_t padding_size) const {
+        if (padding_size == 0 || ncols_ % padding_size) throw std::length_error("ncols is not a multiple of padding_size");
+        RqPolyVec r = stark_rings::gadget_recompose(RqPolyVec(cfg_, w_), b, padding_size);
+        return MatrixPoly(cfg_, nrows_, ncols_ / padding_size, std::move(r).into_words());
+    }
+
+private:
+    CyclotomicConfig cfg_;
+    size_t nrows_, ncols_;
+    std::vector<uint64_t> w_;
+};
+// SparseMatrix<R> in coefficient form: GadgetDecompose / GadgetRecompose for SparseMatrix<R> (mod.rs:315-352)
+class SparseMatrixPoly {
+public:
+    SparseMatrixPoly(CyclotomicConfig cfg, size_t nrows, size_t ncols, std::vector<SparseRow> coeffs)
+        : cfg_(std::move(cfg)), nrows_(nrows), ncols_(ncols), coeffs_(std::move(coeffs)) {
+        if (coeffs_.size() != nrows_) throw std::length_error("Wrong length");
+    }
+    size_t nrows() const { return nrows_; }
+    size_t ncols() const { return ncols_; }
+    const std::vector<SparseRow> &coeffs() const { return coeffs_; }
+    SparseMatrixPoly gadget_decompose(u128 b, size_t padding_size) const {
+        std::vector<SparseRow> rows;
+        for (const auto &r : coeffs_) rows.push_back(sparse_row_gadget_decompose(cfg_, r, b, padding_size));
+        return SparseMatrixPoly(cfg_, nrows_, ncols_ * padding_size, std::move(rows));
+    }
+    SparseMatrixPoly gadget_recompose(u128 b, size_t padding_size) const {
+        std::vector<SparseRow> rows;
+        for (const auto &r : coeffs_) rows.push_back(sparse_row_gadget_recompose(cfg_, r, b, padding_size));
+        return SparseMatrixPoly(cfg_, nrows_, ncols_ / padding_size, std::move(rows));
+    }
+
+private:
+    CyclotomicConfig cfg_;
+    size_t nrows_, ncols_;
+    std::vector<SparseRow> coeffs_;
+};
+
+// One context per GPU of a node from ONE process (what a Rust host that drives all 8 GPUs binds): sr_ctx_create_group builds the
+// twiddle block on device_ids[0] and peer-copies it to the others (the only inter-GPU traffic of the path); shard_range is the
+// contiguous, balanced batch partition of SURVEY 8e (the first batch % n parts get one element more).
+class ContextGroup {
+public:
+    ContextGroup(sr_ring ring, int log2_degree, const std::vector<int> &device_ids, const sr_plan *plan = nullptr) {
+        std::vector<sr_ctx *> raw(device_ids.size(), nullptr);
+        CyclotomicConfig::check(sr_ctx_create_group(ring, log2_degree, device_ids.data(), (int)device_ids.size(), plan, raw.data()),
+                                "sr_ctx_create_group");
+        for (sr_ctx *c : raw) cfgs_.emplace_back(ring, c);
+    }
+    size_t size() const { return cfgs_.size(); }
+    const CyclotomicConfig &operator[](size_t i) const { return cfgs_.at(i); }
+    // elements [first, first + count) of a batch belong to context i
+    std::pair<size_t, size_t> shard_range(size_t batch, size_t i) const {
+        size_t first = 0, count = 0;
+        CyclotomicConfig::check(sr_shard_range(batch, (int)cfgs_.size(), (int)i, &first, &count), "sr_shard_range");
+        return {first, count};
+    }
+
+private:
+    std::vector<CyclotomicConfig> cfgs_;
+};
 
 // Matrix<RqNTT> (crates/linear_algebra/src/matrix.rs): nrows x ncols ring elements in CRT/NTT form, row-major, flat
 class MatrixNTT {

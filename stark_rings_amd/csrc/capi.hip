@@ -93,9 +93,10 @@ struct sr_ctx {
     size_t lanes_probe_elems = 0;
     size_t probe_chunk = 0;
     bool probing = false;
-    void *host_tmp[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // device temporaries of the host-pointer
-    size_t host_tmp_bytes[7] = {0, 0, 0, 0, 0, 0, 0};  // linear-algebra / decomposition calls (grow-only, see DevBuf); [5], [6]: the
-                                                       // widened operands of packed-u32 calls below D = 4096 (DevBufLite)
+    void *host_tmp[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // device temporaries of the host-pointer
+    size_t host_tmp_bytes[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // linear-algebra / decomposition calls (grow-only, see DevBuf); [5], [6]: the
+                                                          // widened operands of packed-u32 calls below D = 4096, [7]: the row parts of
+                                                          // a short-and-wide small-ring mat-vec (DevBufLite)
     void *stage[4] = {nullptr, nullptr, nullptr, nullptr};  // [2], [3]: second lane of the chunked host pipeline
     size_t stage_bytes[4] = {0, 0, 0, 0};
     hipStream_t stream = nullptr;
@@ -465,6 +466,29 @@ struct ScratchUse {
     }
     ~ScratchUse() {
         if (held) (void)rt_scratch_release(c, st);
+    }
+};
+// device temporary in slot `slot` of the context's grow-only set (see DevBuf below; this one is usable from the internal helpers)
+struct DevBufLite {
+    sr_ctx *c;
+    int slot;
+    void *p = nullptr;
+    DevBufLite(sr_ctx *c_, int slot_) : c(c_), slot(slot_) {}
+    int alloc(size_t bytes) {
+        if (bytes == 0) bytes = 8;
+        if (c->host_tmp_bytes[slot] < bytes) {
+            if (c->host_tmp[slot]) {
+                HIP_TRY(hipDeviceSynchronize());  // a _dev call on another stream may still be using the smaller buffer
+                (void)hipFree(c->host_tmp[slot]);
+                c->host_tmp[slot] = nullptr;
+                c->host_tmp_bytes[slot] = 0;
+            }
+            hipError_t e = hipMalloc(&c->host_tmp[slot], bytes);
+            if (e != hipSuccess) return fail(SR_E_ALLOC, std::string("hipMalloc: ") + hipGetErrorString(e));
+            c->host_tmp_bytes[slot] = bytes;
+        }
+        p = c->host_tmp[slot];
+        return SR_OK;
     }
 };
 // ring elements of elem_bytes each the operand scratch may hold for a batch (plan cap; at least one element)
@@ -1096,34 +1120,20 @@ int dev_matmul(sr_ctx *c, uint64_t *y, const uint64_t *a, const uint64_t *b, siz
 int dev_matvec(sr_ctx *c, uint64_t *y, const uint64_t *m, const uint64_t *v, size_t nrows, size_t ncols, hipStream_t st) {
     if (!is_pow2_ring(c->ring)) {
         ProfScope ps(c, st, K_OTHER);
-        DISPATCH_SLOT(c, (sr::slot_matvec<SL>(K, y, m, v, nrows, ncols, st)));
+        // few rows: every row is cut into parts (one workgroup each) whose sums meet in a context-owned buffer (small_linalg.hpp)
+        const int groups = c->ring == SR_RING_FROG_16 ? 64 : 32;
+        const unsigned nsplit = sr::slot_matvec_splits(nrows, ncols, groups);
+        uint64_t *part = nullptr;
+        if (nsplit > 1) {
+            DevBufLite pb(c, 7);
+            if (int rc = pb.alloc(nrows * nsplit * c->degree * 8)) return rc;
+            part = (uint64_t *)pb.p;
+        }
+        DISPATCH_SLOT(c, (sr::slot_matvec<SL>(K, y, m, v, nrows, ncols, part, nsplit, st)));
     }
     if (c->stark_lazy) return matvec_dev<sr::StarkL>(c, y, m, v, nrows, ncols, st);  // sums of products on 28-bit lazy limbs (stark_lazy.hpp)
     DISPATCH_POW2(c, (matvec_dev<F>(c, y, m, v, nrows, ncols, st)));
 }
-// device temporary in slot `slot` of the context's grow-only set (see DevBuf below; this one is usable from the internal helpers)
-struct DevBufLite {
-    sr_ctx *c;
-    int slot;
-    void *p = nullptr;
-    DevBufLite(sr_ctx *c_, int slot_) : c(c_), slot(slot_) {}
-    int alloc(size_t bytes) {
-        if (bytes == 0) bytes = 8;
-        if (c->host_tmp_bytes[slot] < bytes) {
-            if (c->host_tmp[slot]) {
-                HIP_TRY(hipDeviceSynchronize());  // a _dev call on another stream may still be using the smaller buffer
-                (void)hipFree(c->host_tmp[slot]);
-                c->host_tmp[slot] = nullptr;
-                c->host_tmp_bytes[slot] = 0;
-            }
-            hipError_t e = hipMalloc(&c->host_tmp[slot], bytes);
-            if (e != hipSuccess) return fail(SR_E_ALLOC, std::string("hipMalloc: ") + hipGetErrorString(e));
-            c->host_tmp_bytes[slot] = bytes;
-        }
-        p = c->host_tmp[slot];
-        return SR_OK;
-    }
-};
 // ---- plan selection: sr_plan.lanes = 0 means "measure once, keep the winner" ------------------------------------------------
 // The two-lane plans (tuned Goldilocks cols256 product, register-tiled product) only pay when the HIP runtime gives each of the
 // context's two streams its own hardware queue; which queue a stream gets is decided when the stream is created (GPU_MAX_HW_QUEUES,
@@ -1413,7 +1423,7 @@ int sr_ctx_destroy(sr_ctx *c) {
         if (c->rt_scratch[i]) (void)hipFree(c->rt_scratch[i]);
     if (c->out_stream) (void)hipStreamDestroy(c->out_stream);
     if (c->rt_scratch_free) (void)hipEventDestroy(c->rt_scratch_free);
-    for (int i = 0; i < 7; i++)
+    for (int i = 0; i < 8; i++)
         if (c->host_tmp[i]) (void)hipFree(c->host_tmp[i]);
     if (c->gl_lanes.n) {
         for (int i = 0; i < 2; i++)

@@ -8,6 +8,8 @@
 #include <cstdlib>
 #include <vector>
 
+#include <hip/hip_runtime_api.h>  // hipMalloc / hipMemcpy for the device-pointer wrappers (the mirror itself needs no HIP header)
+
 #include "../../include/stark_rings.hpp"
 #include "../../oracle/sr_oracle.h"
 
@@ -297,6 +299,158 @@ static void monomial_suite(sr_ring ring, int field, int log2d) {
     EXPECT(exp_signed(cfg, -3) == monomial(cfg, 3, -1));
 }
 
+// round 3: the reference's whole basis type (b: u128, mod.rs:62), DecomposeToVec (mod.rs:119-161), GadgetDecompose / GadgetRecompose
+// for Matrix<R>, SparseMatrix<R> and &[(R, usize)] (mod.rs:208-352)
+static void gadget_wide_suite(sr_ring ring, int field, int log2d) {
+    CyclotomicConfig cfg(ring, log2d);
+    const size_t d = cfg.dimension(), w = cfg.words_per_elem(), batch = 5;
+    auto a = uniform(field, 51, batch * d);
+    RqPolyVec v(cfg, a);
+    // a basis of 2^64 and more: one-limb fields have |x| < b / 2, so digit 0 is x and the rest are zero; Stark needs real digits
+    const u128 big = ((u128)3 << 70) + 6;
+    const size_t k = field == SRO_STARK ? 5 : 2;
+    RqPolyVec dig = gadget_decompose(v, big, k);
+    EXPECT(dig.len() == batch * k);
+    EXPECT(gadget_recompose(dig, big, k) == v);
+    if (field != SRO_STARK)
+        for (size_t e = 0; e < batch; e++) {
+            EXPECT(std::equal(a.begin() + e * w, a.begin() + (e + 1) * w, dig.words().begin() + e * k * w));
+            for (size_t q = 0; q < w; q++) EXPECT(dig.words()[(e * k + 1) * w + q] == 0);
+        }
+    // the same digits through the 64-bit oracle for a basis below 2^64 passed as u128
+    const size_t k16 = field == SRO_STARK ? 64 : 17;
+    std::vector<uint64_t> want(batch * k16 * w);
+    EXPECT(sro_decompose_balanced(field, a.data(), d, batch, 16, k16, want.data()) == 0);
+    EXPECT(gadget_decompose(v, (u128)16, k16).words() == want);
+    // decompose_to_vec: element e -> its own Vec of k digits
+    auto vecs = decompose_to_vec(v, 16, k16);
+    EXPECT(vecs.size() == batch);
+    for (size_t e = 0; e < batch && e < vecs.size(); e++) {
+        EXPECT(vecs[e].len() == k16);
+        EXPECT(std::equal(vecs[e].words().begin(), vecs[e].words().end(), want.begin() + e * k16 * w));
+        EXPECT(gadget_recompose(vecs[e], 16, k16) == RqPolyVec(cfg, std::vector<uint64_t>(a.begin() + e * w, a.begin() + (e + 1) * w)));
+    }
+    // 2^127 and above is a negative basis after the reference's `b as i128` (mod.rs:73): refused
+    bool threw = false;
+    try {
+        gadget_decompose(v, (u128)1 << 127, 2);
+    } catch (const std::runtime_error &) {
+        threw = true;
+    }
+    EXPECT(threw);
+    // Matrix<R>: 2 x 3 -> 2 x 3k, entry (r, c) -> (r, c k + j); recompose inverts
+    const size_t n = 2, m = 3;
+    auto mw = uniform(field, 52, n * m * d);
+    MatrixPoly M(cfg, n, m, mw);
+    MatrixPoly MD = M.gadget_decompose(16, k16);
+    EXPECT(MD.nrows() == n && MD.ncols() == m * k16);
+    for (size_t r = 0; r < n; r++)
+        for (size_t c = 0; c < m; c++) {
+            RqPolyVec one(cfg, std::vector<uint64_t>(mw.begin() + (r * m + c) * w, mw.begin() + (r * m + c + 1) * w));
+            RqPolyVec dd = gadget_decompose(one, 16, k16);
+            EXPECT(std::equal(dd.words().begin(), dd.words().end(), MD.words().begin() + (r * m * k16 + c * k16) * w));
+        }
+    EXPECT(MD.gadget_recompose(16, k16) == M);
+    // SparseMatrix<R> / &[(R, usize)]: zero digits are dropped, columns become c k + j, recompose restores (element, c)
+    std::vector<uint64_t> small(w, 0), e1(mw.begin(), mw.begin() + w);
+    {
+        std::vector<uint64_t> std5(4 * d, 0), img(4 * d, 0);
+        for (size_t i = 0; i < d; i++) std5[i * cfg.limbs()] = 5;    // the constant-coefficient polynomial 5 + 5X + ...: one non-zero digit in basis 16
+        sro_to_mont(field, std5.data(), img.data(), d);
+        small.assign(img.begin(), img.begin() + w);
+    }
+    std::vector<SparseRow> rows(3);
+    rows[0] = {{small, 1}, {e1, 4}};
+    rows[2] = {{e1, 0}};
+    SparseMatrixPoly S(cfg, 3, 6, rows);
+    SparseMatrixPoly SD = S.gadget_decompose(16, k16);
+    EXPECT(SD.ncols() == 6 * k16 && SD.nrows() == 3);
+    EXPECT(SD.coeffs()[1].empty());
+    EXPECT(!SD.coeffs()[0].empty() && SD.coeffs()[0][0].second == 1 * k16 && SD.coeffs()[0][0].first == small);   // 5 = digit 0, the rest dropped
+    EXPECT(SD.coeffs()[0].size() >= 2 && SD.coeffs()[0][1].second >= 4 * k16);
+    SparseMatrixPoly SR = SD.gadget_recompose(16, k16);
+    EXPECT(SR.ncols() == 6 && SR.coeffs() == rows);
+}
+
+// Cyclotomic::rot / into_rot_iter (traits.rs:54-91; test_rot of goldilocks/mod.rs:249-262): the i-th item of the iterator is X^i x
+static void rot_suite(sr_ring ring, int field, size_t D, int log2d, int trinomial) {
+    CyclotomicConfig cfg(ring, log2d);
+    EXPECT(cfg.dimension() == D);
+    const size_t w = cfg.words_per_elem(), batch = 3;
+    auto a = uniform(field, 61, batch * D);
+    Rotation it = into_rot_iter(RqPolyVec(cfg, a));
+    std::vector<uint64_t> cur = a, nxt(a.size());
+    for (int i = 0; i < 5; i++) {
+        RqPolyVec item = it.next();
+        EXPECT(item.words() == cur);
+        for (size_t e = 0; e < batch; e++) sro_rot(field, cur.data() + e * w, D, trinomial, nxt.data() + e * w);
+        cur = nxt;
+    }
+}
+
+// one context per device from one process (here: two contexts on device 0, the only GPU of the test box) and the device-pointer
+// wrappers: the group's second context computes with the twiddle block it received by peer copy
+static void group_and_device_suite() {
+    ContextGroup grp(SR_RING_GOLDILOCKS_POW2, 13, {0, 0});
+    EXPECT(grp.size() == 2);
+    auto r0 = grp.shard_range(7, 0), r1 = grp.shard_range(7, 1);
+    EXPECT(r0.first == 0 && r0.second == 4 && r1.first == 4 && r1.second == 3);
+    const int log2d = 13;
+    const size_t d = (size_t)1 << log2d, batch = 7;
+    auto a = uniform(SRO_GOLDILOCKS, 71, batch * d), b = uniform(SRO_GOLDILOCKS, 72, batch * d);
+    std::vector<uint64_t> want(batch * d), got(batch * d);
+    sro_pow2_ring_mul_batch(SRO_GOLDILOCKS, want.data(), a.data(), b.data(), log2d, batch, 2);
+    uint64_t *da = nullptr, *db = nullptr, *dout = nullptr;
+    EXPECT(hipMalloc((void **)&da, batch * d * 8) == hipSuccess && hipMalloc((void **)&db, batch * d * 8) == hipSuccess &&
+           hipMalloc((void **)&dout, batch * d * 8) == hipSuccess);
+    EXPECT(hipMemcpy(da, a.data(), batch * d * 8, hipMemcpyHostToDevice) == hipSuccess);
+    EXPECT(hipMemcpy(db, b.data(), batch * d * 8, hipMemcpyHostToDevice) == hipSuccess);
+    for (size_t i = 0; i < grp.size(); i++) {   // each context multiplies ITS shard
+        auto sh = grp.shard_range(batch, i);
+        grp[i].reserve_scratch(sh.second);
+        grp[i].mul_dev(dout + sh.first * d, da + sh.first * d, db + sh.first * d, sh.second, nullptr);
+    }
+    EXPECT(hipDeviceSynchronize() == hipSuccess);
+    EXPECT(hipMemcpy(got.data(), dout, batch * d * 8, hipMemcpyDeviceToHost) == hipSuccess);
+    EXPECT(got == want);
+    // crt / icrt / slot product on device pointers
+    const CyclotomicConfig &cfg = grp[1];
+    cfg.elementwise_crt_dev(da, batch, nullptr);
+    cfg.elementwise_crt_dev(db, batch, nullptr);
+    cfg.ntt_mul_dev(da, db, batch, nullptr);
+    cfg.elementwise_icrt_dev(da, batch, nullptr);
+    EXPECT(hipDeviceSynchronize() == hipSuccess);
+    EXPECT(hipMemcpy(got.data(), da, batch * d * 8, hipMemcpyDeviceToHost) == hipSuccess);
+    EXPECT(got == want);
+    sr_plan pl = cfg.plan_in_use();
+    EXPECT(pl.lanes <= 2);
+    (void)hipFree(da);
+    (void)hipFree(db);
+    (void)hipFree(dout);
+    // packed-u32 BabyBear boundary through the mirror
+    CyclotomicConfig bb(SR_RING_BABYBEAR_POW2, 12);
+    const size_t n = 3 * 4096;
+    auto x = uniform(SRO_BABYBEAR, 73, n), y = uniform(SRO_BABYBEAR, 74, n);
+    std::vector<uint64_t> wantb(n), gotb(n);
+    sro_pow2_ring_mul_batch(SRO_BABYBEAR, wantb.data(), x.data(), y.data(), 12, 3, 2);
+    uint64_t *dx = nullptr, *dy = nullptr;
+    uint32_t *px = nullptr, *py = nullptr;
+    EXPECT(hipMalloc((void **)&dx, n * 8) == hipSuccess && hipMalloc((void **)&dy, n * 8) == hipSuccess &&
+           hipMalloc((void **)&px, n * 4) == hipSuccess && hipMalloc((void **)&py, n * 4) == hipSuccess);
+    EXPECT(hipMemcpy(dx, x.data(), n * 8, hipMemcpyHostToDevice) == hipSuccess && hipMemcpy(dy, y.data(), n * 8, hipMemcpyHostToDevice) == hipSuccess);
+    bb.pack32_dev(px, dx, 3, nullptr);
+    bb.pack32_dev(py, dy, 3, nullptr);
+    bb.mul_packed32_dev(px, px, py, 3, nullptr);
+    bb.unpack32_dev(dx, px, 3, nullptr);
+    EXPECT(hipDeviceSynchronize() == hipSuccess);
+    EXPECT(hipMemcpy(gotb.data(), dx, n * 8, hipMemcpyDeviceToHost) == hipSuccess);
+    EXPECT(gotb == wantb);
+    (void)hipFree(dx);
+    (void)hipFree(dy);
+    (void)hipFree(px);
+    (void)hipFree(py);
+}
+
 int main() {
     try {
         pow2_suite(SR_RING_GOLDILOCKS_POW2, SRO_GOLDILOCKS, 10, 3);   // BASELINE configs[0]: D = 2^10 (batch 1 is element 0)
@@ -318,6 +472,14 @@ int main() {
         monomial_suite(SR_RING_GOLDILOCKS_POW2, SRO_GOLDILOCKS, 6);
         monomial_suite(SR_RING_BABYBEAR_POW2, SRO_BABYBEAR, 5);
         monomial_suite(SR_RING_STARK_POW2, SRO_STARK, 4);
+        gadget_wide_suite(SR_RING_GOLDILOCKS_POW2, SRO_GOLDILOCKS, 5);
+        gadget_wide_suite(SR_RING_BABYBEAR_POW2, SRO_BABYBEAR, 4);
+        gadget_wide_suite(SR_RING_STARK_POW2, SRO_STARK, 3);
+        rot_suite(SR_RING_GOLDILOCKS_POW2, SRO_GOLDILOCKS, 64, 6, 0);
+        rot_suite(SR_RING_STARK_POW2, SRO_STARK, 16, 4, 0);               // stark_prime/mod.rs:179-192
+        rot_suite(SR_RING_GOLDILOCKS_24, SRO_GOLDILOCKS, 24, 0, 1);       // goldilocks/mod.rs:249-262 (X^24 - X^12 + 1)
+        rot_suite(SR_RING_FROG_16, SRO_FROG, 16, 0, 0);
+        group_and_device_suite();
         small_suite(SR_RING_GOLDILOCKS_24, SRO_GOLDILOCKS, 24, 3, sro_g24_crt, sro_g24_ntt_mul, sro_g24_icrt);
         small_suite(SR_RING_BABYBEAR_72, SRO_BABYBEAR, 72, 9, sro_bb72_crt, sro_bb72_ntt_mul, sro_bb72_icrt);
         small_suite(SR_RING_FROG_16, SRO_FROG, 16, 4, sro_frog16_crt, sro_frog16_ntt_mul, sro_frog16_icrt);   // frog_ring/mod.rs tests

@@ -13,7 +13,7 @@ def _build():
 
     oracle_lib.build()
     src = os.path.join(ROOT, "tests", "cpp", "test_host_api.cpp")
-    cmd = ["g++", "-std=c++17", "-O2", "-o", BIN, src,
+    cmd = ["g++", "-std=c++17", "-O2", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", "-o", BIN, src,
            "-L" + os.path.join(ROOT, "stark_rings_amd"), "-lstarkrings_hip",
            "-L" + os.path.join(ROOT, "oracle"), "-lsr_oracle",
            "-Wl,-rpath," + os.path.join(ROOT, "stark_rings_amd"), "-Wl,-rpath," + os.path.join(ROOT, "oracle"),

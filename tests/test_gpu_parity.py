@@ -1341,6 +1341,45 @@ def test_linear_algebra_over_the_reference_rings(torch_cuda, name, base, fn):
     assert z.size == 2 * d and not z.any()
 
 
+@pytest.mark.parametrize("name,base,fn", _SMALL_LA)
+def test_small_ring_linear_algebra_long_rows_and_ragged_blocks(torch_cuda, name, base, fn):
+    """Round 3: the small-ring products sum slot products as INTEGERS (96-bit accumulators per power of X, one Montgomery step and
+    one fold by the non-residue at the end, csrc/small_linalg.hpp), a short-and-wide mat-vec is cut into row parts over several
+    workgroups, and mat-mat works on 2 x 2 output blocks.  Pinned here: 2 rows x 700 columns with every coefficient p - 1 (the
+    largest integer sums; row parts in use) and random, against the oracle's slot products; mat-mat with odd n and p (ragged
+    blocks) and an inner dimension that is not a multiple of the term groups, against mat-vec column by column."""
+    F = O.FIELD_ID[base]
+    p = P.PRIMES[base][0] if base in P.PRIMES else P.FROG_P
+    ring = ring_for(name, 0)
+    d = ring.degree
+    el = lambda buf, i: buf[i * d:(i + 1) * d]
+    nrows, ncols = 2, 700
+    for case in range(2):
+        if case == 0:
+            m = O.to_mont(F, [p - 1] * (nrows * ncols * d))
+            v = O.to_mont(F, [p - 1] * (ncols * d))
+        else:
+            m = O.fill_uniform(F, 0x61, 0, nrows * ncols * d)
+            v = O.fill_uniform(F, 0x62, 0, ncols * d)
+        got = ring.matvec_ntt(m, v, nrows, ncols)
+        for r in range(nrows):
+            want = _oracle_slot_dot(fn, F, p, [el(m, r * ncols + c) for c in range(ncols)], [el(v, c) for c in range(ncols)], d)
+            assert O.from_mont(F, el(got, r)) == want, (name, case, r)
+    # (5 x 23) (23 x 3): every output against the mat-vec of its row block with its column
+    n, mm, pp = 5, 23, 3
+    a = O.fill_uniform(F, 0x63, 0, n * mm * d)
+    b = O.fill_uniform(F, 0x64, 0, mm * pp * d)
+    a[:d] = O.to_mont(F, [p - 1] * d)
+    y = ring.matmul_ntt(a, b, n, mm, pp)
+    for j in range(pp):
+        col = np.concatenate([el(b, t * pp + j) for t in range(mm)])
+        yj = ring.matvec_ntt(a, col, n, mm)
+        for i in range(n):
+            assert np.array_equal(el(y, i * pp + j), el(yj, i)), (name, i, j)
+    want00 = _oracle_slot_dot(fn, F, p, [el(a, t) for t in range(mm)], [el(b, t * pp) for t in range(mm)], d)
+    assert O.from_mont(F, el(y, 0)) == want00
+
+
 # ----------------------------------------------------------------------------- round 2: GadgetDecompose for Matrix / SparseMatrix
 @pytest.mark.parametrize("name,k,basis,pad", [("goldilocks", 4, 4, 33), ("babybear", 3, 16, 9), ("goldilocks24", 0, 1 << 16, 5), ("stark", 2, 1 << 32, 9)])
 def test_matrix_and_sparse_matrix_gadget_decompose(torch_cuda, name, k, basis, pad):
