@@ -80,7 +80,8 @@ enum sr_plan_flags {
     SR_PLAN_RT_NO_COLS256 = 1u << 2,    /* register-tiled path (BabyBear): 4-stage column passes + 12-stage rows                */
     SR_PLAN_GL_REGTILE = 1u << 3,       /* Goldilocks on the register-tiled path (cross-check of ntt_regtile.hpp)               */
     SR_PLAN_STARK_NO_LAZY = 1u << 4,    /* Stark transforms and sums on 8 x 32-bit limbs instead of nine 28-bit lazy limbs       */
-    SR_PLAN_STARK_GENERIC_ON_LAZY = 1u << 5 /* Stark: generic LDS kernels on the lazy limbs instead of ntt_stark.hpp             */
+    SR_PLAN_STARK_GENERIC_ON_LAZY = 1u << 5, /* Stark: generic LDS kernels on the lazy limbs instead of ntt_stark.hpp            */
+    SR_PLAN_NO_HOST_PIN = 1u << 6       /* host-pointer entry points: do not hipHostRegister the caller's buffers for the call   */
 };
 typedef struct sr_plan {
     uint32_t flags;               /* OR of sr_plan_flags                                                                       */

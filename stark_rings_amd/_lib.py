@@ -92,6 +92,7 @@ class Plan(ctypes.Structure):
 
 PLAN_GENERIC_KERNELS, PLAN_GL_NO_COLS256, PLAN_RT_NO_COLS256 = 1, 2, 4
 PLAN_GL_REGTILE, PLAN_STARK_NO_LAZY, PLAN_STARK_GENERIC_ON_LAZY = 8, 16, 32
+PLAN_NO_HOST_PIN = 64
 
 
 def plan_from_env(ring=None):
@@ -111,6 +112,8 @@ def plan_from_env(ring=None):
         f |= PLAN_STARK_NO_LAZY
     if e.get("SR_STARK_TUNED") == "0":
         f |= PLAN_STARK_GENERIC_ON_LAZY
+    if e.get("SR_HOST_PIN") == "0":
+        f |= PLAN_NO_HOST_PIN
     p = Plan()
     p.flags = f
     p.log_tile = int(e.get("SR_LOG_TILE", "0") or 0)

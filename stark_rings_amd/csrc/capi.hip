@@ -1217,7 +1217,9 @@ int lanes_autoselect(sr_ctx *c, size_t batch) {
         c->lanes_probe_ms[0] = best[0];
         c->lanes_probe_ms[1] = best[1];
         c->lanes_probe_elems = n;
-        c->lanes_choice = best[1] < best[0] ? 1 : 2;
+        // The probe's 16 chunks understate the two-lane plan (its first and last chunks run alone; a config-2 batch gains 8 % where
+        // the probe shows 3 %), while lanes that share a hardware queue lose 10 % and more: one stream needs a clear win to be picked.
+        c->lanes_choice = best[1] < 0.97 * best[0] ? 1 : 2;
     } else {
         // no memory for the probe's temporaries (or a launch failed: the real call will report that): keep the default, unmeasured
         (void)hipGetLastError();
@@ -1330,7 +1332,7 @@ int sr_ctx_create_ex(int ring, int log2_degree, int device, const sr_plan *plan,
     if (!out) return fail(SR_E_INVALID, "null out pointer");
     *out = nullptr;
     if (plan) {
-        if (plan->flags >> 6) return fail(SR_E_INVALID, "sr_plan: unknown flag bits");
+        if (plan->flags >> 7) return fail(SR_E_INVALID, "sr_plan: unknown flag bits");
         if (plan->log_tile && (plan->log_tile < 8 || plan->log_tile > 12)) return fail(SR_E_INVALID, "sr_plan: log_tile must be 0 or 8..12");
         if (plan->stark_whole_max && (plan->stark_whole_max < 9 || plan->stark_whole_max > 12))
             return fail(SR_E_INVALID, "sr_plan: stark_whole_max must be 0 or 9..12");
@@ -2064,6 +2066,32 @@ static int host_pipeline(sr_ctx *c, uint64_t *out, const uint64_t *a, const uint
     const size_t elem_bytes = c->degree * c->limbs * 8;
     const size_t bytes = batch * elem_bytes;
     if (bytes == 0) return SR_OK;
+    // The caller's buffers are ordinary (pageable) host memory -- a Rust Vec.  A copy from pageable memory is staged by the runtime
+    // through its own small pinned buffers; registering the caller's pages for the duration of the call (hipHostRegister) lets the
+    // DMA engines read and write them directly.  Worth its cost (page pinning, a few hundred microseconds per GiB... measured in
+    // tools/bench_host_boundary.py) from 32 MiB per operand; a range that cannot be registered (already registered by the caller,
+    // not page-aligned enough, no memory lock limit left) simply stays pageable.  SR_PLAN_NO_HOST_PIN switches it off.
+    struct Pinned {
+        void *p = nullptr;
+        bool pin(const void *q, size_t n) {
+            if (hipHostRegister(const_cast<void *>(q), n, hipHostRegisterDefault) == hipSuccess) {
+                p = const_cast<void *>(q);
+                return true;
+            }
+            (void)hipGetLastError();
+            return false;
+        }
+        ~Pinned() {
+            if (p) (void)hipHostUnregister(p);
+        }
+    } pin_a, pin_b, pin_out;
+    if (!(c->plan.flags & SR_PLAN_NO_HOST_PIN) && bytes >= ((size_t)32 << 20)) {
+        pin_a.pin(a, bytes);
+        if (b && b != a) pin_b.pin(b, bytes);
+        const char *oa = reinterpret_cast<const char *>(out), *aa = reinterpret_cast<const char *>(a), *ba = reinterpret_cast<const char *>(b);
+        const bool overlaps_a = oa < aa + bytes && aa < oa + bytes, overlaps_b = b && oa < ba + bytes && ba < oa + bytes;
+        if (!overlaps_a && !overlaps_b) pin_out.pin(out, bytes);
+    }
     const size_t chunk_mb = c->plan.host_chunk_mb ? c->plan.host_chunk_mb : 128;
     size_t chunk = (chunk_mb << 20) / elem_bytes;
     if (chunk == 0) chunk = 1;

@@ -1256,7 +1256,7 @@ def test_plan_struct_is_validated_and_env_free(torch_cuda):
     """sr_ctx_create_ex refuses malformed plans; the library exports no behaviour switch through the environment."""
     from stark_rings_amd import CyclotomicRing, RingError
 
-    for bad in (_plan(flags=1 << 6), _plan(log_tile=7), _plan(log_tile=13), _plan(stark_whole_max=8), _plan(lanes=3)):
+    for bad in (_plan(flags=1 << 7), _plan(log_tile=7), _plan(log_tile=13), _plan(stark_whole_max=8), _plan(lanes=3)):
         with pytest.raises(RingError):
             CyclotomicRing("goldilocks", 10, device=0, plan=bad)
     import glob
@@ -1753,7 +1753,7 @@ def test_library_settles_the_lanes_plan_itself(torch_cuda):
     ring.reserve_scratch(batch)
     plan, probe = ring.plan_in_use()
     assert plan.lanes in (1, 2) and probe is not None and probe["elems"] == 2048
-    assert (plan.lanes == 2) == (probe["two_lanes_ms"] <= probe["one_stream_ms"])
+    assert (plan.lanes == 1) == (probe["one_stream_ms"] < 0.97 * probe["two_lanes_ms"])   # one stream needs a clear win (capi.hip)
     F = O.GOLDILOCKS
     d = 1 << k
     ta = torch.empty(batch * d, dtype=torch.int64, device="cuda")

@@ -13,9 +13,16 @@ import numpy as np
 import oracle_lib as O
 from stark_rings_amd import CyclotomicRing
 
-for name, k, batch in (("goldilocks", 16, 2048), ("goldilocks", 16, 8192), ("goldilocks", 10, 524288), ("babybear", 16, 8192), ("stark", 12, 32768)):
+from stark_rings_amd._lib import PLAN_NO_HOST_PIN, Plan
+
+# each case twice: the caller's pageable buffers registered for the call (hipHostRegister, the default since round 3) and left pageable
+for name, k, batch, pin in [(n_, k_, b_, p_) for (n_, k_, b_) in (("goldilocks", 16, 2048), ("goldilocks", 16, 8192), ("goldilocks", 10, 524288),
+                                                                  ("babybear", 16, 8192), ("stark", 12, 32768)) for p_ in (True, False)]:
     F = O.FIELD_ID[name]
-    ring = CyclotomicRing(name, k)
+    plan = Plan()
+    if not pin:
+        plan.flags = PLAN_NO_HOST_PIN
+    ring = CyclotomicRing(name, k, plan=plan)
     a = O.fill_uniform(F, 1, 0, batch << k)
     b = O.fill_uniform(F, 2, 0, batch << k)
     out = np.empty_like(a)
@@ -26,6 +33,6 @@ for name, k, batch in (("goldilocks", 16, 2048), ("goldilocks", 16, 8192), ("gol
         ring.mul(a, b, out)
     dt = (time.perf_counter() - t0) / reps
     gb = 3 * a.nbytes / 1e9
-    print("%-10s D=2^%-2d batch %-6d  %8.1f ms  %9.0f ring-muls/s  %5.1f GB/s over PCIe (2 in + 1 out)" % (
-        name, k, batch, dt * 1e3, batch / dt, gb / dt))
+    print("%-10s D=2^%-2d batch %-6d  %-22s %8.1f ms  %9.0f ring-muls/s  %5.1f GB/s over PCIe (2 in + 1 out)" % (
+        name, k, batch, "caller pages pinned" if pin else "pageable (round 2)", dt * 1e3, batch / dt, gb / dt))
     ring.close()
