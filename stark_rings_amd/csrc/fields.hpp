@@ -201,6 +201,70 @@ struct Goldilocks {
     }
 #endif
     SR_HD static elem neg(elem a) { return a ? P - a : 0; }
+    // s = a + b, d = a - b in one go: every butterfly needs both.  Same seven VALU as add + sub, but as ONE asm statement the two carry
+    // chains fill each other's wait states (one s_nop 0 instead of two s_nop 1) and the EXEC mask is saved and restored once
+    // (three SALU instead of four).  SR_GL_FUSED_BF = 1 makes the butterflies of ntt_goldilocks.hpp use it (A/B switch, round 3).
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(SR_GL_NO_EXECMASK)
+    static __device__ __forceinline__ void addsub(elem a, elem b, elem &s, elem &d) {
+        uint64_t t, c1, c2, sv;
+        uint32_t s0, s1, d0, d1;
+        asm("v_lshl_add_u64 %0, %1, 0, %2" : "=v"(t) : "v"(a), "s"((uint64_t)EPS));
+        asm("v_add_co_u32_e64 %0, %4, %6, %8\n\t"
+            "v_sub_co_u32_e64 %2, %5, %10, %8\n\t"
+            "s_nop 0\n\t"
+            "v_addc_co_u32_e64 %1, %4, %7, %9, %4\n\t"
+            "v_subb_co_u32_e64 %3, %5, %11, %9, %5"
+            : "=&v"(s0), "=&v"(s1), "=&v"(d0), "=&v"(d1), "=&s"(c1), "=&s"(c2)
+            : "v"((uint32_t)t), "v"((uint32_t)(t >> 32)), "v"((uint32_t)b), "v"((uint32_t)(b >> 32)), "v"((uint32_t)a), "v"((uint32_t)(a >> 32)));
+        s = (uint64_t)s0 | ((uint64_t)s1 << 32);
+        d = (uint64_t)d0 | ((uint64_t)d1 << 32);
+        asm("s_andn1_saveexec_b64 %2, %3\n\t"      // lanes WITHOUT the carry of t + b take the EPS back
+            "v_lshl_add_u64 %0, %0, 0, %5\n\t"
+            "s_and_b64 exec, %2, %4\n\t"           // lanes that borrowed in a - b take + p
+            "v_lshl_add_u64 %1, %1, 0, %5\n\t"
+            "s_mov_b64 exec, %2"
+            : "+v"(s), "+v"(d), "=&s"(sv)
+            : "s"(c1), "s"(c2), "s"((uint64_t)P)
+            : "scc");
+    }
+    // The same in three separate steps, for callers that run a whole stage's butterflies phase by phase (SR_GL_FUSED_BF = 2,
+    // ntt_goldilocks.hpp): every step's results are consumed eight statements later, so the compiler has no reason to put its
+    // post-asm wait state anywhere.  SWAP: d = b - a instead of a - b (a twiddle 2^E with E >= 96 is -2^(E-96)).
+    static __device__ __forceinline__ elem plus_eps(elem a) {
+        uint64_t t;
+        asm("v_lshl_add_u64 %0, %1, 0, %2" : "=v"(t) : "v"(a), "s"((uint64_t)EPS));
+        return t;
+    }
+    template <bool SWAP>
+    static __device__ __forceinline__ void addsub_chains(elem t, elem a, elem b, uint32_t &s0, uint32_t &s1, uint32_t &d0, uint32_t &d1,
+                                                         uint64_t &c1, uint64_t &c2) {
+        const elem m = SWAP ? b : a, n = SWAP ? a : b;   // d = m - n
+        asm("v_add_co_u32_e64 %0, %4, %6, %8\n\t"
+            "v_sub_co_u32_e64 %2, %5, %10, %12\n\t"
+            "s_nop 0\n\t"
+            "v_addc_co_u32_e64 %1, %4, %7, %9, %4\n\t"
+            "v_subb_co_u32_e64 %3, %5, %11, %13, %5"
+            : "=&v"(s0), "=&v"(s1), "=&v"(d0), "=&v"(d1), "=&s"(c1), "=&s"(c2)
+            : "v"((uint32_t)t), "v"((uint32_t)(t >> 32)), "v"((uint32_t)b), "v"((uint32_t)(b >> 32)), "v"((uint32_t)m), "v"((uint32_t)(m >> 32)),
+              "v"((uint32_t)n), "v"((uint32_t)(n >> 32)));
+    }
+    static __device__ __forceinline__ void addsub_fix(elem &s, elem &d, uint64_t c1, uint64_t c2) {
+        uint64_t sv;
+        asm("s_andn1_saveexec_b64 %2, %3\n\t"
+            "v_lshl_add_u64 %0, %0, 0, %5\n\t"
+            "s_and_b64 exec, %2, %4\n\t"
+            "v_lshl_add_u64 %1, %1, 0, %5\n\t"
+            "s_mov_b64 exec, %2"
+            : "+v"(s), "+v"(d), "=&s"(sv)
+            : "s"(c1), "s"(c2), "s"((uint64_t)P)
+            : "scc");
+    }
+#else
+    SR_HD static void addsub(elem a, elem b, elem &s, elem &d) {
+        s = add(a, b);
+        d = sub(a, b);
+    }
+#endif
 
     // (hi * 2^64 + lo) mod p, using 2^64 = EPS and 2^96 = -1:  lo - hh + hl * EPS
 #ifdef SR_OLD_REDUCE
@@ -236,6 +300,25 @@ struct Goldilocks {
     }
     // canonical (l2 + hl * EPS) for l2 + hl * EPS < 2^64 + p: 3 VALU.  v_mad_u64_u32 delivers the 65th bit as its carry-out;
     // that bit or t >= p (one 64-bit compare against p in an SGPR pair) selects the lanes that take + EPS = - p (mod 2^64).
+    // SR_GL_FUSED_FIX (round 3, default on): the three steps as ONE asm statement.  The compiler cannot see into an asm statement
+    // and, on gfx950, puts a wait state (s_nop 0) between a statement that defines a VGPR and a following instruction that reads it
+    // (its dst_sel forwarding hazard, assumed for anything an asm block may contain): as three statements the fold carried two of
+    // them.  VALU write of an SGPR -> SALU read needs no wait state, SALU write of EXEC -> VALU neither.
+#if !defined(SR_GL_FUSED_FIX) || SR_GL_FUSED_FIX
+    static __device__ __forceinline__ elem mad_eps_fix(uint64_t l2, uint32_t hl) {
+        uint64_t t, cy, c2;
+        asm("v_mad_u64_u32 %0, %1, %3, -1, %4\n\t"
+            "v_cmp_le_u64_e64 %2, %5, %0\n\t"
+            "s_or_b64 %2, %2, %1\n\t"
+            "s_and_saveexec_b64 %1, %2\n\t"
+            "v_lshl_add_u64 %0, %0, 0, %6\n\t"
+            "s_mov_b64 exec, %1"
+            : "=&v"(t), "=&s"(cy), "=&s"(c2)
+            : "v"(hl), "v"(l2), "s"((uint64_t)P), "s"((uint64_t)EPS)
+            : "scc");
+        return t;
+    }
+#else
     static __device__ __forceinline__ elem mad_eps_fix(uint64_t l2, uint32_t hl) {
         uint64_t t, cy, c2, sv;
         asm("v_mad_u64_u32 %0, %1, %2, -1, %3" : "=v"(t), "=s"(cy) : "v"(hl), "v"(l2));
@@ -249,6 +332,7 @@ struct Goldilocks {
             : "scc");
         return t;
     }
+#endif
 #else
     // a - b for any u64 a and b < 2^32 (+ p on borrow).  The high word of b is an opaque zero register: with a literal 0 the
     // combiner rewrites subcarry(x, 0, c) as x - zext(c) and spends a v_cndmask on materialising c.
@@ -315,9 +399,42 @@ struct Goldilocks {
     }
 #endif
 #endif  // SR_GL_NO_EXECMASK
+#ifndef SR_GL_FIX_FOLD
+#define SR_GL_FIX_FOLD 1   // round 3: harness 15.79 -> 15.72 ms per config-2 batch on two streams (three alternations, all lower)
+#endif
+#if !defined(SR_GL_NO_EXECMASK) && SR_GL_FIX_FOLD
+    // the "+ p on the lanes that borrowed" of a subtraction and the fold behind it (mad_eps_fix) as ONE statement: (r + [bo] p) + hl eps
+    static __device__ __forceinline__ elem fix_fold(uint64_t r, uint64_t bo, uint32_t hl) {
+        uint64_t t, cy, c2;
+        asm("s_and_saveexec_b64 %1, %4\n\t"
+            "v_lshl_add_u64 %3, %3, 0, %6\n\t"
+            "s_mov_b64 exec, %1\n\t"
+            "v_mad_u64_u32 %0, %1, %5, -1, %3\n\t"
+            "v_cmp_le_u64_e64 %2, %6, %0\n\t"
+            "s_or_b64 %2, %2, %1\n\t"
+            "s_and_saveexec_b64 %1, %2\n\t"
+            "v_lshl_add_u64 %0, %0, 0, %7\n\t"
+            "s_mov_b64 exec, %1"
+            : "=&v"(t), "=&s"(cy), "=&s"(c2), "+v"(r)
+            : "s"(bo), "v"(hl), "s"((uint64_t)P), "s"((uint64_t)EPS)
+            : "scc");
+        return t;
+    }
+    static __device__ __forceinline__ elem reduce128(uint64_t lo, uint64_t hi) {
+        uint64_t c;
+        uint32_t r0, r1;
+        asm("v_sub_co_u32_e64 %0, %2, %3, %5\n\t"
+            "s_nop 1\n\t"
+            "v_subb_co_u32_e64 %1, %2, %4, 0, %2"
+            : "=&v"(r0), "=&v"(r1), "=&s"(c)
+            : "v"((uint32_t)lo), "v"((uint32_t)(lo >> 32)), "v"((uint32_t)(hi >> 32)));
+        return fix_fold((uint64_t)r0 | ((uint64_t)r1 << 32), c, (uint32_t)hi);
+    }
+#else
     static __device__ __forceinline__ elem reduce128(uint64_t lo, uint64_t hi) {
         return mad_eps_fix(sub_small(lo, (uint32_t)(hi >> 32)), (uint32_t)hi);
     }
+#endif
 #else
     SR_HD static elem reduce128(uint64_t lo, uint64_t hi) {
         uint32_t hh = (uint32_t)(hi >> 32), hl = (uint32_t)hi;
@@ -356,6 +473,10 @@ struct Goldilocks {
             : "=&v"(r0), "=&v"(r1), "=&s"(bo)
             : "v"((uint32_t)p0), "v"((uint32_t)p2), "v"((uint32_t)(p3 >> 32)), "s"(c));
         uint64_t r = (uint64_t)r0 | ((uint64_t)r1 << 32);
+#if SR_GL_FIX_FOLD
+        (void)sv;
+        return fix_fold(r, bo, (uint32_t)p3);
+#else
         asm("s_and_saveexec_b64 %1, %2\n\t"
             "v_lshl_add_u64 %0, %0, 0, %3\n\t"
             "s_mov_b64 exec, %1"
@@ -363,6 +484,7 @@ struct Goldilocks {
             : "s"(bo), "s"((uint64_t)P)
             : "scc");
         return mad_eps_fix(r, (uint32_t)p3);
+#endif
     }
 #else
     SR_HD static elem mul(elem a, elem b) {

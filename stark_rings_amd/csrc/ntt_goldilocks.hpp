@@ -142,9 +142,29 @@ SR_HD u64 mul_pow2(u64 x) {
     }
 }
 
+// How the butterflies are emitted (round 3; same values, same 7 VALU per butterfly -- what changes is the number of NON-VALU issue
+// slots a wave spends: s_nop wait states and EXEC juggling, 3 031 per 2 915 VALU in rows256_kernel<2> before, 2 164 now):
+//   0  add and sub as two independent routines (rounds 1 and 2)
+//   1  the sum and the difference of a butterfly from ONE asm statement (Goldilocks::addsub): the two carry chains fill each
+//      other's wait states, one EXEC save / restore serves both corrections
+//   2  (default) the butterflies of a whole stage phase by phase (dif_stage_phased / dit_stage_phased below)
+// tools/ubench/gl_bench.hip, config-2 batch on two streams: 16.37 / 16.04 / 15.82 ms for 0 / 1 / 2.
+#ifndef SR_GL_FUSED_BF
+#define SR_GL_FUSED_BF 2
+#endif
 // decimation-in-frequency butterfly: (a, b) -> (a + b, (a - b) * 2^E), E in [0, 192)
 template <int E>
 SR_HD void bf_dif(u64 &a, u64 &b) {
+#if SR_GL_FUSED_BF
+    if constexpr (E < 96) {
+        u64 s, d;
+        G::addsub(a, b, s, d);
+        a = s;
+        if constexpr (E == 0) b = d;
+        else b = mul_pow2<E>(d);
+        return;
+    }
+#endif
     const u64 s = G::add(a, b);
     u64 d;
     if constexpr (E == 0) {
@@ -162,6 +182,25 @@ SR_HD void bf_dif(u64 &a, u64 &b) {
 // decimation-in-time butterfly: (u, v) -> (u + v 2^E, u - v 2^E)
 template <int E>
 SR_HD void bf_dit(u64 &u, u64 &v) {
+#if SR_GL_FUSED_BF
+    if constexpr (E < 96) {
+        u64 t = v;
+        if constexpr (E != 0) t = mul_pow2<E>(v);
+        u64 s, d;
+        G::addsub(u, t, s, d);
+        u = s;
+        v = d;
+        return;
+    } else {
+        u64 t = v;
+        if constexpr (E != 96) t = mul_pow2<E - 96>(v);
+        u64 s, d;
+        G::addsub(u, t, s, d);   // u - t is the "sum" leg, u + t the "difference" leg
+        u = d;
+        v = s;
+        return;
+    }
+#endif
     if constexpr (E == 0) {
         const u64 s = G::add(u, v), d = G::sub(u, v);
         u = s;
@@ -191,6 +230,58 @@ template <int HALF, int STEP, int BASE, int... Js>
 SR_HD void dit_group(u64 *x, std::integer_sequence<int, Js...>) {
     (bf_dit<(192 - (STEP * Js) % 192) % 192>(x[BASE + Js], x[BASE + Js + HALF]), ...);
 }
+template <int E>
+SR_HD u64 shift96(u64 x) {  // x 2^E, 0 <= E < 96
+    if constexpr (E == 0) return x;
+    else return mul_pow2<E>(x);
+}
+#if SR_GL_FUSED_BF == 2 && defined(__HIP_DEVICE_COMPILE__)
+// SR_GL_FUSED_BF = 2: the butterflies of a stage run PHASE BY PHASE -- every a + eps, then every pair of carry chains, then every
+// pair of masked corrections, then every shift product -- so that no statement's result is read by the statement right behind it
+// (the compiler's post-asm wait state has nowhere to go) and independent work sits between producer and consumer everywhere.
+// BF<I> describes butterfly I of the stage: register slots lo, hi and its twiddle exponent E in [0, 192).
+template <template <int> class BF, int... Is>
+SR_HD void dif_phased(u64 *x, std::integer_sequence<int, Is...>) {  // (a, b) -> (a + b, (a - b) 2^E)
+    constexpr int n = sizeof...(Is);
+    u64 t[n], c1[n], c2[n];
+    u32 s0[n], s1[n], d0[n], d1[n];
+    ((t[Is] = G::plus_eps(x[BF<Is>::lo])), ...);
+    (G::addsub_chains<(BF<Is>::E >= 96)>(t[Is], x[BF<Is>::lo], x[BF<Is>::hi], s0[Is], s1[Is], d0[Is], d1[Is], c1[Is], c2[Is]), ...);
+    ((x[BF<Is>::lo] = (u64)s0[Is] | ((u64)s1[Is] << 32), x[BF<Is>::hi] = (u64)d0[Is] | ((u64)d1[Is] << 32)), ...);
+    (G::addsub_fix(x[BF<Is>::lo], x[BF<Is>::hi], c1[Is], c2[Is]), ...);
+    ((x[BF<Is>::hi] = shift96<BF<Is>::E % 96>(x[BF<Is>::hi])), ...);
+}
+template <template <int> class BF, int... Is>
+SR_HD void dit_phased(u64 *x, std::integer_sequence<int, Is...>) {  // (u, v) -> (u + v 2^E, u - v 2^E)
+    constexpr int n = sizeof...(Is);
+    u64 t[n], c1[n], c2[n], sv[n], dv[n];
+    u32 s0[n], s1[n], d0[n], d1[n];
+    // v 2^E first (E >= 96: v 2^(E - 96), and the legs swap: u - t is the sum leg)
+    ((x[BF<Is>::hi] = shift96<BF<Is>::E % 96>(x[BF<Is>::hi])), ...);
+    ((t[Is] = G::plus_eps(x[BF<Is>::lo])), ...);
+    (G::addsub_chains<false>(t[Is], x[BF<Is>::lo], x[BF<Is>::hi], s0[Is], s1[Is], d0[Is], d1[Is], c1[Is], c2[Is]), ...);
+    ((sv[Is] = (u64)s0[Is] | ((u64)s1[Is] << 32), dv[Is] = (u64)d0[Is] | ((u64)d1[Is] << 32)), ...);
+    (G::addsub_fix(sv[Is], dv[Is], c1[Is], c2[Is]), ...);
+    ((x[BF<Is>::lo] = BF<Is>::E >= 96 ? dv[Is] : sv[Is], x[BF<Is>::hi] = BF<Is>::E >= 96 ? sv[Is] : dv[Is]), ...);
+}
+// the stages of the cyclic DFT_16 networks: butterfly I = block I / HALF, position I % HALF
+template <int HALF, int STEP, bool DIT>
+struct StageOf {
+    template <int I>
+    struct Bf {
+        static constexpr int lo = (I / HALF) * 2 * HALF + I % HALF, hi = lo + HALF;
+        static constexpr int E = DIT ? (192 - (STEP * (I % HALF)) % 192) % 192 : (STEP * (I % HALF)) % 192;
+    };
+};
+template <int HALF, int STEP, int... Bs>
+SR_HD void dif_stage(u64 *x, std::integer_sequence<int, Bs...>) {
+    dif_phased<StageOf<HALF, STEP, false>::template Bf>(x, std::make_integer_sequence<int, HALF * (int)sizeof...(Bs)>{});
+}
+template <int HALF, int STEP, int... Bs>
+SR_HD void dit_stage(u64 *x, std::integer_sequence<int, Bs...>) {
+    dit_phased<StageOf<HALF, STEP, true>::template Bf>(x, std::make_integer_sequence<int, HALF * (int)sizeof...(Bs)>{});
+}
+#else
 template <int HALF, int STEP, int... Bs>
 SR_HD void dif_stage(u64 *x, std::integer_sequence<int, Bs...>) {
     (dif_group<HALF, STEP, Bs * 2 * HALF>(x, std::make_integer_sequence<int, HALF>{}), ...);
@@ -199,6 +290,7 @@ template <int HALF, int STEP, int... Bs>
 SR_HD void dit_stage(u64 *x, std::integer_sequence<int, Bs...>) {
     (dit_group<HALF, STEP, Bs * 2 * HALF>(x, std::make_integer_sequence<int, HALF>{}), ...);
 }
+#endif
 // 16-point cyclic DFT with omega_16 = 2^156: natural order in, bit-reversed order out (unnormalised)
 SR_HD void dft16_fwd(u64 *x) {
     dif_stage<8, kW16Exp>(x, std::make_integer_sequence<int, 1>{});
@@ -461,6 +553,28 @@ template <int U, int J>
 SR_HD void cols_bf_inv(u64 *x) {
     if constexpr ((J & (8 >> U)) == 0) bf_dif<(192 - cols_tw_exp((1 << U) + (J >> (4 - U)))) % 192>(x[J], x[J + (8 >> U)]);
 }
+#if SR_GL_FUSED_BF == 2 && defined(__HIP_DEVICE_COMPILE__)
+// the merged negacyclic stages of pass A, phase by phase like the DFT_16 stages (dif_phased / dit_phased above): butterfly I of stage U
+// pairs slots (J, J + (8 >> U)) with J = (I / half) 2 half + I % half and carries the twiddle 2^cols_tw_exp(2^U + (J >> (4 - U)))
+template <int U, bool INV>
+struct ColsStageOf {
+    template <int I>
+    struct Bf {
+        static constexpr int half = 8 >> U;
+        static constexpr int lo = (I / half) * 2 * half + I % half, hi = lo + half;
+        static constexpr int e = cols_tw_exp((1 << U) + (lo >> (4 - U)));
+        static constexpr int E = INV ? (192 - e) % 192 : e;
+    };
+};
+template <int U, int... Js>
+SR_HD void cols_stage_fwd(u64 *x, std::integer_sequence<int, Js...>) {
+    dit_phased<ColsStageOf<U, false>::template Bf>(x, std::make_integer_sequence<int, 8>{});
+}
+template <int U, int... Js>
+SR_HD void cols_stage_inv(u64 *x, std::integer_sequence<int, Js...>) {
+    dif_phased<ColsStageOf<U, true>::template Bf>(x, std::make_integer_sequence<int, 8>{});
+}
+#else
 template <int U, int... Js>
 SR_HD void cols_stage_fwd(u64 *x, std::integer_sequence<int, Js...>) {
     (cols_bf_fwd<U, Js>(x), ...);
@@ -469,6 +583,7 @@ template <int U, int... Js>
 SR_HD void cols_stage_inv(u64 *x, std::integer_sequence<int, Js...>) {
     (cols_bf_inv<U, Js>(x), ...);
 }
+#endif
 
 // LC = log2 of the columns a workgroup owns: 16 << LC lanes, 256 legs x 2^LC consecutive columns (2^LC x 8-byte segments).
 // Wider segments stream better (tools/ubench/strided_pattern.hip: 4.7 / 5.1 / 6.1 TB/s for 16 / 32 / 64 columns) at the price of

@@ -181,6 +181,20 @@ struct StarkL {
     SR_HD static void mac_s(int64_t &acc, int32_t x, int32_t y) { acc += (int64_t)x * (int64_t)y; }
     SR_HD static void mac_u(int64_t &acc, uint32_t x, uint32_t y) { acc = (int64_t)((uint64_t)acc + (uint64_t)x * y); }
 #endif
+    // Round 3, device build: ONE asm statement per column (generated: tools/gen_stark_mul_cols.py -> stark_mul_cols.inc).  As one
+    // statement per multiply-add the compiler padded nearly every one of them with a wait state it could not know to be unnecessary
+    // (112 s_nop per 174 VALU); the accumulator dependency is interlocked by the hardware.  SR_ST_NO_COLS_ASM: the former form.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(SR_ST_NO_ASM_MAD) && !defined(SR_ST_NO_COLS_ASM)
+    static __device__ __forceinline__ elem mul_tw(const elem &a, const elem &w) {
+        const uint32_t c24 = 1u << 24, c27 = 1u << 27;
+        int64_t acc = 0;
+        uint64_t cy;
+        uint32_t m[10];
+        elem r;
+#include "stark_mul_cols.inc"
+        return r;
+    }
+#else
     SR_HD static elem mul_tw(const elem &a, const elem &w) {
         uint32_t c24 = 1u << 24, c27 = 1u << 27, c1 = 1u;
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -219,6 +233,7 @@ struct StarkL {
         r.l[8] = (int32_t)acc;
         return r;
     }
+#endif
     // the slot product inside the fused kernel: both operands are data; they are weakly reduced first
     SR_HD static elem mul_data(const elem &a, const elem &b) { return mul_tw(weak_reduce(a), weak_reduce(b)); }
 
