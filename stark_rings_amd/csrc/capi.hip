@@ -1217,9 +1217,11 @@ int lanes_autoselect(sr_ctx *c, size_t batch) {
         c->lanes_probe_ms[0] = best[0];
         c->lanes_probe_ms[1] = best[1];
         c->lanes_probe_elems = n;
-        // The probe's 16 chunks understate the two-lane plan (its first and last chunks run alone; a config-2 batch gains 8 % where
-        // the probe shows 3 %), while lanes that share a hardware queue lose 10 % and more: one stream needs a clear win to be picked.
-        c->lanes_choice = best[1] < 0.97 * best[0] ? 1 : 2;
+        // The probe's 16 chunks understate the two-lane plan (its first and last chunks run alone: a config-2 batch gains 8 % where
+        // the probe shows 3 %, and config 4's shard gains 9 % where the probe showed one stream AHEAD by 3.5 %), while lanes that
+        // share a hardware queue lose 12 % and more against one stream (20.4 against 17.9 ms): one stream is only
+        // picked on a clear win.
+        c->lanes_choice = best[1] < 0.93 * best[0] ? 1 : 2;
     } else {
         // no memory for the probe's temporaries (or a launch failed: the real call will report that): keep the default, unmeasured
         (void)hipGetLastError();

@@ -153,10 +153,10 @@ SR_HD u64 mul_pow2(u64 x) {
 #define SR_GL_FUSED_BF 2
 #endif
 // decimation-in-frequency butterfly: (a, b) -> (a + b, (a - b) * 2^E), E in [0, 192)
-template <int E>
+template <int E, bool FUSED = true>
 SR_HD void bf_dif(u64 &a, u64 &b) {
 #if SR_GL_FUSED_BF
-    if constexpr (E < 96) {
+    if constexpr (FUSED && E < 96) {
         u64 s, d;
         G::addsub(a, b, s, d);
         a = s;
@@ -180,10 +180,10 @@ SR_HD void bf_dif(u64 &a, u64 &b) {
     b = d;
 }
 // decimation-in-time butterfly: (u, v) -> (u + v 2^E, u - v 2^E)
-template <int E>
+template <int E, bool FUSED = true>
 SR_HD void bf_dit(u64 &u, u64 &v) {
 #if SR_GL_FUSED_BF
-    if constexpr (E < 96) {
+    if constexpr (FUSED && E < 96) {
         u64 t = v;
         if constexpr (E != 0) t = mul_pow2<E>(v);
         u64 s, d;
@@ -191,7 +191,7 @@ SR_HD void bf_dit(u64 &u, u64 &v) {
         u = s;
         v = d;
         return;
-    } else {
+    } else if constexpr (FUSED) {
         u64 t = v;
         if constexpr (E != 96) t = mul_pow2<E - 96>(v);
         u64 s, d;
@@ -222,13 +222,13 @@ SR_HD void bf_dit(u64 &u, u64 &v) {
     }
 }
 
-template <int HALF, int STEP, int BASE, int... Js>
+template <int HALF, int STEP, int BASE, bool FUSED, int... Js>
 SR_HD void dif_group(u64 *x, std::integer_sequence<int, Js...>) {
-    (bf_dif<(STEP * Js) % 192>(x[BASE + Js], x[BASE + Js + HALF]), ...);
+    (bf_dif<(STEP * Js) % 192, FUSED>(x[BASE + Js], x[BASE + Js + HALF]), ...);
 }
-template <int HALF, int STEP, int BASE, int... Js>
+template <int HALF, int STEP, int BASE, bool FUSED, int... Js>
 SR_HD void dit_group(u64 *x, std::integer_sequence<int, Js...>) {
-    (bf_dit<(192 - (STEP * Js) % 192) % 192>(x[BASE + Js], x[BASE + Js + HALF]), ...);
+    (bf_dit<(192 - (STEP * Js) % 192) % 192, FUSED>(x[BASE + Js], x[BASE + Js + HALF]), ...);
 }
 template <int E>
 SR_HD u64 shift96(u64 x) {  // x 2^E, 0 <= E < 96
@@ -242,7 +242,7 @@ SR_HD u64 shift96(u64 x) {  // x 2^E, 0 <= E < 96
 // BF<I> describes butterfly I of the stage: register slots lo, hi and its twiddle exponent E in [0, 192).
 template <template <int> class BF, int... Is>
 SR_HD void dif_phased(u64 *x, std::integer_sequence<int, Is...>) {  // (a, b) -> (a + b, (a - b) 2^E)
-    constexpr int n = sizeof...(Is);
+    constexpr int n = 8;  // indexed by the butterfly number (a group may be any subset of a stage's eight)
     u64 t[n], c1[n], c2[n];
     u32 s0[n], s1[n], d0[n], d1[n];
     ((t[Is] = G::plus_eps(x[BF<Is>::lo])), ...);
@@ -253,7 +253,7 @@ SR_HD void dif_phased(u64 *x, std::integer_sequence<int, Is...>) {  // (a, b) ->
 }
 template <template <int> class BF, int... Is>
 SR_HD void dit_phased(u64 *x, std::integer_sequence<int, Is...>) {  // (u, v) -> (u + v 2^E, u - v 2^E)
-    constexpr int n = sizeof...(Is);
+    constexpr int n = 8;
     u64 t[n], c1[n], c2[n], sv[n], dv[n];
     u32 s0[n], s1[n], d0[n], d1[n];
     // v 2^E first (E >= 96: v 2^(E - 96), and the legs swap: u - t is the sum leg)
@@ -273,55 +273,82 @@ struct StageOf {
         static constexpr int E = DIT ? (192 - (STEP * (I % HALF)) % 192) % 192 : (STEP * (I % HALF)) % 192;
     };
 };
-template <int HALF, int STEP, int... Bs>
-SR_HD void dif_stage(u64 *x, std::integer_sequence<int, Bs...>) {
-    dif_phased<StageOf<HALF, STEP, false>::template Bf>(x, std::make_integer_sequence<int, HALF * (int)sizeof...(Bs)>{});
+// P butterflies go through the phases together: 8 = a whole stage of a DFT_16 (the default, SR_GL_PHASE_GROUP), 4 = half a stage
+// (eight VGPRs fewer in flight); P = 0: butterfly by butterfly (Goldilocks::addsub); P < 0: add and sub as separate routines (round 2).
+// The fused 4096-point product kernels keep a whole transformed tile in registers beside the one in flight and spill under the
+// phased form (28-31 VGPRs): they take P = 0, and the whole-ring-element tiles (D <= 4096, already at 160 VGPRs) P = -1.
+#ifndef SR_GL_PHASE_GROUP
+#define SR_GL_PHASE_GROUP 8
+#endif
+template <int OFF, int... Is>
+constexpr std::integer_sequence<int, (OFF + Is)...> seq_from(std::integer_sequence<int, Is...>) { return {}; }
+template <template <int> class BF, bool DIT, int N, int P>
+SR_HD void stage_in_groups(u64 *x) {
+    constexpr int G = P < N ? P : N;
+    if constexpr (DIT) {
+        dit_phased<BF>(x, std::make_integer_sequence<int, G>{});
+        if constexpr (G < N) dit_phased<BF>(x, seq_from<G>(std::make_integer_sequence<int, N - G>{}));
+    } else {
+        dif_phased<BF>(x, std::make_integer_sequence<int, G>{});
+        if constexpr (G < N) dif_phased<BF>(x, seq_from<G>(std::make_integer_sequence<int, N - G>{}));
+    }
 }
-template <int HALF, int STEP, int... Bs>
+template <int HALF, int STEP, int P = SR_GL_PHASE_GROUP, int... Bs>
+SR_HD void dif_stage(u64 *x, std::integer_sequence<int, Bs...>) {
+    if constexpr (P <= 0) (dif_group<HALF, STEP, Bs * 2 * HALF, P == 0>(x, std::make_integer_sequence<int, HALF>{}), ...);
+    else stage_in_groups<StageOf<HALF, STEP, false>::template Bf, false, HALF * (int)sizeof...(Bs), P>(x);
+}
+template <int HALF, int STEP, int P = SR_GL_PHASE_GROUP, int... Bs>
 SR_HD void dit_stage(u64 *x, std::integer_sequence<int, Bs...>) {
-    dit_phased<StageOf<HALF, STEP, true>::template Bf>(x, std::make_integer_sequence<int, HALF * (int)sizeof...(Bs)>{});
+    if constexpr (P <= 0) (dit_group<HALF, STEP, Bs * 2 * HALF, P == 0>(x, std::make_integer_sequence<int, HALF>{}), ...);
+    else stage_in_groups<StageOf<HALF, STEP, true>::template Bf, true, HALF * (int)sizeof...(Bs), P>(x);
 }
 #else
-template <int HALF, int STEP, int... Bs>
+#ifndef SR_GL_PHASE_GROUP
+#define SR_GL_PHASE_GROUP 8
+#endif
+template <int HALF, int STEP, int P = SR_GL_PHASE_GROUP, int... Bs>
 SR_HD void dif_stage(u64 *x, std::integer_sequence<int, Bs...>) {
-    (dif_group<HALF, STEP, Bs * 2 * HALF>(x, std::make_integer_sequence<int, HALF>{}), ...);
+    (dif_group<HALF, STEP, Bs * 2 * HALF, (P >= 0)>(x, std::make_integer_sequence<int, HALF>{}), ...);
 }
-template <int HALF, int STEP, int... Bs>
+template <int HALF, int STEP, int P = SR_GL_PHASE_GROUP, int... Bs>
 SR_HD void dit_stage(u64 *x, std::integer_sequence<int, Bs...>) {
-    (dit_group<HALF, STEP, Bs * 2 * HALF>(x, std::make_integer_sequence<int, HALF>{}), ...);
+    (dit_group<HALF, STEP, Bs * 2 * HALF, (P >= 0)>(x, std::make_integer_sequence<int, HALF>{}), ...);
 }
 #endif
 // 16-point cyclic DFT with omega_16 = 2^156: natural order in, bit-reversed order out (unnormalised)
+template <int P = SR_GL_PHASE_GROUP>
 SR_HD void dft16_fwd(u64 *x) {
-    dif_stage<8, kW16Exp>(x, std::make_integer_sequence<int, 1>{});
-    dif_stage<4, (kW16Exp * 2) % 192>(x, std::make_integer_sequence<int, 2>{});
-    dif_stage<2, (kW16Exp * 4) % 192>(x, std::make_integer_sequence<int, 4>{});
-    dif_stage<1, (kW16Exp * 8) % 192>(x, std::make_integer_sequence<int, 8>{});
+    dif_stage<8, kW16Exp, P>(x, std::make_integer_sequence<int, 1>{});
+    dif_stage<4, (kW16Exp * 2) % 192, P>(x, std::make_integer_sequence<int, 2>{});
+    dif_stage<2, (kW16Exp * 4) % 192, P>(x, std::make_integer_sequence<int, 4>{});
+    dif_stage<1, (kW16Exp * 8) % 192, P>(x, std::make_integer_sequence<int, 8>{});
 }
 // inverse network: bit-reversed order in, natural order out, result = 16 * original
+template <int P = SR_GL_PHASE_GROUP>
 SR_HD void dft16_inv(u64 *x) {
-    dit_stage<1, (kW16Exp * 8) % 192>(x, std::make_integer_sequence<int, 8>{});
-    dit_stage<2, (kW16Exp * 4) % 192>(x, std::make_integer_sequence<int, 4>{});
-    dit_stage<4, (kW16Exp * 2) % 192>(x, std::make_integer_sequence<int, 2>{});
-    dit_stage<8, kW16Exp>(x, std::make_integer_sequence<int, 1>{});
+    dit_stage<1, (kW16Exp * 8) % 192, P>(x, std::make_integer_sequence<int, 8>{});
+    dit_stage<2, (kW16Exp * 4) % 192, P>(x, std::make_integer_sequence<int, 4>{});
+    dit_stage<4, (kW16Exp * 2) % 192, P>(x, std::make_integer_sequence<int, 2>{});
+    dit_stage<8, kW16Exp, P>(x, std::make_integer_sequence<int, 1>{});
 }
 
 // Q leading stages skipped: 2^Q independent cyclic DFTs of size 16 >> Q on consecutive register groups (used when
 // D < 4096 and a tile holds 2^Q ring elements: the stride-256 pass must not mix them); same twiddles as the tail
 // of the full network because omega_(16 >> Q) = omega_16^(2^Q)
-template <int Q>
+template <int Q, int P = SR_GL_PHASE_GROUP>
 SR_HD void dft16_fwd_q(u64 *x) {
-    if constexpr (Q <= 0) dif_stage<8, kW16Exp>(x, std::make_integer_sequence<int, 1>{});
-    if constexpr (Q <= 1) dif_stage<4, (kW16Exp * 2) % 192>(x, std::make_integer_sequence<int, 2>{});
-    if constexpr (Q <= 2) dif_stage<2, (kW16Exp * 4) % 192>(x, std::make_integer_sequence<int, 4>{});
-    if constexpr (Q <= 3) dif_stage<1, (kW16Exp * 8) % 192>(x, std::make_integer_sequence<int, 8>{});
+    if constexpr (Q <= 0) dif_stage<8, kW16Exp, P>(x, std::make_integer_sequence<int, 1>{});
+    if constexpr (Q <= 1) dif_stage<4, (kW16Exp * 2) % 192, P>(x, std::make_integer_sequence<int, 2>{});
+    if constexpr (Q <= 2) dif_stage<2, (kW16Exp * 4) % 192, P>(x, std::make_integer_sequence<int, 4>{});
+    if constexpr (Q <= 3) dif_stage<1, (kW16Exp * 8) % 192, P>(x, std::make_integer_sequence<int, 8>{});
 }
-template <int Q>
+template <int Q, int P = SR_GL_PHASE_GROUP>
 SR_HD void dft16_inv_q(u64 *x) {
-    if constexpr (Q <= 3) dit_stage<1, (kW16Exp * 8) % 192>(x, std::make_integer_sequence<int, 8>{});
-    if constexpr (Q <= 2) dit_stage<2, (kW16Exp * 4) % 192>(x, std::make_integer_sequence<int, 4>{});
-    if constexpr (Q <= 1) dit_stage<4, (kW16Exp * 2) % 192>(x, std::make_integer_sequence<int, 2>{});
-    if constexpr (Q <= 0) dit_stage<8, kW16Exp>(x, std::make_integer_sequence<int, 1>{});
+    if constexpr (Q <= 3) dit_stage<1, (kW16Exp * 8) % 192, P>(x, std::make_integer_sequence<int, 8>{});
+    if constexpr (Q <= 2) dit_stage<2, (kW16Exp * 4) % 192, P>(x, std::make_integer_sequence<int, 4>{});
+    if constexpr (Q <= 1) dit_stage<4, (kW16Exp * 2) % 192, P>(x, std::make_integer_sequence<int, 2>{});
+    if constexpr (Q <= 0) dit_stage<8, kW16Exp, P>(x, std::make_integer_sequence<int, 1>{});
 }
 
 // x * 2^E for any compile-time E in [0, 192): 2^96 = -1
@@ -714,7 +741,7 @@ __global__ __launch_bounds__(16 << LC, LC == 4 ? SR_COLS_WAVES : 4) void cols256
 //   of the radix-16 only; the negacyclic twist psi^(256 row + t) is split into a compile-time shift per register slot
 //   ((psi^256)^row, twist_rows) and the column factor psi^t, which commutes with that pass and lives in the w1 table;
 //   nvalid (a multiple of D) guards a ragged last tile.
-template <int Q, bool TW>
+template <int Q, bool TW, int P = SR_GL_PHASE_GROUP>
 __device__ __forceinline__ void tile_fwd(const u64 *__restrict__ src, u64 *lds, const int t, const Tables &T, u64 *x,
                                          int nvalid) {
 #pragma unroll
@@ -725,7 +752,7 @@ __device__ __forceinline__ void tile_fwd(const u64 *__restrict__ src, u64 *lds, 
         x[j] = TW ? ld_stream(src + (pos < nvalid ? pos : nvalid - 1)) : ld_scratch(src + pos);  // TW: operands; else column-pass output
     }
     if (TW) twist_rows<Q, false>(x, std::make_integer_sequence<int, 16>{});
-    dft16_fwd_q<Q>(x);
+    dft16_fwd_q<Q, P>(x);
     if (TW) x[0] = G::mul(x[0], T.w1f[t]);  // psi^t: with the twist merged in, slot 0 is no longer multiplied by 1
 #pragma unroll
     for (int r = 1; r < 16; r++) x[r] = G::mul(x[r], T.w1f[r * 256 + t]);
@@ -735,7 +762,7 @@ __device__ __forceinline__ void tile_fwd(const u64 *__restrict__ src, u64 *lds, 
     const int i0 = t & 15, base2 = (t >> 4) * 256 + i0;
 #pragma unroll
     for (int j = 0; j < 16; j++) x[j] = lds[pad(base2 + j * 16)];
-    dft16_fwd(x);
+    dft16_fwd<P>(x);
 #pragma unroll
     for (int s = 1; s < 16; s++) x[s] = G::mul(x[s], T.w2f[s * 16 + i0]);
 #pragma unroll
@@ -743,15 +770,15 @@ __device__ __forceinline__ void tile_fwd(const u64 *__restrict__ src, u64 *lds, 
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < 16; j++) x[j] = lds[17 * t + j];
-    dft16_fwd(x);
+    dft16_fwd<P>(x);
 }
 
 // inverse of tile_fwd; x[] holds positions 16 t .. 16 t + 15 on entry.  w1i is the plain or the fused-product table.
 // Without TW the result is 4096 x the cyclic inverse and the strided inverse pass finishes the job.
-template <int Q, bool TW>
+template <int Q, bool TW, int P = SR_GL_PHASE_GROUP>
 __device__ __forceinline__ void tile_inv(u64 *x, u64 *lds, const int t, const Tables &T, const u64 *w1i,
                                          u64 *__restrict__ dst, int nvalid) {
-    dft16_inv(x);
+    dft16_inv<P>(x);
 #pragma unroll
     for (int j = 0; j < 16; j++) lds[17 * t + j] = x[j];
     __syncthreads();
@@ -760,7 +787,7 @@ __device__ __forceinline__ void tile_inv(u64 *x, u64 *lds, const int t, const Ta
     for (int s = 0; s < 16; s++) x[s] = lds[pad(base2 + s * 16)];
 #pragma unroll
     for (int s = 1; s < 16; s++) x[s] = G::mul(x[s], T.w2i[s * 16 + i0]);
-    dft16_inv(x);
+    dft16_inv<P>(x);
 #pragma unroll
     for (int j = 0; j < 16; j++) lds[pad(base2 + j * 16)] = x[j];
     __syncthreads();
@@ -769,7 +796,7 @@ __device__ __forceinline__ void tile_inv(u64 *x, u64 *lds, const int t, const Ta
     if (TW) x[0] = G::mul(x[0], w1i[t]);  // psi^-t * D^-1
 #pragma unroll
     for (int r = 1; r < 16; r++) x[r] = G::mul(x[r], w1i[r * 256 + t]);
-    dft16_inv_q<Q>(x);
+    dft16_inv_q<Q, P>(x);
     if (TW) twist_rows<Q, true>(x, std::make_integer_sequence<int, 16>{});
 #pragma unroll
     for (int j = 0; j < 16; j++) {
@@ -796,6 +823,9 @@ __global__ __launch_bounds__(256, TW ? SR_ROWS_WAVES_TW : SR_ROWS_WAVES) void ro
     const size_t base = (size_t)blockIdx.x * kTile;
     int nvalid = kTile;
     if (TW) nvalid = n_total - base < (size_t)kTile ? (int)(n_total - base) : kTile;
+    // the fused products hold a's transformed tile in registers while b's runs: butterfly by butterfly there (no spills); the
+    // stand-alone transforms take the phased stages
+    constexpr int P = MODE >= 2 ? (TW ? -1 : 0) : SR_GL_PHASE_GROUP;
     u64 A[16];
     if (MODE == 1) {
         // lane-contiguous global load, then an exchange into the 16-contiguous-per-lane layout of the first pass
@@ -808,7 +838,7 @@ __global__ __launch_bounds__(256, TW ? SR_ROWS_WAVES_TW : SR_ROWS_WAVES) void ro
 #pragma unroll
         for (int j = 0; j < 16; j++) A[j] = lds[17 * t + j];
     } else {
-        tile_fwd<Q, TW>(a + base, lds, t, T, A, nvalid);
+        tile_fwd<Q, TW, P>(a + base, lds, t, T, A, nvalid);
         if (MODE == 0) {
             // results sit 16-contiguous per lane; one more exchange makes the global store lane-contiguous
 #pragma unroll
@@ -833,13 +863,13 @@ __global__ __launch_bounds__(256, TW ? SR_ROWS_WAVES_TW : SR_ROWS_WAVES) void ro
 #pragma unroll
             for (int j = 0; j < 16; j++) B[j] = lds[17 * t + j];
         } else {
-            tile_fwd<Q, TW>(b + base, lds, t, T, B, nvalid);
+            tile_fwd<Q, TW, P>(b + base, lds, t, T, B, nvalid);
         }
 #pragma unroll
         for (int j = 0; j < 16; j++) A[j] = G::mul(A[j], B[j]);
         // no barrier: tile_inv first writes the lane's own slots 17 t + j, which only this lane has just read
     }
-    tile_inv<Q, TW>(A, lds, t, T, w1i, out + base, nvalid);
+    tile_inv<Q, TW, P>(A, lds, t, T, w1i, out + base, nvalid);
 }
 
 // ------------------------------------------------------------------------------------------------

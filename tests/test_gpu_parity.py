@@ -1753,7 +1753,7 @@ def test_library_settles_the_lanes_plan_itself(torch_cuda):
     ring.reserve_scratch(batch)
     plan, probe = ring.plan_in_use()
     assert plan.lanes in (1, 2) and probe is not None and probe["elems"] == 2048
-    assert (plan.lanes == 1) == (probe["one_stream_ms"] < 0.97 * probe["two_lanes_ms"])   # one stream needs a clear win (capi.hip)
+    assert (plan.lanes == 1) == (probe["one_stream_ms"] < 0.93 * probe["two_lanes_ms"])   # one stream needs a clear win (capi.hip)
     F = O.GOLDILOCKS
     d = 1 << k
     ta = torch.empty(batch * d, dtype=torch.int64, device="cuda")
