@@ -251,8 +251,8 @@ def readme(outdir):
     md.append("\nThe trace run and the stand-alone bench run are different launches on (possibly) different boxes: the two fractions agree within the")
     md.append("box-to-box spread (a few percent).  PMC bytes per launch equal the algorithmic bytes of each kernel (no re-reads).")
     md.append("Configs 2, 3 and 4 run their chunks on two internal streams (DESIGN.md section 3): a launch's duration in the trace is time in flight")
-    md.append("beside the other stream's kernels, so these per-launch fractions are about half of what the same kernel reaches alone; bench.py's")
-    md.append("`roofline.single_stream` block (a one-stream calibration in the same run) and `whole_step_frac` are the figures to compare with earlier rounds.\n")
+    md.append("beside the other stream's kernels, so these per-launch fractions are about half of what the same kernel reaches alone;")
+    md.append("`bench_one_stream.json` (`bench.py --lanes 1`: the same kernels on one stream) and `whole_step_frac` are the figures to compare with earlier rounds.\n")
     for w in names:
         sp = os.path.join(outdir, "summary_%s.md" % w)
         if os.path.exists(sp):
@@ -261,12 +261,16 @@ def readme(outdir):
     md.append("* `kernel_stats_goldilocks_d65536_b16384_one_stream.csv`, `bench_one_stream_under_trace.json` -- the headline workload with `sr_plan.lanes = 1`")
     md.append("  (one stream, eight large chunks) under `rocprofv3 --kernel-trace --stats`: the kernels' exclusive durations (tools/collect_profiles.sh).")
     md.append("* raw CSVs are cut to their first 4000 rows (the two-lane plans launch hundreds of chunk kernels per step); summaries were computed on the GPU box from the complete files.")
-    md.append("* `bench_default.json` -- plain `python bench.py --steps 10 --warmup 3` (with the CPU baseline leg); `bench_ntt_rhs.json` -- `--variant mul_ntt_rhs`;")
-    md.append("  `bench_babybear.json`, `bench_stark.json`, `bench_c4_shard.json` -- the other BASELINE configs; `bench_2rank_gloo.json` -- `python bench.py --gpus 2 --backend gloo --batch 4096`")
-    md.append("  (bench.py launching its own two ranks on the one GPU of the box).")
-    md.append("* `bench_under_trace_<workload>.json`, `bench_under_pmc_SQ_<workload>.json` -- bench.py's own lines from inside the profiler runs.")
-    md.append("* `bench_matvec.txt`, `bench_next_rows.jsonl`, `bench_small_rings.txt` -- tools/bench_matvec.py (incl. the three reference rings), tools/bench_next_rows.py, tools/bench_small_rings.py.")
-    md.append("* `experiments_gl_bench.txt` -- the A/B timings quoted in DESIGN.md section 6.0 (tools/ubench/gl_bench.hip, strided_pattern.hip).")
+    md.append("* `bench_default.json` -- plain `python bench.py --steps 10 --warmup 3` (with the CPU baseline leg; the plan is the library's own choice, quoted in `config.plan`);")
+    md.append("  `bench_one_stream.json` -- `--lanes 1`; `bench_ntt_rhs.json` -- `--variant mul_ntt_rhs`; `bench_force_dist.json` -- `--force-dist` (one-rank `nccl` group: the RCCL path on one GPU);")
+    md.append("  `bench_babybear.json`, `bench_babybear_packed.json` (the opt-in packed-u32 boundary), `bench_stark.json`, `bench_c4_shard.json`, `bench_config0.json` (BASELINE configs[0]: D = 2^10, batch 1) -- the other")
+    md.append("  BASELINE configs; `bench_2rank_gloo.json` -- `python bench.py --gpus 2 --backend gloo --batch 4096` (bench.py launching its own two ranks on the one GPU of the box).")
+    md.append("* `bench_under_trace_<workload>.json`, `bench_under_pmc_SQ_<workload>.json` -- bench.py's own lines from inside the profiler runs (plan pinned with `--lanes` to what the library chose in a plain run).")
+    md.append("* `arith_variants.txt` -- tools/ubench/arith_variants.hip: the current arithmetic against radix-64 passes and 24-bit limbs modulo 2^96 + 1, register-only (DESIGN.md 6.0);")
+    md.append("  `stark_f64_product.txt` -- tools/ubench/stark_f64_product.hip: product part of a 260-bit multiplication on doubles against the nine-limb integer form; `stark_lazy_check.txt` -- device against host build of `StarkL::mul_tw`;")
+    md.append("  `experiments_gl_bench.txt` -- tools/ubench/gl_bench.hip A/B runs of the butterfly scheduling variants; `bench_babybear_packed_sweep.jsonl`, `bench_stark_cols_ab.jsonl` -- chunk sweep / `cols256x2_kernel` and the per-column Stark product, same-box A/B.")
+    md.append("* `bench_matvec.txt` (mat-vec and mat-mat, incl. the three reference rings as integer sums), `bench_small_rings.txt`, `bench_transforms.txt`, `bench_host_boundary.txt` (caller pages registered against pageable) -- the tools/bench_*.py scripts.")
+    md.append("* `gpu_tests.log` -- `python -m pytest tests -m gpu -x -q` at the final source hash: 312 passed.")
     open(os.path.join(outdir, "README.md"), "w").write("\n".join(md) + "\n")
     print("\n".join(md[:22]))
 
