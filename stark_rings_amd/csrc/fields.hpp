@@ -259,10 +259,40 @@ struct Goldilocks {
             : "s"(c1), "s"(c2), "s"((uint64_t)P)
             : "scc");
     }
+    // LAZY legs of a decimation-in-time butterfly (round 3): s = a + t, d = a - t as 64-bit representatives for ANY u64 a and a
+    // canonical t (the shift product v 2^E it comes from is).  a + t wraps at most once -- the + eps on carry lands below 2^64
+    // because a + t - 2^64 <= p - 2 -- and a - t borrows at most once (t - a <= p): six VALU instead of seven, no a + eps.  The
+    // results are arbitrary representatives; every consumer (another lazy butterfly's `a` or `v`, mul) takes those.
+    // tools/model_fast_goldilocks.py: lazy_bf.
+    static __device__ __forceinline__ void addsub_lazy_fix(elem &s, elem &d, uint64_t c1, uint64_t c2) {
+        uint64_t sv;
+        asm("s_and_saveexec_b64 %2, %3\n\t"       // lanes whose a + t carried take + eps (2^64 = eps)
+            "v_lshl_add_u64 %0, %0, 0, %6\n\t"
+            "s_and_b64 exec, %2, %4\n\t"           // lanes that borrowed in a - t take + p (= - eps mod 2^64)
+            "v_lshl_add_u64 %1, %1, 0, %5\n\t"
+            "s_mov_b64 exec, %2"
+            : "+v"(s), "+v"(d), "=&s"(sv)
+            : "s"(c1), "s"(c2), "s"((uint64_t)P), "s"((uint64_t)EPS)
+            : "scc");
+    }
+    static __device__ __forceinline__ void addsub_lazy(elem a, elem t, elem &s, elem &d) {
+        uint64_t c1, c2;
+        uint32_t s0, s1, d0, d1;
+        addsub_chains<false>(a, a, t, s0, s1, d0, d1, c1, c2);
+        s = (uint64_t)s0 | ((uint64_t)s1 << 32);
+        d = (uint64_t)d0 | ((uint64_t)d1 << 32);
+        addsub_lazy_fix(s, d, c1, c2);
+    }
 #else
     SR_HD static void addsub(elem a, elem b, elem &s, elem &d) {
         s = add(a, b);
         d = sub(a, b);
+    }
+    SR_HD static void addsub_lazy(elem a, elem t, elem &s, elem &d) {
+        s = a + t;
+        if (s < a) s += EPS;
+        d = a - t;
+        if (a < t) d -= EPS;
     }
 #endif
 
@@ -399,6 +429,9 @@ struct Goldilocks {
     }
 #endif
 #endif  // SR_GL_NO_EXECMASK
+#ifndef SR_GL_MUL_LOHI
+#define SR_GL_MUL_LOHI 0
+#endif
 #ifndef SR_GL_FIX_FOLD
 #define SR_GL_FIX_FOLD 1   // round 3: harness 15.79 -> 15.72 ms per config-2 batch on two streams (three alternations, all lower)
 #endif
@@ -457,8 +490,18 @@ struct Goldilocks {
     // Same value bit for bit as reduce128 of the 128-bit product (SR_GL_MUL_PLAIN: A/B switch).
     static __device__ __forceinline__ elem mul(elem a, elem b) {
         const uint32_t al = (uint32_t)a, ah = (uint32_t)(a >> 32), bl = (uint32_t)b, bh = (uint32_t)(b >> 32);
+#if SR_GL_MUL_LOHI
+        // al * bl as v_mul_lo_u32 + v_mul_hi_u32: the high word lands in a register whose partner is a standing zero (the 64-bit
+        // addend of the next product) without the v_mov_b32 a v_mad_u64_u32 result needs, and the two cost 1.66 nJ per wave against
+        // 2.7 nJ for mad + mov (profiles/r02/valu_energy.txt) -- the step is bound by its energy under the 1.4 kW cap
+        uint32_t p0h;
+        p0h = __umulhi(al, bl);
+        const uint64_t p0 = (uint64_t)(al * bl);             // only the low word is used below
+        const uint64_t p1 = (uint64_t)ah * bl + p0h;         // <= 2^64 - 2^32
+#else
         const uint64_t p0 = (uint64_t)al * bl;
         const uint64_t p1 = (uint64_t)ah * bl + (p0 >> 32);  // <= 2^64 - 2^32
+#endif
         uint64_t p2, c, bo, sv;
         asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(p2), "=s"(c) : "v"(al), "v"(bh), "v"(p1));
         const uint64_t p3 = (uint64_t)ah * bh + (p2 >> 32);  // <= 2^64 - 2^32

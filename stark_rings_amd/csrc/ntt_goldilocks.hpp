@@ -179,9 +179,23 @@ SR_HD void bf_dif(u64 &a, u64 &b) {
     a = s;
     b = d;
 }
-// decimation-in-time butterfly: (u, v) -> (u + v 2^E, u - v 2^E)
-template <int E, bool FUSED = true>
+// decimation-in-time butterfly: (u, v) -> (u + v 2^E, u - v 2^E).  LAZY (round 3, SR_GL_LAZY_DIT): a butterfly with a shift
+// (E % 96 != 0) adds and subtracts the CANONICAL v 2^E to any 64-bit representative u with six VALU instead of seven
+// (Goldilocks::addsub_lazy) and leaves arbitrary representatives; butterflies with twiddle 1 keep the canonical form -- in the
+// DFT_16 networks below their inputs always come out of twiddle-1 butterflies (tools/model_fast_goldilocks.py asserts it).
+#ifndef SR_GL_LAZY_DIT
+#define SR_GL_LAZY_DIT 1
+#endif
+template <int E, bool FUSED = true, bool LAZY = false>
 SR_HD void bf_dit(u64 &u, u64 &v) {
+    if constexpr (LAZY && E % 96 != 0) {
+        const u64 t = mul_pow2<E % 96>(v);
+        u64 s, d;
+        G::addsub_lazy(u, t, s, d);
+        u = E >= 96 ? d : s;
+        v = E >= 96 ? s : d;
+        return;
+    }
 #if SR_GL_FUSED_BF
     if constexpr (FUSED && E < 96) {
         u64 t = v;
@@ -226,15 +240,32 @@ template <int HALF, int STEP, int BASE, bool FUSED, int... Js>
 SR_HD void dif_group(u64 *x, std::integer_sequence<int, Js...>) {
     (bf_dif<(STEP * Js) % 192, FUSED>(x[BASE + Js], x[BASE + Js + HALF]), ...);
 }
-template <int HALF, int STEP, int BASE, bool FUSED, int... Js>
+template <int HALF, int STEP, int BASE, bool FUSED, bool LAZY = false, int... Js>
 SR_HD void dit_group(u64 *x, std::integer_sequence<int, Js...>) {
-    (bf_dit<(192 - (STEP * Js) % 192) % 192, FUSED>(x[BASE + Js], x[BASE + Js + HALF]), ...);
+    (bf_dit<(192 - (STEP * Js) % 192) % 192, FUSED, LAZY>(x[BASE + Js], x[BASE + Js + HALF]), ...);
 }
 template <int E>
 SR_HD u64 shift96(u64 x) {  // x 2^E, 0 <= E < 96
     if constexpr (E == 0) return x;
     else return mul_pow2<E>(x);
 }
+// the stages of the cyclic DFT_16 as a decimation-in-TIME network with natural order in and bit-reversed order out (the same
+// function as the DIF network dft16_fwd; what the forward kernels use with lazy butterflies): stage U pairs (lo, lo + (8 >> U));
+// every butterfly of block blk = lo / (16 >> U) carries omega_16^((8 >> U) brv_U(blk)).  tools/model_fast_goldilocks.py: dft16_fwd_dit
+constexpr int brv_n(int v, int bits) {
+    int r = 0;
+    for (int i = 0; i < bits; i++) r |= ((v >> i) & 1) << (bits - 1 - i);
+    return r;
+}
+template <int U>
+struct StageNat {
+    template <int I>
+    struct Bf {
+        static constexpr int half = 8 >> U;
+        static constexpr int lo = (I / half) * 2 * half + I % half, hi = lo + half;
+        static constexpr int E = (kW16Exp * half * brv_n(I / half, U)) % 192;
+    };
+};
 #if SR_GL_FUSED_BF == 2 && defined(__HIP_DEVICE_COMPILE__)
 // SR_GL_FUSED_BF = 2: the butterflies of a stage run PHASE BY PHASE -- every a + eps, then every pair of carry chains, then every
 // pair of masked corrections, then every shift product -- so that no statement's result is read by the statement right behind it
@@ -251,17 +282,27 @@ SR_HD void dif_phased(u64 *x, std::integer_sequence<int, Is...>) {  // (a, b) ->
     (G::addsub_fix(x[BF<Is>::lo], x[BF<Is>::hi], c1[Is], c2[Is]), ...);
     ((x[BF<Is>::hi] = shift96<BF<Is>::E % 96>(x[BF<Is>::hi])), ...);
 }
-template <template <int> class BF, int... Is>
+template <bool LZ>
+__device__ __forceinline__ u64 dit_pre_add(u64 a) {   // the a + eps of the canonical sum; a lazy butterfly has none
+    if constexpr (LZ) return a;
+    else return G::plus_eps(a);
+}
+template <bool LZ>
+__device__ __forceinline__ void dit_fix(u64 &s, u64 &d, u64 c1, u64 c2) {
+    if constexpr (LZ) G::addsub_lazy_fix(s, d, c1, c2);
+    else G::addsub_fix(s, d, c1, c2);
+}
+template <template <int> class BF, bool LAZY = false, int... Is>
 SR_HD void dit_phased(u64 *x, std::integer_sequence<int, Is...>) {  // (u, v) -> (u + v 2^E, u - v 2^E)
     constexpr int n = 8;
     u64 t[n], c1[n], c2[n], sv[n], dv[n];
     u32 s0[n], s1[n], d0[n], d1[n];
     // v 2^E first (E >= 96: v 2^(E - 96), and the legs swap: u - t is the sum leg)
     ((x[BF<Is>::hi] = shift96<BF<Is>::E % 96>(x[BF<Is>::hi])), ...);
-    ((t[Is] = G::plus_eps(x[BF<Is>::lo])), ...);
+    ((t[Is] = dit_pre_add<(LAZY && BF<Is>::E % 96 != 0)>(x[BF<Is>::lo])), ...);
     (G::addsub_chains<false>(t[Is], x[BF<Is>::lo], x[BF<Is>::hi], s0[Is], s1[Is], d0[Is], d1[Is], c1[Is], c2[Is]), ...);
     ((sv[Is] = (u64)s0[Is] | ((u64)s1[Is] << 32), dv[Is] = (u64)d0[Is] | ((u64)d1[Is] << 32)), ...);
-    (G::addsub_fix(sv[Is], dv[Is], c1[Is], c2[Is]), ...);
+    (dit_fix<(LAZY && BF<Is>::E % 96 != 0)>(sv[Is], dv[Is], c1[Is], c2[Is]), ...);
     ((x[BF<Is>::lo] = BF<Is>::E >= 96 ? dv[Is] : sv[Is], x[BF<Is>::hi] = BF<Is>::E >= 96 ? sv[Is] : dv[Is]), ...);
 }
 // the stages of the cyclic DFT_16 networks: butterfly I = block I / HALF, position I % HALF
@@ -282,12 +323,12 @@ struct StageOf {
 #endif
 template <int OFF, int... Is>
 constexpr std::integer_sequence<int, (OFF + Is)...> seq_from(std::integer_sequence<int, Is...>) { return {}; }
-template <template <int> class BF, bool DIT, int N, int P>
+template <template <int> class BF, bool DIT, int N, int P, bool LAZY = false>
 SR_HD void stage_in_groups(u64 *x) {
     constexpr int G = P < N ? P : N;
     if constexpr (DIT) {
-        dit_phased<BF>(x, std::make_integer_sequence<int, G>{});
-        if constexpr (G < N) dit_phased<BF>(x, seq_from<G>(std::make_integer_sequence<int, N - G>{}));
+        dit_phased<BF, LAZY>(x, std::make_integer_sequence<int, G>{});
+        if constexpr (G < N) dit_phased<BF, LAZY>(x, seq_from<G>(std::make_integer_sequence<int, N - G>{}));
     } else {
         dif_phased<BF>(x, std::make_integer_sequence<int, G>{});
         if constexpr (G < N) dif_phased<BF>(x, seq_from<G>(std::make_integer_sequence<int, N - G>{}));
@@ -298,10 +339,19 @@ SR_HD void dif_stage(u64 *x, std::integer_sequence<int, Bs...>) {
     if constexpr (P <= 0) (dif_group<HALF, STEP, Bs * 2 * HALF, P == 0>(x, std::make_integer_sequence<int, HALF>{}), ...);
     else stage_in_groups<StageOf<HALF, STEP, false>::template Bf, false, HALF * (int)sizeof...(Bs), P>(x);
 }
-template <int HALF, int STEP, int P = SR_GL_PHASE_GROUP, int... Bs>
+template <int HALF, int STEP, int P = SR_GL_PHASE_GROUP, bool LAZY = false, int... Bs>
 SR_HD void dit_stage(u64 *x, std::integer_sequence<int, Bs...>) {
-    if constexpr (P <= 0) (dit_group<HALF, STEP, Bs * 2 * HALF, P == 0>(x, std::make_integer_sequence<int, HALF>{}), ...);
-    else stage_in_groups<StageOf<HALF, STEP, true>::template Bf, true, HALF * (int)sizeof...(Bs), P>(x);
+    if constexpr (P <= 0) (dit_group<HALF, STEP, Bs * 2 * HALF, P == 0, LAZY>(x, std::make_integer_sequence<int, HALF>{}), ...);
+    else stage_in_groups<StageOf<HALF, STEP, true>::template Bf, true, HALF * (int)sizeof...(Bs), P, LAZY>(x);
+}
+template <int U, int P, bool LAZY, int... Is>
+SR_HD void dit_nat_bfs(u64 *x, std::integer_sequence<int, Is...>) {
+    (bf_dit<StageNat<U>::template Bf<Is>::E, P == 0, LAZY>(x[StageNat<U>::template Bf<Is>::lo], x[StageNat<U>::template Bf<Is>::hi]), ...);
+}
+template <int U, int P = SR_GL_PHASE_GROUP, bool LAZY = false>
+SR_HD void dit_nat_stage(u64 *x) {
+    if constexpr (P <= 0) dit_nat_bfs<U, P, LAZY>(x, std::make_integer_sequence<int, 8>{});
+    else stage_in_groups<StageNat<U>::template Bf, true, 8, P, LAZY>(x);
 }
 #else
 #ifndef SR_GL_PHASE_GROUP
@@ -311,9 +361,17 @@ template <int HALF, int STEP, int P = SR_GL_PHASE_GROUP, int... Bs>
 SR_HD void dif_stage(u64 *x, std::integer_sequence<int, Bs...>) {
     (dif_group<HALF, STEP, Bs * 2 * HALF, (P >= 0)>(x, std::make_integer_sequence<int, HALF>{}), ...);
 }
-template <int HALF, int STEP, int P = SR_GL_PHASE_GROUP, int... Bs>
+template <int HALF, int STEP, int P = SR_GL_PHASE_GROUP, bool LAZY = false, int... Bs>
 SR_HD void dit_stage(u64 *x, std::integer_sequence<int, Bs...>) {
-    (dit_group<HALF, STEP, Bs * 2 * HALF, (P >= 0)>(x, std::make_integer_sequence<int, HALF>{}), ...);
+    (dit_group<HALF, STEP, Bs * 2 * HALF, (P >= 0), LAZY>(x, std::make_integer_sequence<int, HALF>{}), ...);
+}
+template <int U, int P, bool LAZY, int... Is>
+SR_HD void dit_nat_bfs(u64 *x, std::integer_sequence<int, Is...>) {
+    (bf_dit<StageNat<U>::template Bf<Is>::E, (P >= 0), LAZY>(x[StageNat<U>::template Bf<Is>::lo], x[StageNat<U>::template Bf<Is>::hi]), ...);
+}
+template <int U, int P = SR_GL_PHASE_GROUP, bool LAZY = false>
+SR_HD void dit_nat_stage(u64 *x) {
+    dit_nat_bfs<U, P, LAZY>(x, std::make_integer_sequence<int, 8>{});
 }
 #endif
 // 16-point cyclic DFT with omega_16 = 2^156: natural order in, bit-reversed order out (unnormalised)
@@ -324,14 +382,33 @@ SR_HD void dft16_fwd(u64 *x) {
     dif_stage<2, (kW16Exp * 4) % 192, P>(x, std::make_integer_sequence<int, 4>{});
     dif_stage<1, (kW16Exp * 8) % 192, P>(x, std::make_integer_sequence<int, 8>{});
 }
-// inverse network: bit-reversed order in, natural order out, result = 16 * original
-template <int P = SR_GL_PHASE_GROUP>
+// inverse network: bit-reversed order in, natural order out, result = 16 * original.  LAZY: canonical in, arbitrary 64-bit
+// representatives out (slot 0, which only twiddle-1 butterflies touch, stays canonical)
+template <int P = SR_GL_PHASE_GROUP, bool LAZY = false>
 SR_HD void dft16_inv(u64 *x) {
-    dit_stage<1, (kW16Exp * 8) % 192, P>(x, std::make_integer_sequence<int, 8>{});
-    dit_stage<2, (kW16Exp * 4) % 192, P>(x, std::make_integer_sequence<int, 4>{});
-    dit_stage<4, (kW16Exp * 2) % 192, P>(x, std::make_integer_sequence<int, 2>{});
-    dit_stage<8, kW16Exp, P>(x, std::make_integer_sequence<int, 1>{});
+    dit_stage<1, (kW16Exp * 8) % 192, P, LAZY>(x, std::make_integer_sequence<int, 8>{});
+    dit_stage<2, (kW16Exp * 4) % 192, P, LAZY>(x, std::make_integer_sequence<int, 4>{});
+    dit_stage<4, (kW16Exp * 2) % 192, P, LAZY>(x, std::make_integer_sequence<int, 2>{});
+    dit_stage<8, kW16Exp, P, LAZY>(x, std::make_integer_sequence<int, 1>{});
 }
+// dft16_fwd as a decimation-in-time network (StageNat): same order in, same order out, same values (mod p)
+template <int P = SR_GL_PHASE_GROUP, bool LAZY = false>
+SR_HD void dft16_fwd_dit(u64 *x) {
+    dit_nat_stage<0, P, LAZY>(x);
+    dit_nat_stage<1, P, LAZY>(x);
+    dit_nat_stage<2, P, LAZY>(x);
+    dit_nat_stage<3, P, LAZY>(x);
+}
+// what the D = 2^16 .. 2^20 kernels call: CANON = the results leave the library as they are (plain forward transform)
+template <bool CANON = false>
+SR_HD void dft16_fwd_hot(u64 *x) {
+#if SR_GL_LAZY_DIT == 1   // (2: lazy butterflies in the networks that were DIT already, the forward DFT_16 stays DIF: A/B switch)
+    dft16_fwd_dit<SR_GL_PHASE_GROUP, !CANON>(x);
+#else
+    dft16_fwd(x);
+#endif
+}
+SR_HD void dft16_inv_hot(u64 *x) { dft16_inv<SR_GL_PHASE_GROUP, (SR_GL_LAZY_DIT != 0)>(x); }
 
 // Q leading stages skipped: 2^Q independent cyclic DFTs of size 16 >> Q on consecutive register groups (used when
 // D < 4096 and a tile holds 2^Q ring elements: the stride-256 pass must not mix them); same twiddles as the tail
@@ -574,7 +651,7 @@ constexpr int brv5(int i) { return ((i & 1) << 4) | ((i & 2) << 2) | (i & 4) | (
 constexpr int cols_tw_exp(int i) { return (39 * brv5(i)) % 192; }
 template <int U, int J>
 SR_HD void cols_bf_fwd(u64 *x) {
-    if constexpr ((J & (8 >> U)) == 0) bf_dit<cols_tw_exp((1 << U) + (J >> (4 - U)))>(x[J], x[J + (8 >> U)]);
+    if constexpr ((J & (8 >> U)) == 0) bf_dit<cols_tw_exp((1 << U) + (J >> (4 - U))), true, (SR_GL_LAZY_DIT != 0)>(x[J], x[J + (8 >> U)]);
 }
 template <int U, int J>
 SR_HD void cols_bf_inv(u64 *x) {
@@ -595,7 +672,7 @@ struct ColsStageOf {
 };
 template <int U, int... Js>
 SR_HD void cols_stage_fwd(u64 *x, std::integer_sequence<int, Js...>) {
-    dit_phased<ColsStageOf<U, false>::template Bf>(x, std::make_integer_sequence<int, 8>{});
+    dit_phased<ColsStageOf<U, false>::template Bf, (SR_GL_LAZY_DIT != 0)>(x, std::make_integer_sequence<int, 8>{});
 }
 template <int U, int... Js>
 SR_HD void cols_stage_inv(u64 *x, std::integer_sequence<int, Js...>) {
@@ -684,7 +761,7 @@ __device__ __forceinline__ void cols256_tile(const unsigned tile, u64 *data, con
 #pragma unroll
         for (int j = 0; j < 16; j++) x[j] = lds[CT::idx(16 * rg + j, col)];  // block rg, leg j
 #ifndef SR_DIAG_COLS_NOCOMPUTE
-        dft16_fwd(x);
+        dft16_fwd_hot(x);
 #pragma unroll
         for (int sg = 0; sg < 16; sg++)
             st_scratch(reinterpret_cast<u64 *>(pb + (offB + (unsigned)sg * leg)), G::mul(x[sg], tw[sg]));
@@ -703,7 +780,7 @@ __device__ __forceinline__ void cols256_tile(const unsigned tile, u64 *data, con
         prio_alu();
 #pragma unroll
         for (int sg = 0; sg < 16; sg++) x[sg] = G::mul(x[sg], tw[sg]);
-        dft16_inv(x);
+        dft16_inv_hot(x);
 #pragma unroll
         for (int j = 0; j < 16; j++) lds[CT::idx(16 * rg + j, col)] = x[j];
         __syncthreads();
@@ -886,9 +963,11 @@ __device__ __forceinline__ void tile256_load(const u64 *__restrict__ src, const 
     prio_alu();
 }
 // x holds the lane's 16 coefficients (tile256_load) on entry, its 16 consecutive NTT slots on return
+// CANON: the slots leave the library as they are (plain forward transform): the last network runs canonical butterflies
+template <bool CANON = false>
 __device__ __forceinline__ void tile256_fwd_regs(u64 *lds, const int t, const Tables &T, u64 *x) {
     const int i0 = t & 15, base2 = (t >> 4) * 256 + i0;
-    dft16_fwd(x);
+    dft16_fwd_hot(x);
 #pragma unroll
     for (int s = 1; s < 16; s++) x[s] = G::mul(x[s], T.w2f[s * 16 + i0]);
 #pragma unroll
@@ -896,15 +975,16 @@ __device__ __forceinline__ void tile256_fwd_regs(u64 *lds, const int t, const Ta
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < 16; j++) x[j] = lds[17 * t + j];
-    dft16_fwd(x);
+    dft16_fwd_hot<CANON>(x);
 }
+template <bool CANON = false>
 __device__ __forceinline__ void tile256_fwd(const u64 *__restrict__ src, u64 *lds, const int t, const Tables &T, u64 *x) {
     tile256_load(src, t, x);
-    tile256_fwd_regs(lds, t, T, x);
+    tile256_fwd_regs<CANON>(lds, t, T, x);
 }
 __device__ __forceinline__ void tile256_inv(u64 *x, u64 *lds, const int t, const Tables &T, u64 *__restrict__ dst) {
     const int i0 = t & 15, base2 = (t >> 4) * 256 + i0;
-    dft16_inv(x);
+    dft16_inv_hot(x);
 #pragma unroll
     for (int j = 0; j < 16; j++) lds[17 * t + j] = x[j];
     __syncthreads();
@@ -912,7 +992,7 @@ __device__ __forceinline__ void tile256_inv(u64 *x, u64 *lds, const int t, const
     for (int s = 0; s < 16; s++) x[s] = lds[pad(base2 + s * 16)];
 #pragma unroll
     for (int s = 1; s < 16; s++) x[s] = G::mul(x[s], T.w2i[s * 16 + i0]);
-    dft16_inv(x);
+    dft16_inv_hot(x);
 #pragma unroll
     for (int j = 0; j < 16; j++) st_scratch(dst + base2 + j * 16, x[j]);
 }
@@ -938,9 +1018,9 @@ __device__ __forceinline__ void rows256_tile(const unsigned tile, u64 *a, const 
         u64 B[16];
         tile256_load(a + base, t, A);
         if (MODE == 2) tile256_load(b + base, t, B);  // both operands' loads in flight before the first butterfly
-        tile256_fwd_regs(lds, t, T, A);
+        tile256_fwd_regs<MODE == 0>(lds, t, T, A);
 #else
-        tile256_fwd(a + base, lds, t, T, A);
+        tile256_fwd<MODE == 0>(a + base, lds, t, T, A);
 #endif
         if (MODE == 0) {
 #pragma unroll

@@ -55,3 +55,11 @@ def test_cols256_plus_rows256_equals_reference_transform():
     """D = 2^16 = 256 x 256: shift-only 8-stage column pass (compile-time twiddles 2^(39 brv5(i)), theta W layer, cyclic DFT_16,
     block twist) followed by 256-point cyclic rows."""
     assert M.check_cols256(16, seed=6)
+
+
+def test_lazy_decimation_in_time_networks_keep_their_invariants():
+    """Round 3: the forward DFT_16 as a decimation-in-time network equals the DIF one; with LAZY twiddled butterflies (six VALU:
+    any 64-bit `a`, canonical shift product) no sum wraps twice, no difference borrows twice, twiddle-1 butterflies only ever see
+    canonical inputs, slot 0 stays canonical, and every result is the canonical network's modulo p (representatives modelled bit
+    for bit, edge values included)."""
+    assert M.check_lazy_networks(seed=10, rounds=300)

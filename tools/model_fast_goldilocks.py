@@ -57,6 +57,128 @@ def dft16_inv(x):
     return x
 
 
+# ------------------------------------------------------------------------------------------------
+# Round 3: decimation-in-time butterflies with a LAZY sum / difference (ntt_goldilocks.hpp dit_phased<..., LAZY>).
+# A twiddled DIT butterfly adds and subtracts t = v 2^E, which comes out of the shift product canonical (t < p); its other
+# input a may then be ANY 64-bit representative:  a + t wraps at most once (+ eps on carry lands below 2^64 because
+# a + t - 2^64 <= p - 2), a - t borrows at most once (- eps on borrow stays >= 0 because t - a <= p).  Six VALU instead
+# of seven, outputs are arbitrary u64 representatives.  Butterflies with twiddle 1 keep the canonical seven-instruction
+# form and, in both networks below, only ever see canonical inputs (their inputs come out of twiddle-1 butterflies all the
+# way back to the network's inputs).  This section models the REPRESENTATIVES bit for bit and asserts those claims.
+# ------------------------------------------------------------------------------------------------
+M64 = 1 << 64
+EPS = (1 << 32) - 1
+
+
+def lazy_bf(a, v, e):
+    """(a, v) -> (a + v 2^e, a - v 2^e) on u64 representatives; e in [0, 192), e % 96 != 0"""
+    assert 0 <= a < M64 and 0 <= v < M64 and e % 96 != 0
+    t = v * pow(2, e % 96, p) % p                     # mul_pow2: any u64 in, canonical out
+    s = a + t
+    if s >= M64:
+        s = s - M64 + EPS
+        assert s < M64, "second wrap"
+    d = a - t
+    if d < 0:
+        d = d + M64 - EPS
+        assert d >= 0, "second borrow"
+    return (d, s) if e >= 96 else (s, d)
+
+
+def canon_bf(a, b):
+    assert a < p and b < p, "twiddle-1 butterfly on a non-canonical input"
+    return (a + b) % p, (a - b) % p
+
+
+def brv_bits(x, bits):
+    return brv(x, bits) if bits else 0
+
+
+def dft16_fwd_dit(x, lazy=False):
+    """DIT, natural in, bit-reversed out: the same function as dft16_fwd.  Stage u pairs (lo, lo + (8 >> u)); every butterfly of
+    block blk = lo // (16 >> u) carries omega_16^((8 >> u) brv_u(blk))."""
+    x = list(x)
+    for u in range(4):
+        half = 8 >> u
+        for i in range(8):
+            blk, pos = i // half, i % half
+            lo = blk * 2 * half + pos
+            hi = lo + half
+            e = (W16_EXP * half * brv_bits(blk, u)) % 192
+            if lazy and e % 96:
+                x[lo], x[hi] = lazy_bf(x[lo], x[hi], e)
+            elif lazy:
+                assert e == 0
+                x[lo], x[hi] = canon_bf(x[lo], x[hi])
+            else:
+                t = x[hi] * pow(2, e, p) % p
+                x[lo], x[hi] = (x[lo] + t) % p, (x[lo] - t) % p
+    return x
+
+
+def dft16_inv_lazy(x):
+    """dft16_inv on representatives: bit-reversed in, natural out"""
+    x = list(x)
+    half = 1
+    steps = {1: (W16_EXP * 8) % 192, 2: (W16_EXP * 4) % 192, 4: (W16_EXP * 2) % 192, 8: W16_EXP}
+    while half <= 8:
+        for base in range(0, 16, 2 * half):
+            for j in range(half):
+                e = (192 - (steps[half] * j) % 192) % 192
+                lo, hi = base + j, base + j + half
+                if e % 96:
+                    x[lo], x[hi] = lazy_bf(x[lo], x[hi], e)
+                else:
+                    assert e == 0
+                    x[lo], x[hi] = canon_bf(x[lo], x[hi])
+        half *= 2
+    return x
+
+
+def cols_passA_fwd_lazy(x, tw_exp):
+    """the four merged negacyclic stages of cols256 pass A (every twiddle a shift, none trivial) on representatives"""
+    x = list(x)
+    for u in range(4):
+        half = 8 >> u
+        for jj in range(16):
+            if jj & half:
+                continue
+            e = tw_exp[(1 << u) + (jj >> (4 - u))]
+            assert e % 96
+            x[jj], x[jj + half] = lazy_bf(x[jj], x[jj + half], e)
+    return x
+
+
+def check_lazy_networks(seed=9, rounds=200):
+    rng = random.Random(seed)
+    edge = [0, 1, p - 1, p - 2, EPS, EPS + 1, (1 << 63), p - EPS, (1 << 32), p >> 1]
+    T = cols_tables(16)
+    for r in range(rounds):
+        if r < 40:
+            x = [rng.choice(edge) for _ in range(16)]
+        else:
+            x = [rng.randrange(p) for _ in range(16)]
+        want = dft16_fwd(x)
+        assert dft16_fwd_dit(x) == want
+        got = dft16_fwd_dit(x, lazy=True)
+        assert [v % p for v in got] == want and got[0] < p      # slot 0 skips the table product behind the network: canonical
+        want_i = dft16_inv(x)
+        got_i = dft16_inv_lazy(x)
+        assert [v % p for v in got_i] == want_i and got_i[0] < p
+        # pass A: any u64 on the `a` leg is fine, so non-canonical operands would be too; compare with the canonical stages
+        ref = list(x)
+        for u in range(4):
+            half = 8 >> u
+            for jj in range(16):
+                if jj & half:
+                    continue
+                e = T["tw_exp"][(1 << u) + (jj >> (4 - u))]
+                t = ref[jj + half] * pow(2, e, p) % p
+                ref[jj], ref[jj + half] = (ref[jj] + t) % p, (ref[jj] - t) % p
+        assert [v % p for v in cols_passA_fwd_lazy(x, T["tw_exp"])] == ref
+    return True
+
+
 def tables(k):
     c = k - 12
     psi = P.psi("goldilocks", k)
@@ -439,4 +561,6 @@ if __name__ == "__main__":
         print("small k=%d ok" % k)
     check_cols256(16)
     print("cols256 + rows256 k=16 ok")
+    check_lazy_networks()
+    print("lazy DIT networks ok")
     print("model OK")

@@ -2,7 +2,32 @@
 #include <cstdio>
 #include <vector>
 #include "../../stark_rings_amd/csrc/fields.hpp"
+#include "../../stark_rings_amd/csrc/ntt_goldilocks.hpp"
 using G = sr::Goldilocks;
+// round 3: the lazy decimation-in-time legs (any u64 a, canonical t) and the DFT_16 networks built from them, device against host
+__global__ void klazy(const uint64_t *a, const uint64_t *t, uint64_t *o, int n) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint64_t s, d;
+    G::addsub_lazy(a[i], t[i], s, d);
+    o[2 * i] = s;
+    o[2 * i + 1] = d;
+}
+// per lane: 16 canonical inputs -> the DIF network (canonical), the DIT network with lazy butterflies, the lazy inverse network
+__global__ void knet(const uint64_t *x, uint64_t *o, int n) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint64_t u[16], v[16], w[16];
+    for (int j = 0; j < 16; j++) u[j] = v[j] = w[j] = x[16 * i + j];
+    sr::gl::dft16_fwd(u);
+    sr::gl::dft16_fwd_dit<SR_GL_PHASE_GROUP, true>(v);
+    sr::gl::dft16_inv<SR_GL_PHASE_GROUP, true>(w);
+    for (int j = 0; j < 16; j++) {
+        o[48 * i + j] = u[j];
+        o[48 * i + 16 + j] = v[j];
+        o[48 * i + 32 + j] = w[j];
+    }
+}
 template <class F>
 SR_HD void fq3_mul(uint64_t *x, const uint64_t *y, uint64_t nr) {
     uint64_t t[5];
@@ -60,6 +85,50 @@ int main() {
             fq3_mul<G>(x, &b[3 * i], cst);
             for (int m = 0; m < 3; m++)
                 if (o[3 * i + m] != x[m] && bad++ < 12) printf("MISMATCH fq3[%d] i=%d dev=%016llx host=%016llx\n", m, i, (unsigned long long)o[3 * i + m], (unsigned long long)x[m]);
+        }
+    }
+    {   // lazy legs: a runs over every kind of 64-bit value (canonical or not), t over canonical values
+        const uint64_t av[] = {0, 1, G::P - 1, G::P, G::P + 1, ~0ull, ~0ull - 1, 0xFFFFFFFFull, 0x100000000ull, 1ull << 63, 0xFFFFFFFF00000000ull, 0xFFFFFFFEFFFFFFFFull};
+        const uint64_t tv[] = {0, 1, 2, G::P - 1, G::P - 2, 0xFFFFFFFFull, 0x100000000ull, 0xFFFFFFFF00000000ull, 1ull << 63, 0xFFFFFFFEFFFFFFFFull, 0xFFFFFFFE00000002ull};
+        std::vector<uint64_t> la(n), lt(n), lo(2 * (size_t)n);
+        for (int i = 0; i < n; i++) {
+            la[i] = i < 132 ? av[i / 11] : mix(i + 77);            // any u64
+            lt[i] = i < 132 ? tv[i % 11] : mix(i + 0x777) % G::P;
+        }
+        hipMemcpy(da, la.data(), n * 8, hipMemcpyHostToDevice); hipMemcpy(db, lt.data(), n * 8, hipMemcpyHostToDevice);
+        hipLaunchKernelGGL(klazy, dim3(n / 256), dim3(256), 0, 0, da, db, dout, n);
+        hipMemcpy(lo.data(), dout, (size_t)n * 16, hipMemcpyDeviceToHost);
+        for (int i = 0; i < n; i++) {
+            uint64_t s, d;
+            G::addsub_lazy(la[i], lt[i], s, d);
+            const unsigned __int128 P = G::P;
+            const bool ok_host = (unsigned __int128)s % P == ((unsigned __int128)la[i] + lt[i]) % P &&
+                                 (unsigned __int128)d % P == ((unsigned __int128)la[i] % P + P - lt[i]) % P;
+            if ((lo[2 * i] != s || lo[2 * i + 1] != d || !ok_host) && bad++ < 12)
+                printf("MISMATCH lazy a=%016llx t=%016llx dev=(%016llx,%016llx) host=(%016llx,%016llx) host value %s\n", (unsigned long long)la[i], (unsigned long long)lt[i],
+                       (unsigned long long)lo[2 * i], (unsigned long long)lo[2 * i + 1], (unsigned long long)s, (unsigned long long)d, ok_host ? "ok" : "WRONG");
+        }
+    }
+    {   // networks: the lazy DIT forward network equals the canonical DIF one modulo p, slot 0 canonical; lazy inverse against canonical inverse
+        const int m = n / 16;
+        std::vector<uint64_t> xs(n), no(48 * (size_t)m);
+        const uint64_t ev[] = {0, 1, G::P - 1, G::P - 2, 0xFFFFFFFFull, 0x100000000ull, 1ull << 63, 0xFFFFFFFF00000000ull};
+        for (int i = 0; i < n; i++) xs[i] = i < 4096 ? ev[mix(i) & 7] : mix(i + 31) % G::P;
+        uint64_t *dn;
+        hipMalloc(&dn, (size_t)m * 48 * 8);
+        hipMemcpy(da, xs.data(), n * 8, hipMemcpyHostToDevice);
+        hipLaunchKernelGGL(knet, dim3((m + 255) / 256), dim3(256), 0, 0, da, dn, m);
+        hipMemcpy(no.data(), dn, (size_t)m * 48 * 8, hipMemcpyDeviceToHost);
+        for (int i = 0; i < m; i++) {
+            uint64_t u[16], w[16];
+            for (int j = 0; j < 16; j++) u[j] = w[j] = xs[16 * i + j];
+            sr::gl::dft16_fwd(u);
+            sr::gl::dft16_inv(w);
+            for (int j = 0; j < 16; j++) {
+                const bool f0 = no[48 * i + j] == u[j], f1 = no[48 * i + 16 + j] % G::P == u[j], f2 = no[48 * i + 32 + j] % G::P == w[j];
+                const bool c0 = j != 0 || (no[48 * i + 16] < G::P && no[48 * i + 32] < G::P);
+                if (!(f0 && f1 && f2 && c0) && bad++ < 12) printf("MISMATCH network i=%d slot %d dif %d dit-lazy %d inv-lazy %d slot0-canonical %d\n", i, j, f0, f1, f2, c0);
+            }
         }
     }
     printf("field_check: %d mismatches\n", bad);
