@@ -201,6 +201,8 @@ struct Goldilocks {
     }
 #endif
     SR_HD static elem neg(elem a) { return a ? P - a : 0; }
+    // any 64-bit representative -> the canonical one (representatives >= p exist only for values below 2^32 - 1)
+    SR_HD static elem canon(elem a) { return a >= P ? a - P : a; }
     // s = a + b, d = a - b in one go: every butterfly needs both.  Same seven VALU as add + sub, but as ONE asm statement the two carry
     // chains fill each other's wait states (one s_nop 0 instead of two s_nop 1) and the EXEC mask is saved and restored once
     // (three SALU instead of four).  SR_GL_FUSED_BF = 1 makes the butterflies of ntt_goldilocks.hpp use it (A/B switch, round 3).

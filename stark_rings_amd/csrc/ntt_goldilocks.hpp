@@ -689,6 +689,20 @@ SR_HD void cols_stage_inv(u64 *x, std::integer_sequence<int, Js...>) {
 }
 #endif
 
+// SR_GL_TWIST_IN_ROWS = 1 (experiment, round 3): for D = 2^16 the inverse twist gamma_b^-i D^-1 is applied by rows256 to its results
+// instead of by the inverse column pass to its operands (whose 16 table loads then no longer sit in front of its first butterfly)
+// SR_GL_LAZY_TILE: the 4096-point rows kernels behind a column pass (D >= 2^13) take the lazy networks too
+// SR_GL_LAZY_CANON = 0 leaves out the canonicalisation of the product-free value in front of an inverse network: the build
+// tests/test_gpu_parity.py::test_goldilocks_inverse_with_lazy_sums_landing_on_p was checked to FAIL on (test of the test)
+#ifndef SR_GL_LAZY_CANON
+#define SR_GL_LAZY_CANON 1
+#endif
+#ifndef SR_GL_LAZY_TILE
+#define SR_GL_LAZY_TILE 1
+#endif
+#ifndef SR_GL_TWIST_IN_ROWS
+#define SR_GL_TWIST_IN_ROWS 0
+#endif
 // LC = log2 of the columns a workgroup owns: 16 << LC lanes, 256 legs x 2^LC consecutive columns (2^LC x 8-byte segments).
 // Wider segments stream better (tools/ubench/strided_pattern.hip: 4.7 / 5.1 / 6.1 TB/s for 16 / 32 / 64 columns) at the price of
 // fewer, larger workgroups.  LC = 4 pads the LDS tile (a 32-lane LDS group spans two legs); LC >= 5 needs no padding: every
@@ -770,16 +784,22 @@ __device__ __forceinline__ void cols256_tile(const unsigned tile, u64 *data, con
         for (int sg = 0; sg < 16; sg++) *reinterpret_cast<u64 *>(pb + (offB + (unsigned)sg * leg)) = x[sg] ^ tw[sg];
 #endif
     } else {
-        u64 tw[16];
         prio_mem();
+        if (SR_GL_TWIST_IN_ROWS && k == 16) {   // rows256 multiplied its results by gamma_b^-i D^-1 on the way out
 #pragma unroll
-        for (int sg = 0; sg < 16; sg++) {
-            x[sg] = ld_scratch(reinterpret_cast<const u64 *>(ps + (offB + (unsigned)sg * leg)));
-            tw[sg] = *reinterpret_cast<const u64 *>(tb + (offB + (unsigned)sg * leg));
+            for (int sg = 0; sg < 16; sg++) x[sg] = ld_scratch(reinterpret_cast<const u64 *>(ps + (offB + (unsigned)sg * leg)));
+            prio_alu();
+        } else {
+            u64 tw[16];
+#pragma unroll
+            for (int sg = 0; sg < 16; sg++) {
+                x[sg] = ld_scratch(reinterpret_cast<const u64 *>(ps + (offB + (unsigned)sg * leg)));
+                tw[sg] = *reinterpret_cast<const u64 *>(tb + (offB + (unsigned)sg * leg));
+            }
+            prio_alu();
+#pragma unroll
+            for (int sg = 0; sg < 16; sg++) x[sg] = G::mul(x[sg], tw[sg]);
         }
-        prio_alu();
-#pragma unroll
-        for (int sg = 0; sg < 16; sg++) x[sg] = G::mul(x[sg], tw[sg]);
         dft16_inv_hot(x);
 #pragma unroll
         for (int j = 0; j < 16; j++) lds[CT::idx(16 * rg + j, col)] = x[j];
@@ -818,9 +838,13 @@ __global__ __launch_bounds__(16 << LC, LC == 4 ? SR_COLS_WAVES : 4) void cols256
 //   of the radix-16 only; the negacyclic twist psi^(256 row + t) is split into a compile-time shift per register slot
 //   ((psi^256)^row, twist_rows) and the column factor psi^t, which commutes with that pass and lives in the w1 table;
 //   nvalid (a multiple of D) guards a ragged last tile.
-template <int Q, bool TW, int P = SR_GL_PHASE_GROUP>
+// CANON (plain forward transform): the slots leave the library as they are, so the last network runs canonical butterflies.
+// Twisted 4096-point blocks (TW = false, Q = 0) take the lazy DIT networks like the D = 2^16 kernels; whole-ring-element tiles and the
+// 512..2048-point blocks of D = 2^17..2^19 keep the DIF ones (their partial networks dft16_fwd_q start in the middle of a DFT_16).
+template <int Q, bool TW, int P = SR_GL_PHASE_GROUP, bool CANON = false>
 __device__ __forceinline__ void tile_fwd(const u64 *__restrict__ src, u64 *lds, const int t, const Tables &T, u64 *x,
                                          int nvalid) {
+    constexpr bool LZ = !TW && Q == 0 && SR_GL_LAZY_DIT == 1 && SR_GL_LAZY_TILE;  // Q > 0: 512..2048-point blocks start inside a DFT_16
 #pragma unroll
     for (int j = 0; j < 16; j++) {
         const int pos = j * 256 + t;
@@ -829,7 +853,8 @@ __device__ __forceinline__ void tile_fwd(const u64 *__restrict__ src, u64 *lds, 
         x[j] = TW ? ld_stream(src + (pos < nvalid ? pos : nvalid - 1)) : ld_scratch(src + pos);  // TW: operands; else column-pass output
     }
     if (TW) twist_rows<Q, false>(x, std::make_integer_sequence<int, 16>{});
-    dft16_fwd_q<Q, P>(x);
+    if constexpr (LZ) dft16_fwd_dit<P, true>(x);
+    else dft16_fwd_q<Q, P>(x);
     if (TW) x[0] = G::mul(x[0], T.w1f[t]);  // psi^t: with the twist merged in, slot 0 is no longer multiplied by 1
 #pragma unroll
     for (int r = 1; r < 16; r++) x[r] = G::mul(x[r], T.w1f[r * 256 + t]);
@@ -839,7 +864,8 @@ __device__ __forceinline__ void tile_fwd(const u64 *__restrict__ src, u64 *lds, 
     const int i0 = t & 15, base2 = (t >> 4) * 256 + i0;
 #pragma unroll
     for (int j = 0; j < 16; j++) x[j] = lds[pad(base2 + j * 16)];
-    dft16_fwd<P>(x);
+    if constexpr (LZ) dft16_fwd_dit<P, true>(x);
+    else dft16_fwd<P>(x);
 #pragma unroll
     for (int s = 1; s < 16; s++) x[s] = G::mul(x[s], T.w2f[s * 16 + i0]);
 #pragma unroll
@@ -847,7 +873,8 @@ __device__ __forceinline__ void tile_fwd(const u64 *__restrict__ src, u64 *lds, 
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < 16; j++) x[j] = lds[17 * t + j];
-    dft16_fwd<P>(x);
+    if constexpr (LZ) dft16_fwd_dit<P, !CANON>(x);
+    else dft16_fwd<P>(x);
 }
 
 // inverse of tile_fwd; x[] holds positions 16 t .. 16 t + 15 on entry.  w1i is the plain or the fused-product table.
@@ -855,7 +882,8 @@ __device__ __forceinline__ void tile_fwd(const u64 *__restrict__ src, u64 *lds, 
 template <int Q, bool TW, int P = SR_GL_PHASE_GROUP>
 __device__ __forceinline__ void tile_inv(u64 *x, u64 *lds, const int t, const Tables &T, const u64 *w1i,
                                          u64 *__restrict__ dst, int nvalid) {
-    dft16_inv<P>(x);
+    constexpr bool LZ = !TW && Q == 0 && SR_GL_LAZY_DIT != 0 && SR_GL_LAZY_TILE;  // results go on to an inverse column pass that multiplies first
+    dft16_inv<P, LZ>(x);
 #pragma unroll
     for (int j = 0; j < 16; j++) lds[17 * t + j] = x[j];
     __syncthreads();
@@ -864,7 +892,8 @@ __device__ __forceinline__ void tile_inv(u64 *x, u64 *lds, const int t, const Ta
     for (int s = 0; s < 16; s++) x[s] = lds[pad(base2 + s * 16)];
 #pragma unroll
     for (int s = 1; s < 16; s++) x[s] = G::mul(x[s], T.w2i[s * 16 + i0]);
-    dft16_inv<P>(x);
+    if (LZ && SR_GL_LAZY_CANON) x[0] = G::canon(x[0]);  // see tile256_inv
+    dft16_inv<P, LZ>(x);
 #pragma unroll
     for (int j = 0; j < 16; j++) lds[pad(base2 + j * 16)] = x[j];
     __syncthreads();
@@ -873,7 +902,9 @@ __device__ __forceinline__ void tile_inv(u64 *x, u64 *lds, const int t, const Ta
     if (TW) x[0] = G::mul(x[0], w1i[t]);  // psi^-t * D^-1
 #pragma unroll
     for (int r = 1; r < 16; r++) x[r] = G::mul(x[r], w1i[r * 256 + t]);
-    dft16_inv_q<Q, P>(x);
+    if (LZ && SR_GL_LAZY_CANON) x[0] = G::canon(x[0]);
+    if constexpr (LZ) dft16_inv<P, true>(x);
+    else dft16_inv_q<Q, P>(x);
     if (TW) twist_rows<Q, true>(x, std::make_integer_sequence<int, 16>{});
 #pragma unroll
     for (int j = 0; j < 16; j++) {
@@ -915,7 +946,7 @@ __global__ __launch_bounds__(256, TW ? SR_ROWS_WAVES_TW : SR_ROWS_WAVES) void ro
 #pragma unroll
         for (int j = 0; j < 16; j++) A[j] = lds[17 * t + j];
     } else {
-        tile_fwd<Q, TW, P>(a + base, lds, t, T, A, nvalid);
+        tile_fwd<Q, TW, P, MODE == 0>(a + base, lds, t, T, A, nvalid);
         if (MODE == 0) {
             // results sit 16-contiguous per lane; one more exchange makes the global store lane-contiguous
 #pragma unroll
@@ -982,7 +1013,9 @@ __device__ __forceinline__ void tile256_fwd(const u64 *__restrict__ src, u64 *ld
     tile256_load(src, t, x);
     tile256_fwd_regs<CANON>(lds, t, T, x);
 }
-__device__ __forceinline__ void tile256_inv(u64 *x, u64 *lds, const int t, const Tables &T, u64 *__restrict__ dst) {
+// twi: this tile's 4096 entries of the inverse twist table (SR_GL_TWIST_IN_ROWS), or unused
+__device__ __forceinline__ void tile256_inv(u64 *x, u64 *lds, const int t, const Tables &T, u64 *__restrict__ dst,
+                                            const u64 *__restrict__ twi) {
     const int i0 = t & 15, base2 = (t >> 4) * 256 + i0;
     dft16_inv_hot(x);
 #pragma unroll
@@ -992,7 +1025,19 @@ __device__ __forceinline__ void tile256_inv(u64 *x, u64 *lds, const int t, const
     for (int s = 0; s < 16; s++) x[s] = lds[pad(base2 + s * 16)];
 #pragma unroll
     for (int s = 1; s < 16; s++) x[s] = G::mul(x[s], T.w2i[s * 16 + i0]);
+    // x[0] skips the table product (its factor is 1) but is slot i0 of ANOTHER lane's network, a lazy representative: the twiddle-1
+    // butterflies of the next network want it canonical
+    if (SR_GL_LAZY_DIT && SR_GL_LAZY_CANON) x[0] = G::canon(x[0]);
+#if SR_GL_TWIST_IN_ROWS
+    u64 tw[16];
+#pragma unroll
+    for (int j = 0; j < 16; j++) tw[j] = twi[base2 + j * 16];
+#endif
     dft16_inv_hot(x);
+#if SR_GL_TWIST_IN_ROWS
+#pragma unroll
+    for (int j = 0; j < 16; j++) x[j] = G::mul(x[j], tw[j]);
+#endif
 #pragma unroll
     for (int j = 0; j < 16; j++) st_scratch(dst + base2 + j * 16, x[j]);
 }
@@ -1050,7 +1095,7 @@ __device__ __forceinline__ void rows256_tile(const unsigned tile, u64 *a, const 
 #pragma unroll
         for (int j = 0; j < 16; j++) A[j] = G::mul(A[j], B[j]);
     }
-    tile256_inv(A, lds, t, T, out + base);
+    tile256_inv(A, lds, t, T, out + base, (MODE == 1 ? T.twist_i_plain : T.twist_i_mul) + (size_t)(tile & 15u) * kTile);
 }
 template <int MODE>
 __global__ __launch_bounds__(256, 4) void rows256_kernel(u64 *a, const u64 *b, u64 *out, Tables T) {

@@ -38,7 +38,8 @@ def ring_for(name, k):
 
 
 def edge_and_random(F, k, batch, seed):
-    """batch elements: all-zero, all-(p-1), 1, X^(D-1), then uniform."""
+    """batch elements: all-zero, all-(p-1), 1, X^(D-1), then uniform -- the LAST element always stays uniform (a batch of one is
+    one uniform element: a lone zero polynomial would let any linear kernel through)."""
     name = [n for n, f in O.FIELD_ID.items() if f == F][0]
     p = P.PRIMES[name][0]
     L = O.LIMBS[F]
@@ -50,7 +51,7 @@ def edge_and_random(F, k, batch, seed):
     specials.append([1] + [0] * (d - 1))
     specials.append([0] * (d - 1) + [1])
     for i, s in enumerate(specials):
-        if i < batch:
+        if i + 1 < batch:
             data[i] = O.to_mont(F, s)
     return np.ascontiguousarray(data.reshape(-1))
 
@@ -1881,3 +1882,43 @@ def test_packed32_entry_points_refuse_other_rings(torch_cuda):
     with pytest.raises(RingError, match="alias"):
         bb.mul_packed32_dev(t32, t32.clone(), t32)
 
+
+
+# ----------------------------------------------------------------------------- lazy butterflies: representatives that land on p
+@pytest.mark.gpu
+@pytest.mark.parametrize("k,batch", [(16, 2), (17, 1)])
+def test_goldilocks_inverse_with_lazy_sums_landing_on_p(torch_cuda, k, batch):
+    """The inverse rows kernels run decimation-in-time butterflies whose sums and differences are lazy 64-bit representatives
+    (ntt_goldilocks.hpp, SR_GL_LAZY_DIT).  A representative differs from the canonical value only when a sum lands in [p, 2^64) --
+    probability 2^-32 per value on uniform data, certain on inputs built for it: here every 256-block of the NTT-domain operand
+    starts with sixteen words for which one output of the first 16-point network is 0 mod p with non-zero legs, so that the lazy sum
+    is p itself, in the very slot that reaches the next network WITHOUT a table product in front (factor 1) -- the value
+    G::canon exists for.  Whole transforms against the oracle, every word; plus the product of such operands."""
+    import os
+    import random
+    import sys
+
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import model_fast_goldilocks as M
+
+    F = O.GOLDILOCKS
+    d = 1 << k
+    ring = ring_for("goldilocks", k)
+    rng = random.Random(0x1A2 + k)
+    raw = O.fill_uniform(F, 0x51 + k, 0, batch * d).copy()
+    hits = 0
+    for blk in range(batch * d // 256):
+        slot = 1 + blk % 15
+        words = M.crafted_inverse_block(rng, slot)
+        hits += M.dft16_inv_lazy(words)[slot] == M.p
+        raw[blk * 256:blk * 256 + 16] = np.array(words, dtype=np.uint64)
+    assert hits > batch * d // 256 // 4, "the crafted blocks do not leave the representative p (%d)" % hits
+    want = O.pow2_inv(F, raw, k, batch, 4)
+    got = ring.elementwise_icrt(raw.copy())
+    assert np.array_equal(got, want)
+    assert np.array_equal(ring.elementwise_crt(got.copy()), raw)
+    # the fused product runs the same inverse networks on crt(a) (.) crt(b): choose a = icrt(raw), b = icrt(R^2-image of 1 in every slot)
+    # so that the slot product hands the inverse exactly `raw` again (mul_boundary(x, R) = x)
+    one = O.to_mont(F, [1] * (batch * d))           # Montgomery image of 1 in every NTT slot
+    b = O.pow2_inv(F, one, k, batch, 4)
+    assert np.array_equal(ring.mul(want, b), want)

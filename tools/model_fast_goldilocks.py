@@ -505,6 +505,126 @@ def rows256_inv(row, T):
     return y
 
 
+# ------------------------------------------------------------------------------------------------
+# Whole tiles on representatives, as the kernels run them (round 3): lazy networks, table products that SKIP index 0 (factor 1),
+# and G::canon on the one value per lane that reaches a network without a product in front of it although it is an arbitrary slot
+# of another lane's lazy network (inverse direction only: in the forward direction the skipped value is slot 0 of the lane's own
+# network, canonical by construction).  canon=False reproduces the tile without that step: the twiddle-1 butterflies then see
+# non-canonical inputs (canon_bf asserts) on inputs built to make a lazy sum land on p exactly -- see crafted_inverse_block.
+# ------------------------------------------------------------------------------------------------
+def rows256_fwd_lazy(row, T, last_canonical=False):
+    y = list(row)
+    for i0 in range(16):
+        x = dft16_fwd_dit([y[j * 16 + i0] for j in range(16)], lazy=True)
+        y[i0] = x[0]                                                    # slot 0: no product
+        assert x[0] < p
+        for s_ in range(1, 16):
+            y[s_ * 16 + i0] = x[s_] * T["W2f"][s_][i0] % p
+    for t in range(16):
+        y[16 * t:16 * t + 16] = dft16_fwd_dit(y[16 * t:16 * t + 16], lazy=not last_canonical)
+    return y
+
+
+def rows256_inv_lazy(row, T, canon=True):
+    y = list(row)
+    for t in range(16):
+        y[16 * t:16 * t + 16] = dft16_inv_lazy(y[16 * t:16 * t + 16])
+    for i0 in range(16):
+        xs = [y[i0]] + [y[s_ * 16 + i0] * T["W2i"][s_][i0] % p for s_ in range(1, 16)]
+        if canon:
+            xs[0] %= p                                                  # G::canon
+        x = dft16_inv_lazy(xs)
+        for j in range(16):
+            y[j * 16 + i0] = x[j]
+    return y
+
+
+def rows_fwd_lazy(tile, T, last_canonical=False):
+    y = list(tile)
+    for t in range(256):
+        x = dft16_fwd_dit([y[j * 256 + t] for j in range(16)], lazy=True)
+        y[t] = x[0]
+        for r in range(1, 16):
+            y[r * 256 + t] = x[r] * T["W1f"][r][t] % p
+    for t in range(256):
+        rho, i0 = t >> 4, t & 15
+        x = dft16_fwd_dit([y[rho * 256 + j * 16 + i0] for j in range(16)], lazy=True)
+        y[rho * 256 + i0] = x[0]
+        for s_ in range(1, 16):
+            y[rho * 256 + s_ * 16 + i0] = x[s_] * T["W2f"][s_][i0] % p
+    for t in range(256):
+        y[16 * t:16 * t + 16] = dft16_fwd_dit(y[16 * t:16 * t + 16], lazy=not last_canonical)
+    return y
+
+
+def rows_inv_lazy(tile, T, canon=True):
+    y = list(tile)
+    for t in range(256):
+        y[16 * t:16 * t + 16] = dft16_inv_lazy(y[16 * t:16 * t + 16])
+    for t in range(256):
+        rho, i0 = t >> 4, t & 15
+        xs = [y[rho * 256 + i0]] + [y[rho * 256 + s_ * 16 + i0] * T["W2i"][s_][i0] % p for s_ in range(1, 16)]
+        if canon:
+            xs[0] %= p
+        x = dft16_inv_lazy(xs)
+        for j in range(16):
+            y[rho * 256 + j * 16 + i0] = x[j]
+    for t in range(256):
+        xs = [y[t]] + [y[r * 256 + t] * T["W1i"][r][t] % p for r in range(1, 16)]
+        if canon:
+            xs[0] %= p
+        x = dft16_inv_lazy(xs)
+        for j in range(16):
+            y[j * 256 + t] = x[j]
+    return y
+
+
+def crafted_inverse_block(rng, slot):
+    """16 canonical inputs of dft16_inv whose output `slot` is 0 mod p while the two legs of its last butterfly are not: the lazy sum
+    leaves the representative p there (a + t = p exactly).  The network is linear: fix 15 inputs, solve for the last."""
+    base = [rng.randrange(1, p) for _ in range(15)] + [0]
+    unit = [0] * 15 + [1]
+    f0 = dft16_inv(base)[slot]
+    f1 = dft16_inv(unit)[slot]
+    base[15] = (-f0) * pow(f1, -1, p) % p
+    assert dft16_inv(base)[slot] == 0
+    return base
+
+
+def check_lazy_tiles(seed=21):
+    rng = random.Random(seed)
+    T16 = cols_tables(16)
+    T12 = tables(13)
+    # random tiles: lazy == canonical modulo p, both directions, both tile sizes
+    row = [rng.randrange(p) for _ in range(256)]
+    assert [v % p for v in rows256_fwd_lazy(row, T16)] == rows256_fwd(row, T16)
+    assert rows256_fwd_lazy(row, T16, last_canonical=True) == rows256_fwd(row, T16)
+    assert [v % p for v in rows256_inv_lazy(row, T16)] == rows256_inv(row, T16)
+    tile = [rng.randrange(p) for _ in range(4096)]
+    assert [v % p for v in rows_fwd_lazy(tile, T12)] == rows_fwd(tile, T12)
+    assert rows_fwd_lazy(tile, T12, last_canonical=True) == rows_fwd(tile, T12)
+    assert [v % p for v in rows_inv_lazy(tile, T12)] == rows_inv(tile, T12)
+    # crafted: the 16-blocks that feed the product-free x[0] of the next network (lanes 16 m) leave the representative p in slots 1..15
+    hits = 0
+    for slot in range(1, 16):
+        row = [rng.randrange(p) for _ in range(256)]
+        row[0:16] = crafted_inverse_block(rng, slot)                    # lane 0: its slot `slot` is lane `slot`'s x[0]
+        first = dft16_inv_lazy(row[0:16])
+        if first[slot] == p:
+            hits += 1
+            try:
+                rows256_inv_lazy(row, T16, canon=False)
+                raise SystemExit("the uncanonicalised tile went through: the crafted input does not bite")
+            except AssertionError:
+                pass
+        assert [v % p for v in rows256_inv_lazy(row, T16)] == rows256_inv(row, T16)
+        tile = [rng.randrange(p) for _ in range(4096)]
+        tile[0:16] = crafted_inverse_block(rng, slot)
+        assert [v % p for v in rows_inv_lazy(tile, T12)] == rows_inv(tile, T12)
+    assert hits >= 4, "crafted blocks never produced the representative p (%d)" % hits
+    return True
+
+
 def check_cols256(k=16, seed=5):
     rng = random.Random(seed)
     T = cols_tables(k)
@@ -563,4 +683,6 @@ if __name__ == "__main__":
     print("cols256 + rows256 k=16 ok")
     check_lazy_networks()
     print("lazy DIT networks ok")
+    check_lazy_tiles()
+    print("lazy tiles ok")
     print("model OK")
