@@ -1886,14 +1886,17 @@ def test_packed32_entry_points_refuse_other_rings(torch_cuda):
 
 # ----------------------------------------------------------------------------- lazy butterflies: representatives that land on p
 @pytest.mark.gpu
-@pytest.mark.parametrize("k,batch", [(16, 2), (17, 1)])
+@pytest.mark.parametrize("k,batch", [(16, 2), (17, 1), (13, 3), (20, 1)])
 def test_goldilocks_inverse_with_lazy_sums_landing_on_p(torch_cuda, k, batch):
     """The inverse rows kernels run decimation-in-time butterflies whose sums and differences are lazy 64-bit representatives
     (ntt_goldilocks.hpp, SR_GL_LAZY_DIT).  A representative differs from the canonical value only when a sum lands in [p, 2^64) --
     probability 2^-32 per value on uniform data, certain on inputs built for it: here every 256-block of the NTT-domain operand
     starts with sixteen words for which one output of the first 16-point network is 0 mod p with non-zero legs, so that the lazy sum
     is p itself, in the very slot that reaches the next network WITHOUT a table product in front (factor 1) -- the value
-    G::canon exists for.  Whole transforms against the oracle, every word; plus the product of such operands."""
+    G::canon exists for.  D = 2^13 and 2^20 run 4096-point tiles (three networks): there the first 256-block of every tile is built
+    so that the SECOND-level networks leave p where the third takes it (tools/model_fast_goldilocks.py: crafted_inverse_block256).
+    Whole transforms against the oracle, every word; plus the product of such operands.  The build without the canonicalisation
+    (-DSR_GL_LAZY_CANON=0) fails this test."""
     import os
     import random
     import sys
@@ -1912,6 +1915,11 @@ def test_goldilocks_inverse_with_lazy_sums_landing_on_p(torch_cuda, k, batch):
         words = M.crafted_inverse_block(rng, slot)
         hits += M.dft16_inv_lazy(words)[slot] == M.p
         raw[blk * 256:blk * 256 + 16] = np.array(words, dtype=np.uint64)
+    if k in (13, 20):
+        T = M.tables(13)
+        for tile in range(batch * d // 4096):
+            slots = [1 + (i0 * 7 + tile) % 15 for i0 in range(16)]
+            raw[tile * 4096:tile * 4096 + 256] = np.array(M.crafted_inverse_block256(rng, T, slots), dtype=np.uint64)
     assert hits > batch * d // 256 // 4, "the crafted blocks do not leave the representative p (%d)" % hits
     want = O.pow2_inv(F, raw, k, batch, 4)
     got = ring.elementwise_icrt(raw.copy())

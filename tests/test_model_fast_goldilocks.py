@@ -63,3 +63,11 @@ def test_lazy_decimation_in_time_networks_keep_their_invariants():
     canonical inputs, slot 0 stays canonical, and every result is the canonical network's modulo p (representatives modelled bit
     for bit, edge values included)."""
     assert M.check_lazy_networks(seed=10, rounds=300)
+
+
+def test_lazy_tiles_need_the_canonicalised_skip_value_and_have_it():
+    """Whole 256-point and 4096-point tiles on representatives, table products skipping index 0 as the kernels do: equal to the
+    canonical tiles modulo p in both directions; on operands built so that a lazy sum lands on p in the value that reaches the next
+    inverse network without a product in front (first level: crafted_inverse_block, second level: crafted_inverse_block256) the tile
+    WITHOUT G::canon trips the canonical-input assertion of a twiddle-1 butterfly, the tile with it is right."""
+    assert M.check_lazy_tiles(seed=22)

@@ -591,6 +591,24 @@ def crafted_inverse_block(rng, slot):
     return base
 
 
+def crafted_inverse_block256(rng, T, slots):
+    """256 canonical inputs of one 256-block of an inverse tile (16 first-level networks, table products, 16 second-level networks)
+    such that the SECOND-level network of lane i0 leaves 0 mod p with non-zero legs in its output slots[i0]: the value the third
+    network of a 4096-point tile takes without a product in front.  Built backwards: second-level inputs by crafted_inverse_block,
+    divided by the table factors, pulled through the inverse of the first-level network (dft16_fwd / 16)."""
+    inv16 = pow(16, -1, p)
+    y = [0] * 256
+    for i0 in range(16):
+        xs = crafted_inverse_block(rng, slots[i0])
+        for s_ in range(16):
+            y[s_ * 16 + i0] = xs[s_] * (pow(T["W2i"][s_][i0], -1, p) if s_ else 1) % p
+    out = []
+    for t in range(16):
+        out += [v * inv16 % p for v in dft16_fwd(y[16 * t:16 * t + 16])]
+    assert [v % p for v in sum((dft16_inv(out[16 * t:16 * t + 16]) for t in range(16)), [])] == y
+    return out
+
+
 def check_lazy_tiles(seed=21):
     rng = random.Random(seed)
     T16 = cols_tables(16)
@@ -622,6 +640,15 @@ def check_lazy_tiles(seed=21):
         tile[0:16] = crafted_inverse_block(rng, slot)
         assert [v % p for v in rows_inv_lazy(tile, T12)] == rows_inv(tile, T12)
     assert hits >= 4, "crafted blocks never produced the representative p (%d)" % hits
+    # second level (4096-point tiles): block 0 of the tile built so that the second-level networks leave p where the third takes it
+    tile = [rng.randrange(p) for _ in range(4096)]
+    tile[0:256] = crafted_inverse_block256(rng, T12, [1 + (i0 * 7) % 15 for i0 in range(16)])
+    try:
+        rows_inv_lazy(tile, T12, canon=False)
+        raise SystemExit("the uncanonicalised 4096-point tile went through: the second-level crafted block does not bite")
+    except AssertionError:
+        pass
+    assert [v % p for v in rows_inv_lazy(tile, T12)] == rows_inv(tile, T12)
     return True
 
 
