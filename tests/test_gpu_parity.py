@@ -1930,3 +1930,57 @@ def test_goldilocks_inverse_with_lazy_sums_landing_on_p(torch_cuda, k, batch):
     one = O.to_mont(F, [1] * (batch * d))           # Montgomery image of 1 in every NTT slot
     b = O.pow2_inv(F, one, k, batch, 4)
     assert np.array_equal(ring.mul(want, b), want)
+
+
+def _structured_operands(F, name, k, seed):
+    """ring elements whose transforms are full of coincidences (equal legs, zero differences, sums that land on 0 or p): small and
+    signed-small coefficients, monomials, constants, alternating signs, a geometric sequence of a root of unity, sparse supports"""
+    import random
+
+    p = P.PRIMES[name][0]
+    d = 1 << k
+    rng = random.Random(seed)
+    els = []
+    els.append([1] * d)                                                    # constant 1 in every coefficient
+    els.append([(p - 1) if i & 1 else 1 for i in range(d)])                # +-1 alternating
+    els.append([rng.choice((0, 1, p - 1)) for _ in range(d)])              # ternary
+    els.append([rng.randrange(4) for _ in range(d)])                       # tiny
+    mono = [0] * d
+    mono[d // 2] = 1
+    els.append(mono)                                                       # X^(D/2)
+    sparse = [0] * d
+    for i in rng.sample(range(d), min(d, 5)):
+        sparse[i] = rng.choice((1, p - 1, 2, p - 2))
+    els.append(sparse)
+    w = pow(7, (p - 1) // (2 * d), p) if (p - 1) % (2 * d) == 0 else 3
+    geo, acc = [], 1
+    for i in range(d):
+        geo.append(acc)
+        acc = acc * w % p
+    els.append(geo)                                                        # psi^i: its transform is a single spike (or nearly)
+    els.append([(p - v) % p for v in geo])                                 # and its negative
+    half = [rng.randrange(p) for _ in range(d // 2)]
+    els.append(half + half)                                                # period D/2
+    els.append([p - 1] * d)
+    return els
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,k", [("goldilocks", 10), ("goldilocks", 12), ("goldilocks", 13), ("goldilocks", 16), ("goldilocks", 17),
+                                    ("goldilocks", 20), ("babybear", 12), ("babybear", 16), ("stark", 10)])
+def test_structured_operands_through_every_tuned_plan(torch_cuda, name, k):
+    """Uniform data hardly ever produces equal butterfly legs, zero differences or sums that land exactly on 0 or p; these operands
+    do, all the time.  Transforms, inverse transforms and products (each operand with each) against the oracle, every word."""
+    F = O.FIELD_ID[name]
+    ring = ring_for(name, k)
+    els = _structured_operands(F, name, k, 0x5EED + k)
+    n = len(els)
+    a = O.to_mont(F, [v for e in els for v in e])
+    fa = ring.elementwise_crt(a.copy())
+    assert np.array_equal(fa, O.pow2_fwd(F, a, k, n, 4))
+    assert np.array_equal(ring.elementwise_icrt(fa.copy()), a)
+    L = O.LIMBS[F]
+    a2 = a.reshape(n, -1)
+    for shift in (0, 1, 3, 7):
+        b = np.ascontiguousarray(np.roll(a2, shift, axis=0)).reshape(-1)
+        assert np.array_equal(ring.mul(a, b), O.pow2_ring_mul(F, a, b, k, n, 4)), "shift %d" % shift
