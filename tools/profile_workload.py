@@ -271,6 +271,7 @@ def readme(outdir):
     md.append("  `experiments_gl_bench.txt` -- tools/ubench/gl_bench.hip A/B runs of the butterfly scheduling variants; `bench_babybear_packed_sweep.jsonl`, `bench_stark_cols_ab.jsonl` -- chunk sweep / `cols256x2_kernel` and the per-column Stark product, same-box A/B.")
     md.append("* `ab_lazy_dit.txt`, `ab_mul_lohi.txt`, `ab_twist_in_rows.txt`, `ab_chunks_and_streams.txt` -- same-box alternations of tools/ubench/gl_bench.hip builds (`-DSR_GL_LAZY_DIT=0/1/2`, `-DSR_GL_MUL_LOHI=1`, `-DSR_GL_TWIST_IN_ROWS=1`), DESIGN.md 6.0;")
     md.append("  `pmc_icache_waits.txt` -- `SQC_ICACHE_*`, `SQ_WAVE_CYCLES`, `SQ_WAIT_INST_ANY`, `SQ_ACTIVE_INST_VALU` per kernel of the headline workload (tools/pmc_by_kernel.py).")
+    md.append("* `power_goldilocks_d65536_b16384.txt` (+ the two raw rocm-smi sample files) -- socket power, sclk and joules per batch of the headline workload, two lanes and one stream (tools/power_trace.sh).")
     md.append("* `bench_matvec.txt` (mat-vec and mat-mat, incl. the three reference rings as integer sums), `bench_small_rings.txt`, `bench_transforms.txt`, `bench_host_boundary.txt` (caller pages registered against pageable) -- the tools/bench_*.py scripts.")
     md.append("* `gpu_tests.log` -- `python -m pytest tests -m gpu -x -q` at the final source hash: 315 passed (the crafted-operand and structured-operand cases added behind it pass as well: 13 more).")
     open(os.path.join(outdir, "README.md"), "w").write("\n".join(md) + "\n")
