@@ -273,7 +273,7 @@ def readme(outdir):
     md.append("  `pmc_icache_waits.txt` -- `SQC_ICACHE_*`, `SQ_WAVE_CYCLES`, `SQ_WAIT_INST_ANY`, `SQ_ACTIVE_INST_VALU` per kernel of the headline workload (tools/pmc_by_kernel.py).")
     md.append("* `power_goldilocks_d65536_b16384.txt` (+ the two raw rocm-smi sample files) -- socket power, sclk and joules per batch of the headline workload, two lanes and one stream (tools/power_trace.sh).")
     md.append("* `bench_matvec.txt` (mat-vec and mat-mat, incl. the three reference rings as integer sums), `bench_small_rings.txt`, `bench_transforms.txt`, `bench_host_boundary.txt` (caller pages registered against pageable) -- the tools/bench_*.py scripts.")
-    md.append("* `gpu_tests.log` -- `python -m pytest tests -m gpu -x -q` at the final source hash: 315 passed (the crafted-operand and structured-operand cases added behind it pass as well: 13 more).")
+    md.append("* `gpu_tests.log` -- `python -m pytest tests -m gpu -x -q` at the final tree: 326 passed, 2 min 47 s.")
     open(os.path.join(outdir, "README.md"), "w").write("\n".join(md) + "\n")
     print("\n".join(md[:22]))
 
