@@ -273,6 +273,7 @@ def readme(outdir):
     md.append("  `pmc_icache_waits.txt` -- `SQC_ICACHE_*`, `SQ_WAVE_CYCLES`, `SQ_WAIT_INST_ANY`, `SQ_ACTIVE_INST_VALU` per kernel of the headline workload (tools/pmc_by_kernel.py).")
     md.append("* `power_goldilocks_d65536_b16384.txt` (+ the two raw rocm-smi sample files) -- socket power, sclk and joules per batch of the headline workload, two lanes and one stream (tools/power_trace.sh).")
     md.append("* `bench_matvec.txt` (mat-vec and mat-mat, incl. the three reference rings as integer sums), `bench_small_rings.txt`, `bench_transforms.txt`, `bench_host_boundary.txt` (caller pages registered against pageable) -- the tools/bench_*.py scripts.")
+    md.append("* `full_parity_extra.txt` -- every word of products and transforms at Goldilocks degrees 2^10 ... 2^20 outside the suite's BASELINE shapes (tools/fuzz_full_parity.py); `fuzz_random.txt` -- 500 s of random ring / degree / batch / operation against the oracle.")
     md.append("* `gpu_tests.log` -- `python -m pytest tests -m gpu -x -q` at the final tree: 326 passed, 2 min 47 s.")
     open(os.path.join(outdir, "README.md"), "w").write("\n".join(md) + "\n")
     print("\n".join(md[:22]))
