@@ -264,7 +264,7 @@ def readme(outdir):
     md.append("* `bench_default.json` -- plain `python bench.py --steps 10 --warmup 3` (with the CPU baseline leg; the plan is the library's own choice, quoted in `config.plan`);")
     md.append("  `bench_one_stream.json` -- `--lanes 1`; `bench_ntt_rhs.json` -- `--variant mul_ntt_rhs`; `bench_force_dist.json` -- `--force-dist` (one-rank `nccl` group: the RCCL path on one GPU);")
     md.append("  `bench_babybear.json`, `bench_babybear_packed.json` (the opt-in packed-u32 boundary), `bench_stark.json`, `bench_c4_shard.json`, `bench_config0.json` (BASELINE configs[0]: D = 2^10, batch 1) -- the other")
-    md.append("  BASELINE configs; `bench_2rank_gloo.json` -- `python bench.py --gpus 2 --backend gloo --batch 4096` (bench.py launching its own two ranks on the one GPU of the box).")
+    md.append("  BASELINE configs; `bench_2rank_gloo.json`, `bench_4rank_gloo.json` -- `python bench.py --gpus 2 --backend gloo --batch 4096` / `--gpus 4 ... --batch 2048` (bench.py launching its own ranks on the one GPU of the box: a rehearsal of the sharding and of the rank bookkeeping, not a scaling figure).")
     md.append("* `bench_under_trace_<workload>.json`, `bench_under_pmc_SQ_<workload>.json` -- bench.py's own lines from inside the profiler runs (plan pinned with `--lanes` to what the library chose in a plain run).")
     md.append("* `arith_variants.txt` -- tools/ubench/arith_variants.hip: the current arithmetic against radix-64 passes and 24-bit limbs modulo 2^96 + 1, register-only (DESIGN.md 6.0);")
     md.append("  `stark_f64_product.txt` -- tools/ubench/stark_f64_product.hip: product part of a 260-bit multiplication on doubles against the nine-limb integer form; `stark_lazy_check.txt` -- device against host build of `StarkL::mul_tw`;")
