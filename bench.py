@@ -505,6 +505,7 @@ def main():
     if world == 1 and not args.no_cpu_baseline:
         import oracle_lib as O  # the timed CPU baseline (the parity check above used it as the checker)
 
+        cflags = O.use_native_build()  # the timed build is -O3 -march=native, compiled on this box for this box
         F = O.FIELD_ID[ring_name]
         cores = usable_cores()
         n0 = max(cores, 8)
@@ -527,7 +528,8 @@ def main():
         out["cpu_baseline"] = {
             "value": n / cpu_t, "unit": "ring-muls/s", "cores": cores, "kind": "port",
             "sample": "%d ring-muls of the same workload (D=2^%d), %d pthreads over the batch, %.1f s; "
-                      "C restatement of the reference CPU path (oracle/sr_oracle.c), not the Rust binary" % (n, k, cores, cpu_t),
+                      "C restatement of the reference CPU path (oracle/sr_oracle.c, gcc %s, built on this box), not the Rust binary"
+                      % (n, k, cores, cpu_t, cflags),
             "single_thread_value": n1 / cpu_t1,
         }
         out["gpu_over_cpu"] = value / (n / cpu_t)

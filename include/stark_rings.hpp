@@ -135,6 +135,13 @@ public:
     }
     void add_dev(uint64_t *lhs, const uint64_t *rhs, size_t batch, void *stream) const { check(sr_add_batch_dev(raw(), lhs, rhs, batch, stream), "add_dev"); }
     void sub_dev(uint64_t *lhs, const uint64_t *rhs, size_t batch, void *stream) const { check(sr_sub_batch_dev(raw(), lhs, rhs, batch, stream), "sub_dev"); }
+    // Neg, Mul<scalar>, Add<scalar> (coeff_form.rs:270-278, 390-408, 610-700; ntt_form.rs:191-203, 373-505); scalar: host pointer to the
+    // Montgomery image of the base-field element
+    void neg_dev(uint64_t *d, size_t batch, void *stream) const { check(sr_neg_batch_dev(raw(), d, batch, stream), "neg_dev"); }
+    void scale_dev(uint64_t *d, const uint64_t *scalar, size_t batch, void *stream) const { check(sr_scale_batch_dev(raw(), d, scalar, batch, stream), "scale_dev"); }
+    void add_scalar_dev(uint64_t *d, const uint64_t *scalar, bool ntt_form, size_t batch, void *stream) const {
+        check(sr_add_scalar_batch_dev(raw(), d, scalar, ntt_form ? 1 : 0, batch, stream), "add_scalar_dev");
+    }
     // out = a * b (RqPoly * &RqPoly); a, b only read; out may alias a
     void mul_dev(uint64_t *out, const uint64_t *a, const uint64_t *b, size_t batch, void *stream) const {
         check(sr_ring_mul_batch_dev(raw(), out, a, b, batch, stream), "mul_dev");
@@ -212,6 +219,21 @@ public:
         CyclotomicConfig::check(sr_sub_batch(cfg_.raw(), w_.data(), rhs.w_.data(), len()), "RqPoly -=");
         return *this;
     }
+    RqPolyVec operator-() && {                                   // coeff_form.rs:270-278
+        CyclotomicConfig::check(sr_neg_batch(cfg_.raw(), w_.data(), len()), "-RqPoly");
+        return std::move(*this);
+    }
+    // scalar: the Montgomery image of one base-field element (limbs() words) -- Mul<Fp>, Mul<u64> ... (coeff_form.rs:390-408, 610-650)
+    RqPolyVec &operator*=(const std::vector<uint64_t> &scalar) {
+        if (scalar.size() != (size_t)cfg_.limbs()) throw std::length_error("scalar: wrong number of limbs");
+        CyclotomicConfig::check(sr_scale_batch(cfg_.raw(), w_.data(), scalar.data(), len()), "RqPoly *= scalar");
+        return *this;
+    }
+    RqPolyVec &operator+=(const std::vector<uint64_t> &scalar) {  // coefficient 0 of every element (coeff_form.rs:652-700)
+        if (scalar.size() != (size_t)cfg_.limbs()) throw std::length_error("scalar: wrong number of limbs");
+        CyclotomicConfig::check(sr_add_scalar_batch(cfg_.raw(), w_.data(), scalar.data(), 0, len()), "RqPoly += scalar");
+        return *this;
+    }
     std::vector<uint64_t> into_words() && { return std::move(w_); }
 
 private:
@@ -251,6 +273,20 @@ public:
     RqNTTVec &operator-=(const RqNTTVec &rhs) {                  // ntt_form.rs:588-638
         if (rhs.w_.size() != w_.size()) throw std::length_error("operand lengths differ");
         CyclotomicConfig::check(sr_sub_batch(cfg_.raw(), w_.data(), rhs.w_.data(), len()), "RqNTT -=");
+        return *this;
+    }
+    RqNTTVec operator-() && {                                    // ntt_form.rs:191-203
+        CyclotomicConfig::check(sr_neg_batch(cfg_.raw(), w_.data(), len()), "-RqNTT");
+        return std::move(*this);
+    }
+    RqNTTVec &operator*=(const std::vector<uint64_t> &scalar) {  // `*lhs *= BaseCRTField::from(rhs)` (ntt_form.rs:373-425)
+        if (scalar.size() != (size_t)cfg_.limbs()) throw std::length_error("scalar: wrong number of limbs");
+        CyclotomicConfig::check(sr_scale_batch(cfg_.raw(), w_.data(), scalar.data(), len()), "RqNTT *= scalar");
+        return *this;
+    }
+    RqNTTVec &operator+=(const std::vector<uint64_t> &scalar) {  // component 0 of every slot (ntt_form.rs:427-505)
+        if (scalar.size() != (size_t)cfg_.limbs()) throw std::length_error("scalar: wrong number of limbs");
+        CyclotomicConfig::check(sr_add_scalar_batch(cfg_.raw(), w_.data(), scalar.data(), 1, len()), "RqNTT += scalar");
         return *this;
     }
     std::vector<uint64_t> into_words() && { return std::move(w_); }

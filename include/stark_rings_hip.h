@@ -58,7 +58,8 @@ enum sr_status {
     SR_E_INVALID = 1,   /* null pointer, bad ring id, bad degree, bad length */
     SR_E_NO_DEVICE = 2, /* no HIP device / device index out of range */
     SR_E_HIP = 3,       /* a HIP runtime call failed */
-    SR_E_ALLOC = 4
+    SR_E_ALLOC = 4,
+    SR_E_UNSUPPORTED = 5 /* the entry point exists but this build does not provide it (sr_selftest_rep_counters outside the checking build) */
 };
 
 typedef struct sr_ctx sr_ctx;
@@ -81,7 +82,9 @@ enum sr_plan_flags {
     SR_PLAN_GL_REGTILE = 1u << 3,       /* Goldilocks on the register-tiled path (cross-check of ntt_regtile.hpp)               */
     SR_PLAN_STARK_NO_LAZY = 1u << 4,    /* Stark transforms and sums on 8 x 32-bit limbs instead of nine 28-bit lazy limbs       */
     SR_PLAN_STARK_GENERIC_ON_LAZY = 1u << 5, /* Stark: generic LDS kernels on the lazy limbs instead of ntt_stark.hpp            */
-    SR_PLAN_NO_HOST_PIN = 1u << 6       /* host-pointer entry points: do not hipHostRegister the caller's buffers for the call   */
+    SR_PLAN_NO_HOST_PIN = 1u << 6,      /* accepted, no effect: host buffers are never registered (round 4 removed the pinning)  */
+    SR_PLAN_GL_PLAIN_COLS = 1u << 7     /* Goldilocks lane plans: the plain column pass instead of the workgroup-owns-its-columns
+                                           one (cols256_keep_kernel, ntt_goldilocks.hpp)                                          */
 };
 typedef struct sr_plan {
     uint32_t flags;               /* OR of sr_plan_flags                                                                       */
@@ -92,8 +95,10 @@ typedef struct sr_plan {
     uint64_t scratch_limit_bytes; /* cap of the operand scratch (0 = default 16 GiB); larger batches run in chunks             */
     uint32_t host_chunk_mb;       /* chunk of the host-pointer pipeline in MiB (0 = default 128)                               */
     uint32_t lanes;               /* chunked products (tuned Goldilocks 2^16 <= D <= 2^20, register-tiled BabyBear): 0 = AUTO -- the
-                                     library times both plans once on this process's real stream-to-hardware-queue mapping (inside
-                                     sr_ctx_reserve_scratch, or the first product large enough to be chunked) and keeps the winner;
+                                     library times the steady state of both plans once on this process's real stream-to-hardware-
+                                     queue mapping and keeps the faster.  The measurement runs ONLY inside sr_ctx_reserve_scratch
+                                     (a blocking call anyway); a context whose host never reserves runs two lanes, unmeasured --
+                                     no asynchronous _dev call ever probes, blocks on a measurement or breaks a stream capture;
                                      2 = two internal streams ("lanes"), chunks of chunk_polys or 64 MiB of coefficients each,
                                      intermediates in per-lane scratch so that they are re-read from the Infinity Cache;
                                      1 = one stream (eight large chunks, or chunk_polys).  sr_ctx_plan_in_use tells which.     */
@@ -105,9 +110,10 @@ int sr_ctx_create_ex(int ring, int log2_degree, int device, const sr_plan *plan,
  * (or accept that the first product of a new size blocks) and no _dev call blocks afterwards. */
 int sr_ctx_reserve_scratch(sr_ctx *ctx, size_t batch);
 /* The plan the context runs: *plan = the sr_plan it was created with, with lanes resolved to 1 or 2 once the library has settled it
- * (lanes stays 0 while sr_plan.lanes = 0 and no chunked product or sr_ctx_reserve_scratch has run yet).  probe_ms (optional):
- * what the probe measured, [0] two lanes, [1] one stream, milliseconds for probe_elems ring products (0 = not measured: the plan
- * was given explicitly, the ring has no chunked product, or the probe's temporaries could not be allocated). */
+ * (lanes stays 0 while sr_plan.lanes = 0 and sr_ctx_reserve_scratch has not run: such a context runs two lanes).  probe_ms
+ * (optional): what the probe measured, [0] two lanes (steady state: twelve chunks with both lanes busy, scaled), [1] one stream,
+ * milliseconds for probe_elems ring products (0 = not measured: the plan was given explicitly, the ring has no chunked product,
+ * the batch reserved for is below eight chunks, or the probe's temporaries could not be allocated). */
 int sr_ctx_plan_in_use(sr_ctx *ctx, sr_plan *plan, double probe_ms[2], size_t *probe_elems);
 int sr_ctx_destroy(sr_ctx *ctx);
 /* D, u64 limbs per coefficient, u64 words per ring element */
@@ -136,6 +142,20 @@ int sr_pointwise_mul_batch(sr_ctx *ctx, uint64_t *lhs_inout, const uint64_t *rhs
 /* RqNTT += / -= &RqNTT (ntt_form.rs:227-285, 588-638) and the same for RqPoly: coefficient-wise in either form. */
 int sr_add_batch(sr_ctx *ctx, uint64_t *lhs_inout, const uint64_t *rhs, size_t batch);
 int sr_sub_batch(sr_ctx *ctx, uint64_t *lhs_inout, const uint64_t *rhs, size_t batch);
+/* The unary operators of the same element types (round 4), every ring id, word-wise in either form:
+ *   sr_neg_batch          Neg: RqPoly `self.0.map(|x| -x)` (coeff_form.rs:270-278), RqNTT (ntt_form.rs:191-203).
+ *   sr_scale_batch        every coefficient / every slot component times ONE base-field scalar: RqPoly Mul<Fp> (= poly_mul by
+ *                         from_scalar, coeff_form.rs:390-408) and Mul / MulAssign<u128|u64|u32|u16|u8|bool> (`*lhs *= Fp::from(rhs)`,
+ *                         coeff_form.rs:610-650); RqNTT Mul / MulAssign<primitive> (`*lhs *= BaseCRTField::from(rhs)`,
+ *                         ntt_form.rs:373-425: a base-field element embedded in Fq3 / Fq9 / Fq4 scales every component).
+ *   sr_add_scalar_batch   Add / AddAssign<primitive> (Sub: pass the negated scalar).  ntt_form = 0, RqPoly: coefficient 0 of every
+ *                         element += scalar (coeff_form.rs:652-700); ntt_form != 0, RqNTT: component 0 of EVERY slot += scalar
+ *                         (`*lhs += BaseCRTField::from(rhs)`, ntt_form.rs:427-505).
+ * scalar: HOST pointer (also in the _dev forms) to the N-limb Montgomery memory image of the base-field element (what Fp::from(rhs)
+ * holds); a word >= p is SR_E_INVALID. */
+int sr_neg_batch(sr_ctx *ctx, uint64_t *data, size_t batch);
+int sr_scale_batch(sr_ctx *ctx, uint64_t *data, const uint64_t *scalar, size_t batch);
+int sr_add_scalar_batch(sr_ctx *ctx, uint64_t *data, const uint64_t *scalar, int ntt_form, size_t batch);
 /* RqPoly * RqPoly == icrt(crt(a) * crt(b)) (coeff_form.rs:250-258; identity tested at
  * stark_prime/mod.rs:161-177).  out may alias a.                                          */
 int sr_ring_mul_batch(sr_ctx *ctx, uint64_t *out, const uint64_t *a, const uint64_t *b, size_t batch);
@@ -150,6 +170,9 @@ int sr_ntt_inv_batch_dev(sr_ctx *ctx, uint64_t *d_data, size_t batch, void *stre
 int sr_pointwise_mul_batch_dev(sr_ctx *ctx, uint64_t *d_lhs_inout, const uint64_t *d_rhs, size_t batch, void *stream);
 int sr_add_batch_dev(sr_ctx *ctx, uint64_t *d_lhs_inout, const uint64_t *d_rhs, size_t batch, void *stream);
 int sr_sub_batch_dev(sr_ctx *ctx, uint64_t *d_lhs_inout, const uint64_t *d_rhs, size_t batch, void *stream);
+int sr_neg_batch_dev(sr_ctx *ctx, uint64_t *d_data, size_t batch, void *stream);
+int sr_scale_batch_dev(sr_ctx *ctx, uint64_t *d_data, const uint64_t *host_scalar, size_t batch, void *stream);
+int sr_add_scalar_batch_dev(sr_ctx *ctx, uint64_t *d_data, const uint64_t *host_scalar, int ntt_form, size_t batch, void *stream);
 /* First "next" row: y = M * v for a dense nrows x ncols matrix of ring elements in CRT/NTT form
  * (row-major, each entry one ring element) and a vector of ncols elements -- Matrix<RqNTT>::checked_mul_vec,
  * crates/linear_algebra/src/matrix.rs:168-178 -- as one fused multiply-accumulate pass over M.  Every ring id: the fully
@@ -287,6 +310,13 @@ int sr_ctx_profile_read(sr_ctx *ctx, double ms_total[SR_PROF_NTAGS], uint64_t la
  * compile-time shift product a[0] * 2^b[0] mod p, 1 <= b[0] <= 95.
  * Not a compute path. */
 int sr_selftest_field_op(int field, int op, const uint64_t *a, const uint64_t *b, uint64_t *out);
+
+/* Test hook of the CHECKING build (libstarkrings_hip_check.so = the same sources compiled with -DSR_GL_CHECK_REPS): while the real
+ * kernels of the tuned Goldilocks path run, every canonical butterfly counts a non-canonical input, every lazy butterfly a second
+ * wrap or borrow, every result store a word >= p (csrc/fields.hpp: repcheck).  counters[0..4] as documented there; reset != 0
+ * clears them.  Synchronises the device.  The product library returns SR_E_UNSUPPORTED: it carries no checks.
+ * Not a compute path. */
+int sr_selftest_rep_counters(uint64_t counters[8], int reset);
 
 const char *sr_last_error_string(void);
 const char *sr_version(void);

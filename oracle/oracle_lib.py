@@ -30,10 +30,30 @@ def build(force=False):
     return so
 
 
-def lib():
+PORTABLE_FLAGS = "-O3 -march=x86-64-v2"
+_flags = PORTABLE_FLAGS
+
+
+def use_native_build():
+    """bench.py's TIMED cpu_baseline only (`-O3 -march=native`): compile the restatement on THIS machine for THIS
+    machine's cores and load that build from now on; returns the flags in force (the portable ones when no compiler is here)."""
+    global _lib, _flags
+    so = os.path.join(HERE, "libsr_oracle_native.so")
+    try:
+        subprocess.check_call(["make", "-C", HERE, "-s", "-B", "native"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        _lib = None
+        lib(so)
+        _flags = "-O3 -march=native"
+    except Exception:  # no gcc / make on this machine: the portable build stays
+        _lib = None
+        lib()
+    return _flags
+
+
+def lib(path=None):
     global _lib
     if _lib is None:
-        L = ctypes.CDLL(build())
+        L = ctypes.CDLL(path or build())
         sz, i, u64 = ctypes.c_size_t, ctypes.c_int, ctypes.c_uint64
         sigs = {
             "sro_limbs": (i, [i]),

@@ -31,6 +31,12 @@ SYMBOLS = {
     "sr_add_batch": (_c.c_int, [_c.c_void_p, u64p, u64p, _c.c_size_t]),
     "sr_sub_batch": (_c.c_int, [_c.c_void_p, u64p, u64p, _c.c_size_t]),
     "sr_ring_mul_batch": (_c.c_int, [_c.c_void_p, u64p, u64p, u64p, _c.c_size_t]),
+    "sr_neg_batch": (_c.c_int, [_c.c_void_p, u64p, _c.c_size_t]),
+    "sr_scale_batch": (_c.c_int, [_c.c_void_p, u64p, u64p, _c.c_size_t]),
+    "sr_add_scalar_batch": (_c.c_int, [_c.c_void_p, u64p, u64p, _c.c_int, _c.c_size_t]),
+    "sr_neg_batch_dev": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_size_t, _c.c_void_p]),
+    "sr_scale_batch_dev": (_c.c_int, [_c.c_void_p, _c.c_void_p, u64p, _c.c_size_t, _c.c_void_p]),
+    "sr_add_scalar_batch_dev": (_c.c_int, [_c.c_void_p, _c.c_void_p, u64p, _c.c_int, _c.c_size_t, _c.c_void_p]),
     "sr_reduce_batch": (_c.c_int, [_c.c_void_p, u64p, _c.c_size_t, u64p, _c.c_size_t]),
     "sr_ntt_fwd_batch_dev": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_size_t, _c.c_void_p]),
     "sr_ntt_inv_batch_dev": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_size_t, _c.c_void_p]),
@@ -78,6 +84,7 @@ SYMBOLS = {
     "sr_ctx_profile_enable": (_c.c_int, [_c.c_void_p, _c.c_int]),
     "sr_ctx_profile_read": (_c.c_int, [_c.c_void_p, _c.POINTER(_c.c_double), _c.POINTER(_c.c_uint64)]),
     "sr_selftest_field_op": (_c.c_int, [_c.c_int, _c.c_int, u64p, u64p, u64p]),
+    "sr_selftest_rep_counters": (_c.c_int, [u64p, _c.c_int]),
     "sr_last_error_string": (_c.c_char_p, []),
     "sr_version": (_c.c_char_p, []),
 }
@@ -93,6 +100,7 @@ class Plan(ctypes.Structure):
 PLAN_GENERIC_KERNELS, PLAN_GL_NO_COLS256, PLAN_RT_NO_COLS256 = 1, 2, 4
 PLAN_GL_REGTILE, PLAN_STARK_NO_LAZY, PLAN_STARK_GENERIC_ON_LAZY = 8, 16, 32
 PLAN_NO_HOST_PIN = 64
+PLAN_GL_PLAIN_COLS = 128
 
 
 def plan_from_env(ring=None):
@@ -114,6 +122,8 @@ def plan_from_env(ring=None):
         f |= PLAN_STARK_GENERIC_ON_LAZY
     if e.get("SR_HOST_PIN") == "0":
         f |= PLAN_NO_HOST_PIN
+    if e.get("SR_GL_KEEP_COLS") == "0":
+        f |= PLAN_GL_PLAIN_COLS
     p = Plan()
     p.flags = f
     p.log_tile = int(e.get("SR_LOG_TILE", "0") or 0)

@@ -290,6 +290,7 @@ int init_pow2(sr_ctx *c) {
                              (const uint64_t *)pows.data(), (const uint64_t *)ipows.data(), (uint64_t)dinv,
                              (uint64_t)fused, !(c->plan.flags & SR_PLAN_GL_NO_COLS256), c->plan.chunk_polys, c->stream))
             return fail(SR_E_HIP, "goldilocks fast-path table build failed");
+        c->gl_fast.keep_cols = !(c->plan.flags & SR_PLAN_GL_PLAIN_COLS);
     }
     return SR_OK;
 }
@@ -423,17 +424,8 @@ int matmul_dev(sr_ctx *c, uint64_t *y, const uint64_t *a, const uint64_t *b, siz
     if (n == 0 || p == 0) return SR_OK;
     // register block of outputs per lane: RB + CB operand loads feed RB * CB multiply-adds.  BabyBear's accumulators are one
     // register each (8 x 4); Goldilocks' 96-bit sums and Stark's nine limbs cost 12 and 10 (4 x 2).
-#ifndef SR_MM_BB_RB
-#define SR_MM_BB_RB 8
-#define SR_MM_BB_CB 4
-#endif
     constexpr bool bb = std::is_same<F, sr::BabyBear>::value;
-#ifndef SR_MM_GL_RB
-#define SR_MM_GL_RB 4
-#define SR_MM_GL_CB 2
-#endif
-    constexpr bool gl = std::is_same<F, sr::Goldilocks>::value;
-    constexpr int RB = bb ? SR_MM_BB_RB : (gl ? SR_MM_GL_RB : 4), CB = bb ? SR_MM_BB_CB : (gl ? SR_MM_GL_CB : 2);
+    constexpr int RB = bb ? 8 : 4, CB = bb ? 4 : 2;
     const size_t blocks = ((c->degree + 255) / 256) * ((n + RB - 1) / RB) * ((p + CB - 1) / CB);
     if (blocks > 0x7FFFFFFFull) return fail(SR_E_INVALID, "matmul: too many rows or columns for one launch");
     ProfScope ps(c, st, K_OTHER);
@@ -1035,7 +1027,6 @@ int check_count(const sr_ctx *c, size_t n_elems, size_t per_elem = 1) {
 // ---- per-ring device dispatch (pow2 rings and the reference-native small rings) --------------
 int lanes_autoselect(sr_ctx *c, size_t batch);  // sr_plan.lanes = 0: measure once which plan this process's queues favour (below)
 int dev_fwd(sr_ctx *c, uint64_t *d, size_t batch, hipStream_t st) {
-    if (st != c->stream && st != c->out_stream) (void)lanes_autoselect(c, batch);
     if (c->ring == SR_RING_FROG_16) return sr::frog_launch(c->frog, sr::FROG_CRT, d, nullptr, 0, d, batch, st) ? fail(SR_E_HIP, "frog-ring launch failed") : SR_OK;
     if (c->ring == SR_RING_GOLDILOCKS_24) return sr::small_launch(c->small, sr::SMALL_G24_CRT, d, nullptr, 0, d, batch, st) ? fail(SR_E_HIP, "small-ring launch failed") : SR_OK;
     if (c->ring == SR_RING_BABYBEAR_72) return sr::small_launch(c->small, sr::SMALL_B72_CRT, d, nullptr, 0, d, batch, st) ? fail(SR_E_HIP, "small-ring launch failed") : SR_OK;
@@ -1056,7 +1047,6 @@ int dev_fwd(sr_ctx *c, uint64_t *d, size_t batch, hipStream_t st) {
     DISPATCH_POW2(c, (fwd_dev<F>(c, d, batch, st)));
 }
 int dev_inv(sr_ctx *c, uint64_t *d, size_t batch, hipStream_t st) {
-    if (st != c->stream && st != c->out_stream) (void)lanes_autoselect(c, batch);
     if (c->ring == SR_RING_FROG_16) return sr::frog_launch(c->frog, sr::FROG_ICRT, d, nullptr, 0, d, batch, st) ? fail(SR_E_HIP, "frog-ring launch failed") : SR_OK;
     if (c->ring == SR_RING_GOLDILOCKS_24) return sr::small_launch(c->small, sr::SMALL_G24_ICRT, d, nullptr, 0, d, batch, st) ? fail(SR_E_HIP, "small-ring launch failed") : SR_OK;
     if (c->ring == SR_RING_BABYBEAR_72) return sr::small_launch(c->small, sr::SMALL_B72_ICRT, d, nullptr, 0, d, batch, st) ? fail(SR_E_HIP, "small-ring launch failed") : SR_OK;
@@ -1093,6 +1083,73 @@ int dev_addsub(sr_ctx *c, uint64_t *l, const uint64_t *r, size_t batch, bool sub
         default: return addsub_dev<sr::Stark>(c, l, r, n, sub, st);
     }
 }
+// ---- unary word-wise operators of RqPoly / RqNTT: Neg, Mul<scalar>, Add<scalar> (every ring id, either form) -------------------
+#define DISPATCH_BASE_FIELD(c, CALL)                                                       \
+    switch ((c)->ring) {                                                                   \
+        case SR_RING_GOLDILOCKS_POW2:                                                      \
+        case SR_RING_GOLDILOCKS_24: { using F = sr::Goldilocks; return CALL; }             \
+        case SR_RING_BABYBEAR_POW2:                                                        \
+        case SR_RING_BABYBEAR_72: { using F = sr::BabyBear; return CALL; }                 \
+        case SR_RING_FROG_16: { using F = sr::Frog; return CALL; }                         \
+        default: { using F = sr::Stark; return CALL; }                                     \
+    }
+extern "C++" {
+template <class F>
+int neg_dev(sr_ctx *c, uint64_t *d, size_t n_words, hipStream_t st) {
+    if (n_words == 0) return SR_OK;
+    ProfScope ps(c, st, K_POINTWISE);
+    hipLaunchKernelGGL(sr::neg_kernel<F>, dim3(sr::stream_blocks<F>(n_words)), dim3(256), 0, st, reinterpret_cast<typename F::storage *>(d), n_words);
+    HIP_TRY(hipGetLastError());
+    return SR_OK;
+}
+template <class F>
+int load_scalar(const uint64_t *scalar, typename F::storage *out) {
+    typename F::storage s;
+    memcpy(&s, scalar, sizeof(s));
+    if (!F::valid(F::load(&s))) return fail(SR_E_INVALID, "scalar is not a canonical Montgomery image (>= p)");
+    *out = s;
+    return SR_OK;
+}
+template <class F>
+int scale_dev(sr_ctx *c, uint64_t *d, const uint64_t *scalar, size_t n_words, hipStream_t st) {
+    typename F::storage s;
+    if (int rc = load_scalar<F>(scalar, &s)) return rc;
+    if (n_words == 0) return SR_OK;
+    ProfScope ps(c, st, K_POINTWISE);
+    hipLaunchKernelGGL(sr::scale_kernel<F>, dim3(sr::stream_blocks<F>(n_words)), dim3(256), 0, st, reinterpret_cast<typename F::storage *>(d), n_words, s);
+    HIP_TRY(hipGetLastError());
+    return SR_OK;
+}
+template <class F>
+int add_scalar_dev(sr_ctx *c, uint64_t *d, const uint64_t *scalar, size_t count, size_t stride, hipStream_t st) {
+    typename F::storage s;
+    if (int rc = load_scalar<F>(scalar, &s)) return rc;
+    if (count == 0) return SR_OK;
+    size_t blocks = (count + 255) / 256;
+    if (blocks > 0xFFFFFFull) blocks = 0xFFFFFFull;
+    ProfScope ps(c, st, K_POINTWISE);
+    hipLaunchKernelGGL(sr::add_scalar_kernel<F>, dim3((unsigned)blocks), dim3(256), 0, st, reinterpret_cast<typename F::storage *>(d), count, stride, s);
+    HIP_TRY(hipGetLastError());
+    return SR_OK;
+}
+}  // extern "C++"
+// base-field words per NTT slot: the extension degree of BaseCRTField (1 for the power-of-two rings)
+size_t slot_words(const sr_ctx *c) {
+    switch (c->ring) {
+        case SR_RING_GOLDILOCKS_24: return 3;
+        case SR_RING_BABYBEAR_72: return 9;
+        case SR_RING_FROG_16: return 4;
+        default: return 1;
+    }
+}
+int dev_neg(sr_ctx *c, uint64_t *d, size_t batch, hipStream_t st) { DISPATCH_BASE_FIELD(c, (neg_dev<F>(c, d, batch * c->degree, st))); }
+int dev_scale(sr_ctx *c, uint64_t *d, const uint64_t *scalar, size_t batch, hipStream_t st) {
+    DISPATCH_BASE_FIELD(c, (scale_dev<F>(c, d, scalar, batch * c->degree, st)));
+}
+int dev_add_scalar(sr_ctx *c, uint64_t *d, const uint64_t *scalar, bool ntt_form, size_t batch, hipStream_t st) {
+    const size_t stride = ntt_form ? slot_words(c) : c->degree, count = batch * c->degree / stride;
+    DISPATCH_BASE_FIELD(c, (add_scalar_dev<F>(c, d, scalar, count, stride, st)));
+}
 // the three reference-native rings: one slot (Fq3 / Fq9 / Fq4) per lane, small_linalg.hpp
 #define DISPATCH_SLOT(c, CALL)                                                                                   \
     switch ((c)->ring) {                                                                                         \
@@ -1124,10 +1181,14 @@ int dev_matvec(sr_ctx *c, uint64_t *y, const uint64_t *m, const uint64_t *v, siz
         const int groups = c->ring == SR_RING_FROG_16 ? 64 : 32;
         const unsigned nsplit = sr::slot_matvec_splits(nrows, ncols, groups);
         uint64_t *part = nullptr;
+        // `part` is one buffer per context while _dev calls may come in on any stream: its users are ordered like those of the
+        // operand scratch (an event recorded at release, awaited by the next user on another stream)
+        ScratchUse su(c, st);
         if (nsplit > 1) {
             DevBufLite pb(c, 7);
             if (int rc = pb.alloc(nrows * nsplit * c->degree * 8)) return rc;
             part = (uint64_t *)pb.p;
+            if (int rc = su.acquire()) return rc;
         }
         DISPATCH_SLOT(c, (sr::slot_matvec<SL>(K, y, m, v, nrows, ncols, part, nsplit, st)));
     }
@@ -1138,11 +1199,16 @@ int dev_matvec(sr_ctx *c, uint64_t *y, const uint64_t *m, const uint64_t *v, siz
 // The two-lane plans (tuned Goldilocks cols256 product, register-tiled product) only pay when the HIP runtime gives each of the
 // context's two streams its own hardware queue; which queue a stream gets is decided when the stream is created (GPU_MAX_HW_QUEUES,
 // the streams the process already holds), so a host that runs RCCL or a framework beside this library can end up with both lanes
-// on one queue -- and then the one-stream plan is the faster one (20.4 against 17.9 ms per config-2 batch, DESIGN.md 6.0).  The library
-// therefore times both plans itself, once per context, on the context's real streams: up to 16 lane chunks of device-generated
-// uniform operands in temporary buffers, each plan warmed once and timed twice (best of two), on the legacy default stream as the
-// caller's stream (no stream is created for the probe).  Runs inside sr_ctx_reserve_scratch or, failing that, inside the first
-// product large enough to be chunked (which blocks anyway while the scratch is allocated).  sr_ctx_plan_in_use reports the outcome.
+// on one queue -- and then the one-stream plan is the faster one (20.4 against 17.9 ms per config-2 batch, DESIGN.md 6).  The library
+// therefore times both plans itself, once per context, on the context's real lanes, with a private non-blocking stream standing in
+// for the caller's, on device-generated uniform operands in temporary buffers.
+//   What is timed is the STEADY STATE of each plan (round 4; the round-3 probe timed 16 chunks once, whose first and last ran
+//   alone, and needed a 7 % fudge): after four warm-up calls, four calls back to back of n = up to 32 chunks.  Two lanes:
+//   t(n) - t(n / 4), the cost of 3/4 n with both lanes busy and no ramp, scaled to n; one stream: t(n), sets of launches back to
+//   back, which is how that plan runs a batch.  The faster plan wins, no margin.
+//   Where it runs: ONLY inside sr_ctx_reserve_scratch (a blocking call by contract: it allocates).  A context whose host never
+//   reserves runs two lanes, unmeasured -- an asynchronous _dev call never probes (it may be under stream capture, and its latency
+//   belongs to the caller).  sr_ctx_plan_in_use reports the outcome.
 int dev_ring_mul(sr_ctx *c, uint64_t *out, const uint64_t *a, const uint64_t *b, size_t batch, hipStream_t st);
 size_t lanes_chunk_of(const sr_ctx *c) {
     if (c->regtile) return c->ring == SR_RING_BABYBEAR_POW2 ? rt_lane_chunk<sr::BabyBear>(c) : rt_lane_chunk<sr::Goldilocks>(c);
@@ -1157,34 +1223,24 @@ bool lanes_candidate(const sr_ctx *c, size_t batch) {
 int lanes_autoselect(sr_ctx *c, size_t batch) {
     if (c->plan.lanes || c->lanes_choice || c->probing || !lanes_candidate(c, batch)) return SR_OK;
     const size_t chunk = lanes_chunk_of(c);
-    size_t n = batch < 16 * chunk ? batch : 16 * chunk;
+    if (batch < 8 * chunk) return SR_OK;  // too small for a steady state: two lanes, unmeasured (effective_lanes)
+    // up to 32 chunks per call (2 GiB per buffer), a quarter of them for the "head" call
+    size_t nch = batch / chunk;
+    if (nch > 32) nch = 32;
+    nch &= ~(size_t)3;
+    const size_t n = nch * chunk, n_head = n / 4;
     const size_t elem = c->degree * c->limbs * 8, bytes = n * elem;
     void *buf[3] = {nullptr, nullptr, nullptr};
     hipEvent_t ev[2] = {nullptr, nullptr};
-    auto cleanup = [&]() {
-        (void)hipDeviceSynchronize();
-        for (auto &p : buf)
-            if (p) (void)hipFree(p);
-        for (auto &e : ev)
-            if (e) (void)hipEventDestroy(e);
-        // the probe sized the operand scratch for ITS one-stream run: drop it, the plan that won allocates what it needs
-        for (int i = 0; i < 2; i++) {
-            if (c->rt_scratch[i]) (void)hipFree(c->rt_scratch[i]);
-            c->rt_scratch[i] = nullptr;
-            c->rt_scratch_bytes[i] = 0;
-        }
-        c->rt_scratch_used = false;
-        c->probe_chunk = 0;
-        c->probing = false;
-    };
+    hipStream_t st = nullptr;
     c->probing = true;
     const bool prof_was = c->prof.on;
     c->prof.on = false;
-    bool ok = true;
+    bool ok = hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess;
     for (auto &p : buf) ok = ok && hipMalloc(&p, bytes) == hipSuccess;
     for (auto &e : ev) ok = ok && hipEventCreate(&e) == hipSuccess;
-    hipStream_t st = nullptr;  // the legacy default stream stands in for the caller's
-    double best[2] = {0, 0};   // [0] two lanes, [1] one stream
+    double t2_full = 0, t2_head = 0, t1_set = 0;  // milliseconds per call, averaged over kCalls back-to-back calls
+    constexpr int kWarm = 4, kCalls = 4;
     if (ok) {
         const size_t words = n * c->degree;
         auto fill = [&](void *p, uint64_t seed) {
@@ -1194,34 +1250,58 @@ int lanes_autoselect(sr_ctx *c, size_t batch) {
             }
         };
         ok = fill(buf[1], 0x9E3779B97F4A7C15ull) == SR_OK && fill(buf[2], 0xD1B54A32D192ED03ull) == SR_OK;
+        // `calls` products of `elems` elements back to back; the clock the chip holds under this load settles within the warm-up
+        // (the step runs at the socket's power cap: a cold 2 ms sample reads 3-4 % fast)
+        auto timed = [&](size_t elems, int calls, double &per_call) {
+            float ms = 0;
+            ok = ok && hipEventRecord(ev[0], st) == hipSuccess;
+            for (int i = 0; i < calls; i++)
+                ok = ok && dev_ring_mul(c, (uint64_t *)buf[0], (const uint64_t *)buf[1], (const uint64_t *)buf[2], elems, st) == SR_OK;
+            ok = ok && hipEventRecord(ev[1], st) == hipSuccess && hipEventSynchronize(ev[1]) == hipSuccess &&
+                 hipEventElapsedTime(&ms, ev[0], ev[1]) == hipSuccess;
+            if (ok) per_call = ms / calls;
+        };
         for (int plan = 0; plan < 2 && ok; plan++) {
             c->lanes_choice = plan == 0 ? 2 : 1;
-            c->probe_chunk = plan == 0 ? 0 : n;  // one stream: one set of launches, as the real plan runs its 1/8-batch chunks
-            for (int rep = 0; rep < 3 && ok; rep++) {
-                if (rep) ok = hipEventRecord(ev[0], st) == hipSuccess;
-                ok = ok && dev_ring_mul(c, (uint64_t *)buf[0], (const uint64_t *)buf[1], (const uint64_t *)buf[2], n, st) == SR_OK;
-                if (rep) {
-                    float ms = 0;
-                    ok = ok && hipEventRecord(ev[1], st) == hipSuccess && hipEventSynchronize(ev[1]) == hipSuccess &&
-                         hipEventElapsedTime(&ms, ev[0], ev[1]) == hipSuccess;
-                    if (ok && (best[plan] == 0 || ms < best[plan])) best[plan] = ms;
-                } else {
-                    ok = ok && hipStreamSynchronize(st) == hipSuccess;
-                }
+            c->probe_chunk = 0;
+            if (plan == 1) {  // one stream: sets of launches of the size the REAL batch will run in (an eighth of it by default)
+                const size_t real = c->regtile ? rt_chunk_polys(c, batch) : gl_chunk_polys(c, batch);
+                c->probe_chunk = real < n ? real : n;
+            }
+            double warm = 0;
+            timed(n, kWarm, warm);               // allocates the plan's scratch, warms the caches and settles the clock
+            if (plan == 0) {
+                timed(n, kCalls, t2_full);
+                timed(n_head, kCalls, t2_head);
+            } else {
+                timed(n, kCalls, t1_set);        // sets of launches back to back on one stream: exactly how the plan runs a batch
             }
         }
+        ok = ok && hipStreamSynchronize(st) == hipSuccess;
     }
-    cleanup();
+    // every launch of the probe was joined onto st and st has been waited for: the temporaries are idle (hipFree synchronises by itself)
+    if (!ok && st) (void)hipStreamSynchronize(st);
+    for (auto &p : buf)
+        if (p) (void)hipFree(p);
+    for (auto &e : ev)
+        if (e) (void)hipEventDestroy(e);
+    if (st) (void)hipStreamDestroy(st);
+    // the probe sized the operand scratch for ITS one-stream run: drop it, the plan that won allocates what it needs
+    for (int i = 0; i < 2; i++) {
+        if (c->rt_scratch[i]) (void)hipFree(c->rt_scratch[i]);
+        c->rt_scratch[i] = nullptr;
+        c->rt_scratch_bytes[i] = 0;
+    }
+    c->rt_scratch_used = false;
+    c->probe_chunk = 0;
+    c->probing = false;
     c->prof.on = prof_was;
-    if (ok && best[0] > 0 && best[1] > 0) {
-        c->lanes_probe_ms[0] = best[0];
-        c->lanes_probe_ms[1] = best[1];
+    if (ok && t2_full > t2_head && t2_head > 0 && t1_set > 0) {
+        // two lanes: the cost of the 3/4 n elements that a full call runs beyond a head call -- both lanes busy, no ramp -- scaled to n
+        c->lanes_probe_ms[0] = (t2_full - t2_head) * (4.0 / 3.0);
+        c->lanes_probe_ms[1] = t1_set;
         c->lanes_probe_elems = n;
-        // The probe's 16 chunks understate the two-lane plan (its first and last chunks run alone: a config-2 batch gains 8 % where
-        // the probe shows 3 %, and config 4's shard gains 9 % where the probe showed one stream AHEAD by 3.5 %), while lanes that
-        // share a hardware queue lose 12 % and more against one stream (20.4 against 17.9 ms): one stream is only
-        // picked on a clear win.
-        c->lanes_choice = best[1] < 0.93 * best[0] ? 1 : 2;
+        c->lanes_choice = c->lanes_probe_ms[1] < c->lanes_probe_ms[0] ? 1 : 2;
     } else {
         // no memory for the probe's temporaries (or a launch failed: the real call will report that): keep the default, unmeasured
         (void)hipGetLastError();
@@ -1232,7 +1312,6 @@ int lanes_autoselect(sr_ctx *c, size_t batch) {
 }
 
 int dev_ring_mul(sr_ctx *c, uint64_t *out, const uint64_t *a, const uint64_t *b, size_t batch, hipStream_t st) {
-    if (st != c->stream && st != c->out_stream) (void)lanes_autoselect(c, batch);  // (the host pipeline never uses the lanes)
     if (c->ring == SR_RING_FROG_16) return sr::frog_launch(c->frog, sr::FROG_RINGMUL, a, b, 0, out, batch, st) ? fail(SR_E_HIP, "frog-ring launch failed") : SR_OK;
     if (c->ring == SR_RING_GOLDILOCKS_24) return sr::small_launch(c->small, sr::SMALL_G24_RINGMUL, a, b, 0, out, batch, st) ? fail(SR_E_HIP, "small-ring launch failed") : SR_OK;
     if (c->ring == SR_RING_BABYBEAR_72) return sr::small_launch(c->small, sr::SMALL_B72_RINGMUL, a, b, 0, out, batch, st) ? fail(SR_E_HIP, "small-ring launch failed") : SR_OK;
@@ -1280,7 +1359,6 @@ int dev_ring_mul(sr_ctx *c, uint64_t *out, const uint64_t *a, const uint64_t *b,
 // Goldilocks tuned path fuses them: gl_fast_ring_mul_rhs)
 int dev_ring_mul_ntt_rhs(sr_ctx *c, uint64_t *out, const uint64_t *a, const uint64_t *b_ntt, size_t batch, hipStream_t st) {
     if (batch == 0) return SR_OK;
-    if (st != c->stream && st != c->out_stream) (void)lanes_autoselect(c, batch);
     if (c->ring == SR_RING_GOLDILOCKS_POW2 && !c->regtile && c->fast_goldilocks && sr::gl_fast_supported(c->gl_fast) && c->k >= 8) {
         if (gl_use_lanes(c, batch) && st != c->stream && st != c->out_stream) {  // as dev_ring_mul: chunks on the two lanes
             const size_t chunk = gl_lane_chunk(c), words = chunk << c->k;
@@ -1536,6 +1614,27 @@ int sr_sub_batch_dev(sr_ctx *c, uint64_t *l, const uint64_t *r, size_t batch, vo
     std::lock_guard<std::mutex> lk(c->mu);
     DeviceGuard g(c->device);
     return dev_addsub(c, l, r, batch, true, (hipStream_t)stream);
+}
+int sr_neg_batch_dev(sr_ctx *c, uint64_t *d, size_t batch, void *stream) {
+    if (int rc = check(c, d)) return rc;
+    if (int rc = check_count(c, batch)) return rc;
+    std::lock_guard<std::mutex> lk(c->mu);
+    DeviceGuard g(c->device);
+    return dev_neg(c, d, batch, (hipStream_t)stream);
+}
+int sr_scale_batch_dev(sr_ctx *c, uint64_t *d, const uint64_t *scalar, size_t batch, void *stream) {
+    if (int rc = check(c, d, scalar)) return rc;
+    if (int rc = check_count(c, batch)) return rc;
+    std::lock_guard<std::mutex> lk(c->mu);
+    DeviceGuard g(c->device);
+    return dev_scale(c, d, scalar, batch, (hipStream_t)stream);
+}
+int sr_add_scalar_batch_dev(sr_ctx *c, uint64_t *d, const uint64_t *scalar, int ntt_form, size_t batch, void *stream) {
+    if (int rc = check(c, d, scalar)) return rc;
+    if (int rc = check_count(c, batch)) return rc;
+    std::lock_guard<std::mutex> lk(c->mu);
+    DeviceGuard g(c->device);
+    return dev_add_scalar(c, d, scalar, ntt_form != 0, batch, (hipStream_t)stream);
 }
 int sr_matvec_ntt_dev(sr_ctx *c, uint64_t *y, const uint64_t *m, const uint64_t *v, size_t nrows, size_t ncols, void *stream) {
     if (int rc = check(c, y, m, v)) return rc;
@@ -1915,6 +2014,8 @@ int packed_via_wide(sr_ctx *c, uint32_t *out, const uint32_t *a, const uint32_t 
     if (int rc = wa.alloc(n * 8)) return rc;
     if (b)
         if (int rc = wb.alloc(n * 8)) return rc;
+    ScratchUse su(c, st);  // the staging buffers belong to the context, the call may arrive on any stream: ordered like the operand scratch
+    if (int rc = su.acquire()) return rc;
     if (int rc = launch_unpack32(c, (uint64_t *)wa.p, a, n, st)) return rc;
     if (b)
         if (int rc = launch_unpack32(c, (uint64_t *)wb.p, b, n, st)) return rc;
@@ -1948,7 +2049,6 @@ int sr_ntt_fwd_packed32_batch_dev(sr_ctx *c, uint32_t *d, size_t batch, void *st
     hipStream_t st = (hipStream_t)stream;
     if (batch == 0) return SR_OK;
     if (c->regtile) {
-        if (st != c->stream && st != c->out_stream) (void)lanes_autoselect(c, batch);
         return rt_fwd<sr::BabyBear, sr::rt::PackedStream>(c, d, batch, st);
     }
     return packed_via_wide(c, d, d, nullptr, batch, st, [&](uint64_t *wa, uint64_t *) { return dev_fwd(c, wa, batch, st); });
@@ -1962,7 +2062,6 @@ int sr_ntt_inv_packed32_batch_dev(sr_ctx *c, uint32_t *d, size_t batch, void *st
     hipStream_t st = (hipStream_t)stream;
     if (batch == 0) return SR_OK;
     if (c->regtile) {
-        if (st != c->stream && st != c->out_stream) (void)lanes_autoselect(c, batch);
         return rt_inv<sr::BabyBear, sr::rt::PackedStream>(c, d, batch, st);
     }
     return packed_via_wide(c, d, d, nullptr, batch, st, [&](uint64_t *wa, uint64_t *) { return dev_inv(c, wa, batch, st); });
@@ -1977,7 +2076,6 @@ int sr_ring_mul_packed32_batch_dev(sr_ctx *c, uint32_t *d_out, const uint32_t *d
     hipStream_t st = (hipStream_t)stream;
     if (batch == 0) return SR_OK;
     if (c->regtile) {
-        if (st != c->stream && st != c->out_stream) (void)lanes_autoselect(c, batch);
         return rt_ring_mul<sr::BabyBear, sr::rt::PackedStream>(c, d_out, d_a, d_b, batch, st);
     }
     return packed_via_wide(c, d_out, d_a, d_b, batch, st, [&](uint64_t *wa, uint64_t *wb) { return dev_ring_mul(c, wa, wa, wb, batch, st); });
@@ -2068,32 +2166,11 @@ static int host_pipeline(sr_ctx *c, uint64_t *out, const uint64_t *a, const uint
     const size_t elem_bytes = c->degree * c->limbs * 8;
     const size_t bytes = batch * elem_bytes;
     if (bytes == 0) return SR_OK;
-    // The caller's buffers are ordinary (pageable) host memory -- a Rust Vec.  A copy from pageable memory is staged by the runtime
-    // through its own small pinned buffers; registering the caller's pages for the duration of the call (hipHostRegister) lets the
-    // DMA engines read and write them directly.  Worth its cost (page pinning, a few hundred microseconds per GiB... measured in
-    // tools/bench_host_boundary.py) from 32 MiB per operand; a range that cannot be registered (already registered by the caller,
-    // not page-aligned enough, no memory lock limit left) simply stays pageable.  SR_PLAN_NO_HOST_PIN switches it off.
-    struct Pinned {
-        void *p = nullptr;
-        bool pin(const void *q, size_t n) {
-            if (hipHostRegister(const_cast<void *>(q), n, hipHostRegisterDefault) == hipSuccess) {
-                p = const_cast<void *>(q);
-                return true;
-            }
-            (void)hipGetLastError();
-            return false;
-        }
-        ~Pinned() {
-            if (p) (void)hipHostUnregister(p);
-        }
-    } pin_a, pin_b, pin_out;
-    if (!(c->plan.flags & SR_PLAN_NO_HOST_PIN) && bytes >= ((size_t)32 << 20)) {
-        pin_a.pin(a, bytes);
-        if (b && b != a) pin_b.pin(b, bytes);
-        const char *oa = reinterpret_cast<const char *>(out), *aa = reinterpret_cast<const char *>(a), *ba = reinterpret_cast<const char *>(b);
-        const bool overlaps_a = oa < aa + bytes && aa < oa + bytes, overlaps_b = b && oa < ba + bytes && ba < oa + bytes;
-        if (!overlaps_a && !overlaps_b) pin_out.pin(out, bytes);
-    }
+    // The caller's buffers are ordinary (pageable) host memory -- a Rust Vec -- and stay that way: round 3 registered them with the
+    // HIP runtime for the duration of the call (hipHostRegister), which measured inside the noise (69.8-78.3 against 66.9-73.0 GB/s:
+    // the pipeline is PCIe-bound either way) and had two lifetime hazards (a read-only operand shared by two contexts on two
+    // threads was unregistered by whichever call returned first while the other GPU's DMA still read it; an early error return
+    // unregistered pages under an in-flight copy).  Removed in round 4; SR_PLAN_NO_HOST_PIN is accepted and has no effect.
     const size_t chunk_mb = c->plan.host_chunk_mb ? c->plan.host_chunk_mb : 128;
     size_t chunk = (chunk_mb << 20) / elem_bytes;
     if (chunk == 0) chunk = 1;
@@ -2198,6 +2275,21 @@ static int host_inplace(sr_ctx *c, uint64_t *data, size_t batch, bool fwd) {
     return host_pipeline(c, data, data, nullptr, batch, [&](uint64_t *s0, uint64_t *, size_t n, hipStream_t st) {
         return fwd ? dev_fwd(c, s0, n, st) : dev_inv(c, s0, n, st);
     });
+}
+// the unary operators on host buffers: op 0 neg, 1 scale, 2 add scalar (coefficient form), 3 add scalar (NTT form)
+static int host_unary(sr_ctx *c, uint64_t *data, const uint64_t *scalar, size_t batch, int op) {
+    if (int rc = check(c, data, op ? (const void *)scalar : (const void *)1)) return rc;
+    if (int rc = check_count(c, batch)) return rc;
+    std::lock_guard<std::mutex> lk(c->mu);
+    DeviceGuard g(c->device);
+    return host_pipeline(c, data, data, nullptr, batch, [&](uint64_t *s0, uint64_t *, size_t n, hipStream_t st) {
+        return op == 0 ? dev_neg(c, s0, n, st) : op == 1 ? dev_scale(c, s0, scalar, n, st) : dev_add_scalar(c, s0, scalar, op == 3, n, st);
+    });
+}
+int sr_neg_batch(sr_ctx *c, uint64_t *data, size_t batch) { return host_unary(c, data, nullptr, batch, 0); }
+int sr_scale_batch(sr_ctx *c, uint64_t *data, const uint64_t *scalar, size_t batch) { return host_unary(c, data, scalar, batch, 1); }
+int sr_add_scalar_batch(sr_ctx *c, uint64_t *data, const uint64_t *scalar, int ntt_form, size_t batch) {
+    return host_unary(c, data, scalar, batch, ntt_form ? 3 : 2);
 }
 int sr_ntt_fwd_batch(sr_ctx *c, uint64_t *data, size_t batch) { return host_inplace(c, data, batch, true); }
 int sr_ntt_inv_batch(sr_ctx *c, uint64_t *data, size_t batch) { return host_inplace(c, data, batch, false); }
@@ -2335,6 +2427,26 @@ int sr_selftest_field_op(int field, int op, const uint64_t *a, const uint64_t *b
     }
     memcpy(out, to, words * 8);
     return rc;
+}
+
+// Representative-invariant counters of the checking build (fields.hpp: repcheck).  The product library counts nothing and says so.
+int sr_selftest_rep_counters(uint64_t counters[8], int reset) {
+    if (!counters) return fail(SR_E_INVALID, "null argument");
+#if defined(SR_GL_CHECK_REPS)
+    unsigned long long h[8];
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpyFromSymbol(h, HIP_SYMBOL(sr::repcheck::g_counters), sizeof(h)));
+    for (int i = 0; i < 8; i++) counters[i] = h[i];
+    if (reset) {
+        memset(h, 0, sizeof(h));
+        HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(sr::repcheck::g_counters), h, sizeof(h)));
+    }
+    return SR_OK;
+#else
+    (void)reset;
+    for (int i = 0; i < 8; i++) counters[i] = 0;
+    return fail(SR_E_UNSUPPORTED, "this build does not check representatives (built without -DSR_GL_CHECK_REPS)");
+#endif
 }
 
 // ---- profiling ----

@@ -38,20 +38,56 @@ namespace sr {
 // and DRAM sees its pages opened once per chunk.  xcd_tile() gives runs of 2^cl consecutive tiles (column chunks of one ring
 // element) to ONE XCD, back to back (run 8 g + x goes to XCD x): the 16-column pattern of D = 2^16 then streams at 6.0 instead
 // of 5.4 TB/s (tools/ubench/blocked_pattern.hip).  `grouped` = the launch's tile count rounded down to a multiple of 8 * 2^cl
-// (xcd_grouped_tiles); tiles at or beyond it keep tile = blockIdx.  SR_COLS_XCD_MAP = 0: A/B switch.
-#ifndef SR_COLS_XCD_MAP
-#define SR_COLS_XCD_MAP 1
-#endif
+// (xcd_grouped_tiles); tiles at or beyond it keep tile = blockIdx.
 __device__ __forceinline__ unsigned xcd_tile(unsigned bid, int cl, unsigned grouped) {
-#if SR_COLS_XCD_MAP
     if (bid < grouped) {
         const unsigned xcd = bid & 7u, slot = bid >> 3;
         return ((((slot >> cl) << 3) + xcd) << cl) | (slot & ((1u << cl) - 1u));
     }
-#endif
     return bid;
 }
 inline unsigned xcd_grouped_tiles(size_t tiles, int cl) { return (unsigned)(tiles & ~(((size_t)8 << cl) - 1)); }
+
+// ------------------------------------------------------------------------------------------
+// Representative checks of the tuned Goldilocks path.  The lazy butterflies (Goldilocks::addsub_lazy, ntt_goldilocks.hpp) leave
+// 64-bit representatives that differ from the canonical value only when a sum lands in [p, 2^64): 2^-32 per value on uniform
+// data, which no uniform-data parity test can see.  The product library compiles these hooks to nothing.  A second build with
+// -DSR_GL_CHECK_REPS (libstarkrings_hip_check.so; __graft_entry__.build) makes every kernel count, while the real kernels run:
+//   [0] a canonical routine (add, sub, addsub, a phased canonical butterfly) or the canonical leg t of a lazy butterfly that was
+//       handed a representative >= p;
+//   [1] a lazy sum whose + eps wrapped a second time;   [2] a lazy difference whose + p borrowed a second time;
+//   [3] a word >= p leaving the library;                 [4] a routine documented "canonical out" that returned >= p.
+// sr_selftest_rep_counters reads and clears them; tests/test_rep_invariants.py asserts zeros over crafted, structured, edge and
+// uniform operands of every tuned plan.
+// ------------------------------------------------------------------------------------------
+namespace repcheck {
+constexpr unsigned long long kP = 0xFFFFFFFF00000001ull;
+#if defined(SR_GL_CHECK_REPS)
+__device__ unsigned long long g_counters[8];
+#endif
+#if defined(SR_GL_CHECK_REPS) && defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ void count(int i) { atomicAdd(&g_counters[i], 1ull); }
+__device__ __forceinline__ void canonical_in(unsigned long long a, unsigned long long b) {
+    if (a >= kP || b >= kP) count(0);
+}
+__device__ __forceinline__ void lazy_fix(unsigned long long s, unsigned long long d, unsigned long long c1, unsigned long long c2) {
+    const unsigned lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    if (((c1 >> lane) & 1ull) && s > ~0xFFFFFFFFull) count(1);   // s + eps would wrap again
+    if (((c2 >> lane) & 1ull) && d < 0xFFFFFFFFull) count(2);    // d + p = d - eps would borrow again
+}
+__device__ __forceinline__ void leaves_library(unsigned long long v) {
+    if (v >= kP) count(3);
+}
+__device__ __forceinline__ void canonical_out(unsigned long long v) {
+    if (v >= kP) count(4);
+}
+#else
+SR_HD void canonical_in(unsigned long long, unsigned long long) {}
+SR_HD void lazy_fix(unsigned long long, unsigned long long, unsigned long long, unsigned long long) {}
+SR_HD void leaves_library(unsigned long long) {}
+SR_HD void canonical_out(unsigned long long) {}
+#endif
+}  // namespace repcheck
 
 // ------------------------------------------------------------------------------------------
 // Goldilocks  p = 2^64 - 2^32 + 1
@@ -72,46 +108,28 @@ struct Goldilocks {
     SR_HD static void store(storage *p, elem v) { *p = v; }
     SR_HD static bool valid(elem v) { return v < P; }
 
-    // Carry chains are written with __builtin_addc / __builtin_subc on 32-bit limbs: hipcc turns them into
-    // v_add_co/v_addc_co (v_sub_co/v_subb_co) and pads the VCC hazards itself.  On gfx950 nearly every integer
-    // VALU instruction (carries, compares, v_cndmask, v_mad_u64_u32) issues at the same rate, so the goal is
-    // simply the fewest instructions: add 6, sub 5, reduce128 12 (profiles/r01/valu_issue_rates_gfx950.txt).
-#ifdef SR_OLD_ADD
+    SR_HD static elem neg(elem a) { return a ? P - a : 0; }
+    // any 64-bit representative -> the canonical one (representatives >= p exist only for values below 2^32 - 1)
+    SR_HD static elem canon(elem a) { return a >= P ? a - P : a; }
+
+    // The arithmetic below exists twice with identical signatures and identical values: hand-scheduled gfx950 code for the device
+    // pass, plain C++ for the host pass (context set-up, sr_selftest_field_op, tools/ubench/field_check.hip, which compares the two).
+    // On gfx950 nearly every integer VALU instruction this needs (carries, compares, v_mad_u64_u32, 64-bit adds) issues at the same
+    // rate (profiles/r01/valu_issue_rates_gfx950.txt), so the device forms are written for the fewest instructions AND the fewest
+    // non-VALU issue slots around them:
+    //   * a conditional +-p is ONE v_lshl_add_u64 executed under an EXEC mask made from the carry (s_and / s_andn1_saveexec ...
+    //     s_mov exec: SALU work, issued beside the other waves' VALU) instead of a second carry chain plus two v_cndmask;
+    //   * s_nop: the two wait states gfx950 wants between a VALU write of an SGPR carry and the VALU read of it -- the compiler
+    //     cannot see into an asm statement, so every statement pads its own hazards; a statement that writes SCC (s_or_b64,
+    //     s_and*_saveexec) declares the clobber (tests/test_inline_asm_clobbers.py);
+    //   * multi-step operations are single statements where the compiler would otherwise put a wait state (s_nop 0) between a
+    //     statement that defines a VGPR and the next instruction that reads it.
+    // SR_GL_CHECK_REPS (the invariant-checking build, tests/test_rep_invariants.py) counts violated preconditions in repcheck::.
+#if defined(__HIP_DEVICE_COMPILE__)
+    // a + b for canonical a, b: 4 VALU.  t = a + eps cannot overflow; the carry of t + b says a + b >= p (then t + b - 2^64 = a + b - p
+    // is the answer) and the other lanes take the eps back (+ p mod 2^64).
     SR_HD static elem add(elem a, elem b) {
-        uint64_t s = a + b;
-        bool fix = (s < a) | (s >= P);
-        return fix ? s + EPS : s;
-    }
-#elif defined(__HIP_DEVICE_COMPILE__) && !defined(SR_GL_NO_EXECMASK) && defined(SR_ADD_CMP)
-    // 4 VALU like the form below, with the full-width pre-add of EPS (v_lshl_add_u64: 1.6 nJ per wave-instruction, the most
-    // expensive of the integer adds -- tools/ubench/valu_energy.hip) replaced by a 64-bit compare (0.8 nJ): s = a + b on a carry
-    // chain; the lanes with a carry or with s >= p take + EPS (= - p mod 2^64) under an EXEC mask.
-    static __device__ __forceinline__ elem add(elem a, elem b) {
-        uint64_t c, c2, sv;
-        uint32_t r0, r1;
-        asm("v_add_co_u32_e64 %0, %2, %3, %5\n\t"
-            "s_nop 1\n\t"
-            "v_addc_co_u32_e64 %1, %2, %4, %6, %2"
-            : "=&v"(r0), "=&v"(r1), "=&s"(c)
-            : "v"((uint32_t)a), "v"((uint32_t)(a >> 32)), "v"((uint32_t)b), "v"((uint32_t)(b >> 32)));
-        uint64_t r = (uint64_t)r0 | ((uint64_t)r1 << 32);
-        asm("v_cmp_le_u64_e64 %2, %4, %0\n\t"
-            "s_or_b64 %2, %2, %3\n\t"
-            "s_and_saveexec_b64 %1, %2\n\t"
-            "v_lshl_add_u64 %0, %0, 0, %5\n\t"
-            "s_mov_b64 exec, %1"
-            : "+v"(r), "=&s"(sv), "=&s"(c2)
-            : "s"(c), "s"((uint64_t)P), "s"((uint64_t)EPS)
-            : "scc");
-        return r;
-    }
-#elif defined(__HIP_DEVICE_COMPILE__) && !defined(SR_GL_NO_EXECMASK)
-    // Round-2 form, 4 VALU (3 for sub): the conditional correction is ONE v_lshl_add_u64 executed under an EXEC mask made from
-    // the carry (s_and / s_andn1_saveexec ... s_mov exec: SALU work, which the scalar unit issues beside the other waves' VALU)
-    // instead of a second carry chain plus two v_cndmask.  t = a + EPS cannot overflow for canonical a; the carry of t + b says
-    // a + b >= p (then t + b - 2^64 = a + b - p is the answer), and the other lanes take the EPS back (+ p mod 2^64).
-    // s_nop 1: the two wait states gfx950 wants between a VALU write of an SGPR carry and the VALU read of it.
-    static __device__ __forceinline__ elem add(elem a, elem b) {
+        repcheck::canonical_in(a, b);
         uint64_t t, c, sv;
         uint32_t r0, r1;
         asm("v_lshl_add_u64 %0, %1, 0, %2" : "=v"(t) : "v"(a), "s"((uint64_t)EPS));
@@ -129,49 +147,9 @@ struct Goldilocks {
             : "scc");
         return r;
     }
-#elif defined(__HIP_DEVICE_COMPILE__) && !defined(SR_ADD6)
-    // 5 VALU: s = a + b on a carry chain, then u = s + EPS (= s - p mod 2^64) as ONE v_mad_u64_u32 (1 * 0xFFFFFFFF + s) whose
-    // carry-out says s >= p; either carry selects u.  (The C++ form below spends an add_co / addc_co pair on u: 6 VALU.)
-    // s_nop 1: the two wait states gfx950 wants between a VALU write of an SGPR carry and the VALU read of it.
-    static __device__ __forceinline__ elem add(elem a, elem b) {
-        uint32_t s0, s1, r0, r1;
-        uint64_t c1, c2, u;
-        asm("v_add_co_u32_e64 %0, %2, %3, %5\n\t"
-            "s_nop 1\n\t"
-            "v_addc_co_u32_e64 %1, %2, %4, %6, %2"
-            : "=&v"(s0), "=&v"(s1), "=&s"(c1)
-            : "v"((uint32_t)a), "v"((uint32_t)(a >> 32)), "v"((uint32_t)b), "v"((uint32_t)(b >> 32)));
-        const uint64_t s = (uint64_t)s0 | ((uint64_t)s1 << 32);
-        asm("v_mad_u64_u32 %0, %1, 1, -1, %2" : "=v"(u), "=s"(c2) : "v"(s));
-        asm("s_or_b64 %2, %2, %7\n\t"
-            "v_cndmask_b32_e64 %0, %3, %5, %2\n\t"
-            "v_cndmask_b32_e64 %1, %4, %6, %2"
-            : "=&v"(r0), "=&v"(r1), "+s"(c2)
-            : "v"(s0), "v"(s1), "v"((uint32_t)u), "v"((uint32_t)(u >> 32)), "s"(c1)
-            : "scc");
-        return (uint64_t)r0 | ((uint64_t)r1 << 32);
-    }
-#else
-    SR_HD static elem add(elem a, elem b) {
-        uint32_t c, c1, c2;
-        uint32_t s0 = __builtin_addc((uint32_t)a, (uint32_t)b, 0u, &c);
-        uint32_t s1 = __builtin_addc((uint32_t)(a >> 32), (uint32_t)(b >> 32), c, &c1);
-        SR_OPAQUE(s1);
-        uint32_t u0 = __builtin_addc(s0, 0xFFFFFFFFu, 0u, &c);  // u = s + EPS = s - p (mod 2^64)
-        uint32_t u1 = __builtin_addc(s1, 0u, c, &c2);            // c2 <=> s >= p (when c1 = 0)
-        bool fix = (c1 | c2) != 0;
-        return (uint64_t)(fix ? u0 : s0) | ((uint64_t)(fix ? u1 : s1) << 32);
-    }
-#endif
-    // a - b (+ p on borrow).  Exact for canonical a, b; also used with arbitrary a and b < 2^32 (reduce128).
-#ifdef SR_OLD_SUB
+    // a - b (+ p on borrow): 3 VALU.  Exact for canonical a, b.
     SR_HD static elem sub(elem a, elem b) {
-        uint64_t d = a - b;
-        return (a < b) ? d - EPS : d;
-    }
-#elif defined(__HIP_DEVICE_COMPILE__) && !defined(SR_GL_NO_EXECMASK)
-    // 3 VALU: borrow chain, then + p on the lanes that borrowed (EXEC-masked v_lshl_add_u64, see add)
-    static __device__ __forceinline__ elem sub(elem a, elem b) {
+        repcheck::canonical_in(a, b);
         uint64_t c, sv;
         uint32_t r0, r1;
         asm("v_sub_co_u32_e64 %0, %2, %3, %5\n\t"
@@ -188,26 +166,10 @@ struct Goldilocks {
             : "scc");
         return r;
     }
-#else
-    SR_HD static elem sub(elem a, elem b) {
-        uint32_t c, br;
-        uint32_t d0 = __builtin_subc((uint32_t)a, (uint32_t)b, 0u, &c);
-        uint32_t d1 = __builtin_subc((uint32_t)(a >> 32), (uint32_t)(b >> 32), c, &br);
-        SR_OPAQUE(d1);
-        uint32_t m = 0u - br;                                     // borrow ? 0xFFFFFFFF : 0
-        uint32_t e0 = __builtin_subc(d0, m, 0u, &c);              // + p == - EPS (mod 2^64)
-        uint32_t e1 = __builtin_subc(d1, 0u, c, &c);
-        return (uint64_t)e0 | ((uint64_t)e1 << 32);
-    }
-#endif
-    SR_HD static elem neg(elem a) { return a ? P - a : 0; }
-    // any 64-bit representative -> the canonical one (representatives >= p exist only for values below 2^32 - 1)
-    SR_HD static elem canon(elem a) { return a >= P ? a - P : a; }
-    // s = a + b, d = a - b in one go: every butterfly needs both.  Same seven VALU as add + sub, but as ONE asm statement the two carry
-    // chains fill each other's wait states (one s_nop 0 instead of two s_nop 1) and the EXEC mask is saved and restored once
-    // (three SALU instead of four).  SR_GL_FUSED_BF = 1 makes the butterflies of ntt_goldilocks.hpp use it (A/B switch, round 3).
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(SR_GL_NO_EXECMASK)
-    static __device__ __forceinline__ void addsub(elem a, elem b, elem &s, elem &d) {
+    // s = a + b, d = a - b in one go (every butterfly needs both): the seven VALU of add + sub, but as one statement the two carry
+    // chains fill each other's wait states and the EXEC mask is saved and restored once.
+    SR_HD static void addsub(elem a, elem b, elem &s, elem &d) {
+        repcheck::canonical_in(a, b);
         uint64_t t, c1, c2, sv;
         uint32_t s0, s1, d0, d1;
         asm("v_lshl_add_u64 %0, %1, 0, %2" : "=v"(t) : "v"(a), "s"((uint64_t)EPS));
@@ -220,7 +182,7 @@ struct Goldilocks {
             : "v"((uint32_t)t), "v"((uint32_t)(t >> 32)), "v"((uint32_t)b), "v"((uint32_t)(b >> 32)), "v"((uint32_t)a), "v"((uint32_t)(a >> 32)));
         s = (uint64_t)s0 | ((uint64_t)s1 << 32);
         d = (uint64_t)d0 | ((uint64_t)d1 << 32);
-        asm("s_andn1_saveexec_b64 %2, %3\n\t"      // lanes WITHOUT the carry of t + b take the EPS back
+        asm("s_andn1_saveexec_b64 %2, %3\n\t"      // lanes WITHOUT the carry of t + b take the eps back
             "v_lshl_add_u64 %0, %0, 0, %5\n\t"
             "s_and_b64 exec, %2, %4\n\t"           // lanes that borrowed in a - b take + p
             "v_lshl_add_u64 %1, %1, 0, %5\n\t"
@@ -229,17 +191,17 @@ struct Goldilocks {
             : "s"(c1), "s"(c2), "s"((uint64_t)P)
             : "scc");
     }
-    // The same in three separate steps, for callers that run a whole stage's butterflies phase by phase (SR_GL_FUSED_BF = 2,
-    // ntt_goldilocks.hpp): every step's results are consumed eight statements later, so the compiler has no reason to put its
-    // post-asm wait state anywhere.  SWAP: d = b - a instead of a - b (a twiddle 2^E with E >= 96 is -2^(E-96)).
-    static __device__ __forceinline__ elem plus_eps(elem a) {
+    // The same in three separate steps, for callers that run a whole stage's butterflies phase by phase (ntt_goldilocks.hpp:
+    // dif_phased / dit_phased): every step's results are consumed eight statements later, so no post-asm wait state is needed
+    // anywhere.  plus_eps: the t = a + eps of the canonical sum.  addsub_chains: the carry chains of s = t + b and d = m - n with
+    // (m, n) = (a, b), or (b, a) under SWAP (a twiddle 2^E with E >= 96 is -2^(E-96)).  addsub_fix: the two masked corrections.
+    SR_HD static elem plus_eps(elem a) {
         uint64_t t;
         asm("v_lshl_add_u64 %0, %1, 0, %2" : "=v"(t) : "v"(a), "s"((uint64_t)EPS));
         return t;
     }
     template <bool SWAP>
-    static __device__ __forceinline__ void addsub_chains(elem t, elem a, elem b, uint32_t &s0, uint32_t &s1, uint32_t &d0, uint32_t &d1,
-                                                         uint64_t &c1, uint64_t &c2) {
+    SR_HD static void addsub_chains(elem t, elem a, elem b, uint32_t &s0, uint32_t &s1, uint32_t &d0, uint32_t &d1, uint64_t &c1, uint64_t &c2) {
         const elem m = SWAP ? b : a, n = SWAP ? a : b;   // d = m - n
         asm("v_add_co_u32_e64 %0, %4, %6, %8\n\t"
             "v_sub_co_u32_e64 %2, %5, %10, %12\n\t"
@@ -250,7 +212,7 @@ struct Goldilocks {
             : "v"((uint32_t)t), "v"((uint32_t)(t >> 32)), "v"((uint32_t)b), "v"((uint32_t)(b >> 32)), "v"((uint32_t)m), "v"((uint32_t)(m >> 32)),
               "v"((uint32_t)n), "v"((uint32_t)(n >> 32)));
     }
-    static __device__ __forceinline__ void addsub_fix(elem &s, elem &d, uint64_t c1, uint64_t c2) {
+    SR_HD static void addsub_fix(elem &s, elem &d, uint64_t c1, uint64_t c2) {
         uint64_t sv;
         asm("s_andn1_saveexec_b64 %2, %3\n\t"
             "v_lshl_add_u64 %0, %0, 0, %5\n\t"
@@ -261,12 +223,13 @@ struct Goldilocks {
             : "s"(c1), "s"(c2), "s"((uint64_t)P)
             : "scc");
     }
-    // LAZY legs of a decimation-in-time butterfly (round 3): s = a + t, d = a - t as 64-bit representatives for ANY u64 a and a
-    // canonical t (the shift product v 2^E it comes from is).  a + t wraps at most once -- the + eps on carry lands below 2^64
-    // because a + t - 2^64 <= p - 2 -- and a - t borrows at most once (t - a <= p): six VALU instead of seven, no a + eps.  The
-    // results are arbitrary representatives; every consumer (another lazy butterfly's `a` or `v`, mul) takes those.
-    // tools/model_fast_goldilocks.py: lazy_bf.
-    static __device__ __forceinline__ void addsub_lazy_fix(elem &s, elem &d, uint64_t c1, uint64_t c2) {
+    // LAZY legs of a decimation-in-time butterfly: s = a + t, d = a - t as 64-bit representatives for ANY u64 a and a CANONICAL t
+    // (the shift product v 2^E it comes from is).  a + t wraps at most once -- the + eps on carry lands below 2^64 because
+    // a + t - 2^64 <= p - 2 -- and a - t borrows at most once (t - a <= p): six VALU instead of seven, no a + eps.  The results are
+    // arbitrary representatives; their consumers (another lazy butterfly's a or v, mul, mul_pow2) take those; a canonical butterfly
+    // does NOT (ntt_goldilocks.hpp says where each kind sits; tools/model_fast_goldilocks.py: lazy_bf).
+    SR_HD static void addsub_lazy_fix(elem &s, elem &d, uint64_t c1, uint64_t c2) {
+        repcheck::lazy_fix(s, d, c1, c2);
         uint64_t sv;
         asm("s_and_saveexec_b64 %2, %3\n\t"       // lanes whose a + t carried take + eps (2^64 = eps)
             "v_lshl_add_u64 %0, %0, 0, %6\n\t"
@@ -277,67 +240,9 @@ struct Goldilocks {
             : "s"(c1), "s"(c2), "s"((uint64_t)P), "s"((uint64_t)EPS)
             : "scc");
     }
-    static __device__ __forceinline__ void addsub_lazy(elem a, elem t, elem &s, elem &d) {
-        uint64_t c1, c2;
-        uint32_t s0, s1, d0, d1;
-        addsub_chains<false>(a, a, t, s0, s1, d0, d1, c1, c2);
-        s = (uint64_t)s0 | ((uint64_t)s1 << 32);
-        d = (uint64_t)d0 | ((uint64_t)d1 << 32);
-        addsub_lazy_fix(s, d, c1, c2);
-    }
-#else
-    SR_HD static void addsub(elem a, elem b, elem &s, elem &d) {
-        s = add(a, b);
-        d = sub(a, b);
-    }
-    SR_HD static void addsub_lazy(elem a, elem t, elem &s, elem &d) {
-        s = a + t;
-        if (s < a) s += EPS;
-        d = a - t;
-        if (a < t) d -= EPS;
-    }
-#endif
-
-    // (hi * 2^64 + lo) mod p, using 2^64 = EPS and 2^96 = -1:  lo - hh + hl * EPS
-#ifdef SR_OLD_REDUCE
-    SR_HD static elem reduce128(uint64_t lo, uint64_t hi) {
-        uint32_t hh = (uint32_t)(hi >> 32), hl = (uint32_t)hi;
-        uint64_t t0 = lo - hh;
-        if (lo < hh) t0 -= EPS;
-        uint64_t t1 = ((uint64_t)hl << 32) - hl;
-        uint64_t r = t0 + t1;
-        if (r < t1) r += EPS;
-        return r >= P ? r - P : r;
-    }
-#else
-#if defined(__HIP_DEVICE_COMPILE__)
-#if !defined(SR_GL_NO_EXECMASK)
-    // a - b for any u64 a and b < 2^32 (+ p on borrow): 3 VALU (see sub)
-    static __device__ __forceinline__ uint64_t sub_small(uint64_t a, uint32_t b) {
-        uint64_t c, sv;
-        uint32_t r0, r1;
-        asm("v_sub_co_u32_e64 %0, %2, %3, %5\n\t"
-            "s_nop 1\n\t"
-            "v_subb_co_u32_e64 %1, %2, %4, 0, %2"
-            : "=&v"(r0), "=&v"(r1), "=&s"(c)
-            : "v"((uint32_t)a), "v"((uint32_t)(a >> 32)), "v"(b));
-        uint64_t r = (uint64_t)r0 | ((uint64_t)r1 << 32);
-        asm("s_and_saveexec_b64 %1, %2\n\t"
-            "v_lshl_add_u64 %0, %0, 0, %3\n\t"
-            "s_mov_b64 exec, %1"
-            : "+v"(r), "=&s"(sv)
-            : "s"(c), "s"((uint64_t)P)
-            : "scc");
-        return r;
-    }
-    // canonical (l2 + hl * EPS) for l2 + hl * EPS < 2^64 + p: 3 VALU.  v_mad_u64_u32 delivers the 65th bit as its carry-out;
-    // that bit or t >= p (one 64-bit compare against p in an SGPR pair) selects the lanes that take + EPS = - p (mod 2^64).
-    // SR_GL_FUSED_FIX (round 3, default on): the three steps as ONE asm statement.  The compiler cannot see into an asm statement
-    // and, on gfx950, puts a wait state (s_nop 0) between a statement that defines a VGPR and a following instruction that reads it
-    // (its dst_sel forwarding hazard, assumed for anything an asm block may contain): as three statements the fold carried two of
-    // them.  VALU write of an SGPR -> SALU read needs no wait state, SALU write of EXEC -> VALU neither.
-#if !defined(SR_GL_FUSED_FIX) || SR_GL_FUSED_FIX
-    static __device__ __forceinline__ elem mad_eps_fix(uint64_t l2, uint32_t hl) {
+    // canonical (l2 + hl * eps) for l2 + hl * eps < 2^64 + p: 3 VALU.  v_mad_u64_u32 delivers the 65th bit as its carry-out (C++
+    // cannot name it); that bit or t >= p (one 64-bit compare against p in an SGPR pair) selects the lanes that take + eps = - p.
+    SR_HD static elem mad_eps_fix(uint64_t l2, uint32_t hl) {
         uint64_t t, cy, c2;
         asm("v_mad_u64_u32 %0, %1, %3, -1, %4\n\t"
             "v_cmp_le_u64_e64 %2, %5, %0\n\t"
@@ -350,96 +255,8 @@ struct Goldilocks {
             : "scc");
         return t;
     }
-#else
-    static __device__ __forceinline__ elem mad_eps_fix(uint64_t l2, uint32_t hl) {
-        uint64_t t, cy, c2, sv;
-        asm("v_mad_u64_u32 %0, %1, %2, -1, %3" : "=v"(t), "=s"(cy) : "v"(hl), "v"(l2));
-        asm("v_cmp_le_u64_e64 %0, %1, %2" : "=s"(c2) : "s"((uint64_t)P), "v"(t));
-        asm("s_or_b64 %1, %2, %3\n\t"
-            "s_and_saveexec_b64 %1, %1\n\t"
-            "v_lshl_add_u64 %0, %0, 0, %4\n\t"
-            "s_mov_b64 exec, %1"
-            : "+v"(t), "=&s"(sv)
-            : "s"(c2), "s"(cy), "s"((uint64_t)EPS)
-            : "scc");
-        return t;
-    }
-#endif
-#else
-    // a - b for any u64 a and b < 2^32 (+ p on borrow).  The high word of b is an opaque zero register: with a literal 0 the
-    // combiner rewrites subcarry(x, 0, c) as x - zext(c) and spends a v_cndmask on materialising c.
-    static __device__ __forceinline__ uint64_t sub_small(uint64_t a, uint32_t b) {
-        uint32_t z = 0, c, br;
-        SR_OPAQUE(z);
-        uint32_t d0 = __builtin_subc((uint32_t)a, b, 0u, &c);
-        uint32_t d1 = __builtin_subc((uint32_t)(a >> 32), z, c, &br);
-        SR_OPAQUE(d1);
-        uint32_t m = 0u - br;
-        uint32_t e0 = __builtin_subc(d0, m, 0u, &c);
-        uint32_t e1 = __builtin_subc(d1, 0u, c, &c);
-        return (uint64_t)e0 | ((uint64_t)e1 << 32);
-    }
-    // canonical (l2 + hl * EPS) for l2 + hl * EPS < 2^64 + p.  v_mad_u64_u32 delivers the 65th bit as its carry-out, which C++
-    // cannot name (the compiler adds the product with v_lshl_add_u64 and recovers the carry with a 64-bit compare), so the
-    // multiply-add and the conditional + EPS are two small asm statements: 1 + 4 VALU instead of 3 + 4.  The s_nop covers the
-    // 2 wait states between a VALU write of an SGPR carry and the VALU read of it.
-#if defined(SR_NO_MAD_ASM)  // plain C++ (A/B builds): the compiler recovers the carry with a 64-bit compare
-    static __device__ __forceinline__ elem mad_eps_fix(uint64_t l2, uint32_t hl) {
-        unsigned __int128 w = (unsigned __int128)l2 + (uint64_t)hl * EPS;
-        uint64_t t = (uint64_t)w;
-        bool c1 = (uint64_t)(w >> 64) != 0;
-        uint32_t c, c2, t0 = (uint32_t)t, t1 = (uint32_t)(t >> 32);
-        SR_OPAQUE(t1);
-        uint32_t u0 = __builtin_addc(t0, 0xFFFFFFFFu, 0u, &c);
-        uint32_t u1 = __builtin_addc(t1, 0u, c, &c2);
-        bool fix = c1 | (c2 != 0);
-        return (uint64_t)(fix ? u0 : t0) | ((uint64_t)(fix ? u1 : t1) << 32);
-    }
-#elif defined(SR_FIX5)  // round-1 form: the conditional + EPS on an add_co / addc_co pair (1 + 4 VALU)
-    static __device__ __forceinline__ elem mad_eps_fix(uint64_t l2, uint32_t hl) {
-        uint64_t t, cy, tmp;
-        uint32_t r0, r1;
-        asm("v_mad_u64_u32 %0, %1, %2, -1, %3" : "=v"(t), "=s"(cy) : "v"(hl), "v"(l2));
-        const uint32_t t0 = (uint32_t)t, t1 = (uint32_t)(t >> 32);
-        asm("v_add_co_u32_e64 %0, %2, -1, %3\n\t"   // u = t + EPS = t - p (mod 2^64); carry <=> t >= p
-            "s_nop 1\n\t"
-            "v_addc_co_u32_e64 %1, %2, 0, %4, %2\n\t"
-            "s_or_b64 %2, %2, %5\n\t"               // or the multiply-add overflowed (then u < p)
-            "v_cndmask_b32_e64 %0, %3, %0, %2\n\t"
-            "v_cndmask_b32_e64 %1, %4, %1, %2"
-            : "=&v"(r0), "=&v"(r1), "=&s"(tmp)
-            : "v"(t0), "v"(t1), "s"(cy)
-            : "scc");  // s_or_b64 writes SCC: without the clobber the scheduler may (and did) drop this statement between an
-                       // s_add_u32 / s_addc_u32 address pair, corrupting the carry (a +2^32 address fault)
-        return (uint64_t)r0 | ((uint64_t)r1 << 32);
-    }
-#else
-    // 1 + 3 VALU: the conditional + EPS is a second v_mad_u64_u32 (1 * 0xFFFFFFFF + t) whose carry-out says t >= p
-    static __device__ __forceinline__ elem mad_eps_fix(uint64_t l2, uint32_t hl) {
-        uint64_t t, u, cy, c2;
-        uint32_t r0, r1;
-        asm("v_mad_u64_u32 %0, %1, %2, -1, %3" : "=v"(t), "=s"(cy) : "v"(hl), "v"(l2));
-        asm("v_mad_u64_u32 %0, %1, 1, -1, %2" : "=v"(u), "=s"(c2) : "v"(t));  // u = t + EPS = t - p (mod 2^64); carry <=> t >= p
-        asm("s_or_b64 %2, %2, %7\n\t"               // or the multiply-add overflowed (then u < p)
-            "v_cndmask_b32_e64 %0, %3, %5, %2\n\t"
-            "v_cndmask_b32_e64 %1, %4, %6, %2"
-            : "=&v"(r0), "=&v"(r1), "+s"(c2)
-            : "v"((uint32_t)t), "v"((uint32_t)(t >> 32)), "v"((uint32_t)u), "v"((uint32_t)(u >> 32)), "s"(cy)
-            : "scc");  // s_or_b64 writes SCC: without the clobber the scheduler may (and did) drop this statement between an
-                       // s_add_u32 / s_addc_u32 address pair, corrupting the carry (a +2^32 address fault)
-        return (uint64_t)r0 | ((uint64_t)r1 << 32);
-    }
-#endif
-#endif  // SR_GL_NO_EXECMASK
-#ifndef SR_GL_MUL_LOHI
-#define SR_GL_MUL_LOHI 0
-#endif
-#ifndef SR_GL_FIX_FOLD
-#define SR_GL_FIX_FOLD 1   // round 3: harness 15.79 -> 15.72 ms per config-2 batch on two streams (three alternations, all lower)
-#endif
-#if !defined(SR_GL_NO_EXECMASK) && SR_GL_FIX_FOLD
-    // the "+ p on the lanes that borrowed" of a subtraction and the fold behind it (mad_eps_fix) as ONE statement: (r + [bo] p) + hl eps
-    static __device__ __forceinline__ elem fix_fold(uint64_t r, uint64_t bo, uint32_t hl) {
+    // the "+ p on the lanes that borrowed" of a subtraction and the fold behind it as ONE statement: canonical ((r + [bo] p) + hl eps)
+    SR_HD static elem fix_fold(uint64_t r, uint64_t bo, uint32_t hl) {
         uint64_t t, cy, c2;
         asm("s_and_saveexec_b64 %1, %4\n\t"
             "v_lshl_add_u64 %3, %3, 0, %6\n\t"
@@ -455,7 +272,8 @@ struct Goldilocks {
             : "scc");
         return t;
     }
-    static __device__ __forceinline__ elem reduce128(uint64_t lo, uint64_t hi) {
+    // (hi * 2^64 + lo) mod p for ANY lo, hi, using 2^64 = eps and 2^96 = -1:  lo - hh + hl * eps
+    SR_HD static elem reduce128(uint64_t lo, uint64_t hi) {
         uint64_t c;
         uint32_t r0, r1;
         asm("v_sub_co_u32_e64 %0, %2, %3, %5\n\t"
@@ -465,46 +283,17 @@ struct Goldilocks {
             : "v"((uint32_t)lo), "v"((uint32_t)(lo >> 32)), "v"((uint32_t)(hi >> 32)));
         return fix_fold((uint64_t)r0 | ((uint64_t)r1 << 32), c, (uint32_t)hi);
     }
-#else
-    static __device__ __forceinline__ elem reduce128(uint64_t lo, uint64_t hi) {
-        return mad_eps_fix(sub_small(lo, (uint32_t)(hi >> 32)), (uint32_t)hi);
-    }
-#endif
-#else
-    SR_HD static elem reduce128(uint64_t lo, uint64_t hi) {
-        uint32_t hh = (uint32_t)(hi >> 32), hl = (uint32_t)hi;
-        uint64_t l2 = sub(lo, (uint64_t)hh);                      // any u64; borrow fixed by + p (never overflows: hh < 2^32)
-        unsigned __int128 w = (unsigned __int128)l2 + (uint64_t)hl * EPS;
-        uint64_t t = (uint64_t)w;
-        bool c1 = (uint64_t)(w >> 64) != 0;                       // then t <= 2^64 - 2^33 and t + EPS < p
-        if (c1 || t >= P) t += EPS;
-        return t;
-    }
-#endif
-#endif
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(SR_GL_NO_EXECMASK) && !defined(SR_OLD_REDUCE) && !defined(SR_GL_MUL_PLAIN)
-    // Device form, 13 VALU.  The compiler's expansion of the 64 x 64 -> 128-bit product zero-extends four 32-bit halves into
-    // 64-bit addends of v_mad_u64_u32 (gfx950 wants 64-bit register pairs even-aligned, so {hi(x), 0} always costs a v_mov_b32)
-    // and adds the two middle carries with a v_lshl_add_u64: 4 mads + 5 moves + 1 add, 16 VALU with the reduction.  Here the middle
-    // product takes its FULL 64-bit addend, al*bh + (ah*bl + hi(al*bl)) = P2 + c 2^64, and the carry-out c (weight 2^96 = -1 mod p)
-    // goes straight into the borrow-in of the reduction's subtraction:
+    // a * b mod p for ANY 64-bit representatives a, b; canonical out.  13 VALU.  The compiler's expansion of the 64 x 64 -> 128-bit
+    // product zero-extends four 32-bit halves into 64-bit addends of v_mad_u64_u32 (gfx950 wants 64-bit register pairs
+    // even-aligned, so {hi(x), 0} always costs a v_mov_b32) and adds the two middle carries with a v_lshl_add_u64: 16 VALU with the
+    // reduction.  Here the middle product takes its FULL 64-bit addend, al*bh + (ah*bl + hi(al*bl)) = P2 + c 2^64, and the carry-out
+    // c (weight 2^96 = -1 mod p) goes straight into the borrow-in of the reduction's subtraction:
     //   a b = LO + P3 2^64 + c 2^96,  LO = {lo(al bl), lo(P2)},  P3 = ah bh + hi(P2)   ==>   a b = LO - hi(P3) - c + lo(P3) eps  (mod p)
-    // Same value bit for bit as reduce128 of the 128-bit product (SR_GL_MUL_PLAIN: A/B switch).
-    static __device__ __forceinline__ elem mul(elem a, elem b) {
+    SR_HD static elem mul(elem a, elem b) {
         const uint32_t al = (uint32_t)a, ah = (uint32_t)(a >> 32), bl = (uint32_t)b, bh = (uint32_t)(b >> 32);
-#if SR_GL_MUL_LOHI
-        // al * bl as v_mul_lo_u32 + v_mul_hi_u32: the high word lands in a register whose partner is a standing zero (the 64-bit
-        // addend of the next product) without the v_mov_b32 a v_mad_u64_u32 result needs, and the two cost 1.66 nJ per wave against
-        // 2.7 nJ for mad + mov (profiles/r02/valu_energy.txt) -- the step is bound by its energy under the 1.4 kW cap
-        uint32_t p0h;
-        p0h = __umulhi(al, bl);
-        const uint64_t p0 = (uint64_t)(al * bl);             // only the low word is used below
-        const uint64_t p1 = (uint64_t)ah * bl + p0h;         // <= 2^64 - 2^32
-#else
         const uint64_t p0 = (uint64_t)al * bl;
         const uint64_t p1 = (uint64_t)ah * bl + (p0 >> 32);  // <= 2^64 - 2^32
-#endif
-        uint64_t p2, c, bo, sv;
+        uint64_t p2, c, bo;
         asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(p2), "=s"(c) : "v"(al), "v"(bh), "v"(p1));
         const uint64_t p3 = (uint64_t)ah * bh + (p2 >> 32);  // <= 2^64 - 2^32
         uint32_t r0, r1;
@@ -517,26 +306,62 @@ struct Goldilocks {
             "v_subb_co_u32_e64 %1, %2, %4, 0, %2"
             : "=&v"(r0), "=&v"(r1), "=&s"(bo)
             : "v"((uint32_t)p0), "v"((uint32_t)p2), "v"((uint32_t)(p3 >> 32)), "s"(c));
-        uint64_t r = (uint64_t)r0 | ((uint64_t)r1 << 32);
-#if SR_GL_FIX_FOLD
-        (void)sv;
-        return fix_fold(r, bo, (uint32_t)p3);
-#else
-        asm("s_and_saveexec_b64 %1, %2\n\t"
-            "v_lshl_add_u64 %0, %0, 0, %3\n\t"
-            "s_mov_b64 exec, %1"
-            : "+v"(r), "=&s"(sv)
-            : "s"(bo), "s"((uint64_t)P)
-            : "scc");
-        return mad_eps_fix(r, (uint32_t)p3);
-#endif
+        return fix_fold((uint64_t)r0 | ((uint64_t)r1 << 32), bo, (uint32_t)p3);
     }
 #else
+    SR_HD static elem add(elem a, elem b) {
+        const uint64_t s = a + b;
+        return ((s < a) | (s >= P)) ? s + EPS : s;
+    }
+    SR_HD static elem sub(elem a, elem b) {
+        const uint64_t d = a - b;
+        return a < b ? d - EPS : d;
+    }
+    SR_HD static void addsub(elem a, elem b, elem &s, elem &d) {
+        s = add(a, b);
+        d = sub(a, b);
+    }
+    SR_HD static elem plus_eps(elem a) { return a + EPS; }
+    template <bool SWAP>
+    SR_HD static void addsub_chains(elem t, elem a, elem b, uint32_t &s0, uint32_t &s1, uint32_t &d0, uint32_t &d1, uint64_t &c1, uint64_t &c2) {
+        const elem m = SWAP ? b : a, n = SWAP ? a : b;
+        const uint64_t s = t + b, d = m - n;
+        c1 = s < t;   // carry of t + b
+        c2 = m < n;   // borrow of m - n
+        s0 = (uint32_t)s, s1 = (uint32_t)(s >> 32), d0 = (uint32_t)d, d1 = (uint32_t)(d >> 32);
+    }
+    SR_HD static void addsub_fix(elem &s, elem &d, uint64_t c1, uint64_t c2) {
+        if (!c1) s += P;   // takes the eps of plus_eps back
+        if (c2) d += P;
+    }
+    SR_HD static void addsub_lazy_fix(elem &s, elem &d, uint64_t c1, uint64_t c2) {
+        if (c1) s += EPS;
+        if (c2) d += P;
+    }
+    SR_HD static elem mad_eps_fix(uint64_t l2, uint32_t hl) {
+        const unsigned __int128 w = (unsigned __int128)l2 + (uint64_t)hl * EPS;
+        uint64_t t = (uint64_t)w;
+        if ((uint64_t)(w >> 64) != 0 || t >= P) t += EPS;   // on overflow t <= 2^64 - 2^33 and t + eps < p
+        return t;
+    }
+    SR_HD static elem fix_fold(uint64_t r, uint64_t bo, uint32_t hl) { return mad_eps_fix(bo ? r + P : r, hl); }
+    SR_HD static elem reduce128(uint64_t lo, uint64_t hi) {
+        const uint32_t hh = (uint32_t)(hi >> 32);
+        return fix_fold(lo - hh, lo < hh, (uint32_t)hi);   // lo - hh + [borrow] p never overflows: hh < 2^32
+    }
     SR_HD static elem mul(elem a, elem b) {
-        unsigned __int128 x = (unsigned __int128)a * b;
+        const unsigned __int128 x = (unsigned __int128)a * b;
         return reduce128((uint64_t)x, (uint64_t)(x >> 64));
     }
 #endif
+    SR_HD static void addsub_lazy(elem a, elem t, elem &s, elem &d) {
+        uint64_t c1, c2;
+        uint32_t s0, s1, d0, d1;
+        addsub_chains<false>(a, a, t, s0, s1, d0, d1, c1, c2);
+        s = (uint64_t)s0 | ((uint64_t)s1 << 32);
+        d = (uint64_t)d0 | ((uint64_t)d1 << 32);
+        addsub_lazy_fix(s, d, c1, c2);
+    }
     SR_HD static elem mul_tw(elem a, elem w) { return mul(a, w); }
     // a * b * 2^-64: 2^-64 = -2^32 (mod p), so (hi, lo) -> hi - lo * 2^32
     SR_HD static elem mul_boundary(elem a, elem b) {

@@ -245,6 +245,56 @@ template <class F, bool SUB>
 __global__ __launch_bounds__(256) void addsub_kernel(typename F::storage *lhs, const typename F::storage *rhs, size_t n) {
     elementwise2<F>(lhs, rhs, n, [](const typename F::elem &a, const typename F::elem &b) { return SUB ? F::sub(a, b) : F::add(a, b); });
 }
+// the unary form: data[i] = op(data[i]), same access shape
+template <class F, class Op>
+__device__ __forceinline__ void elementwise1(typename F::storage *data, size_t n, Op op) {
+    const size_t gid = blockIdx.x * (size_t)blockDim.x + threadIdx.x, stride = (size_t)gridDim.x * blockDim.x;
+    size_t done = 0;
+    if constexpr (sizeof(typename F::storage) == 8) {
+        if (((uintptr_t)data & 15u) == 0) {
+            typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+            const size_t pairs = n >> 1;
+            u64x2 *d2 = reinterpret_cast<u64x2 *>(data);
+            for (size_t i = gid; i < pairs; i += stride) {
+                u64x2 x = __builtin_nontemporal_load(d2 + i);
+                typename F::storage xs[2] = {x.x, x.y};
+                F::store(&xs[0], op(F::load(&xs[0])));
+                F::store(&xs[1], op(F::load(&xs[1])));
+                x.x = xs[0];
+                x.y = xs[1];
+                __builtin_nontemporal_store(x, d2 + i);
+            }
+            done = pairs << 1;
+        }
+    }
+    for (size_t i = done + gid; i < n; i += stride) F::store(data + i, op(F::load(data + i)));
+}
+// data[i] = -data[i]: Neg of RqPoly / RqNTT (coeff_form.rs:270-278 `self.0.map(|x| -x)`, ntt_form.rs:191-203) -- the same word-wise
+// map in either form and for every ring (an Fq3 / Fq9 / Fq4 slot negates component-wise)
+template <class F>
+__global__ __launch_bounds__(256) void neg_kernel(typename F::storage *data, size_t n) {
+    elementwise1<F>(data, n, [](const typename F::elem &a) { return F::neg(a); });
+}
+// data[i] = data[i] * s on the in-memory images, s one base-field scalar (its memory image, a kernel argument): Mul<Fp> =
+// poly_mul(from_scalar(rhs)) and Mul<u128 | u64 | ... | bool> / MulAssign of RqPoly (coeff_form.rs:390-408, 610-650:
+// `self.0.iter_mut().for_each(|lhs| *lhs *= r)`) and of RqNTT (ntt_form.rs:373-425: `*lhs *= BaseCRTField::from(rhs)` -- a
+// base-field element embedded in Fq3 / Fq9 / Fq4 is (r, 0, ..), so the slot product scales every component by r)
+template <class F>
+__global__ __launch_bounds__(256) void scale_kernel(typename F::storage *data, size_t n, typename F::storage scalar) {
+    const typename F::elem s = F::load(&scalar);
+    elementwise1<F>(data, n, [s](const typename F::elem &a) { return F::mul_boundary(a, s); });
+}
+// data[i * stride] += s for i < count: Add<primitive> / Sub<primitive> (the caller negates).  RqPoly: `self.0[0] += Fp::from(rhs)`,
+// stride = D words, one per ring element (coeff_form.rs:652-700); RqNTT: `*lhs += BaseCRTField::from(rhs)` for every slot, i.e.
+// component 0 of every slot, stride = the slot's extension degree (ntt_form.rs:427-505)
+template <class F>
+__global__ __launch_bounds__(256) void add_scalar_kernel(typename F::storage *data, size_t count, size_t stride, typename F::storage scalar) {
+    const typename F::elem s = F::load(&scalar);
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < count; i += (size_t)gridDim.x * blockDim.x) {
+        typename F::storage *p = data + i * stride;
+        F::store(p, F::add(F::load(p), s));
+    }
+}
 // workgroups for a streaming kernel over n coefficients: one 16-byte access per lane where the field allows it (no grid-stride
 // loop below 2^24 workgroups (HIP limits a launch to 2^32 lanes): a lane that loops streams measurably worse, see elementwise2)
 template <class F>

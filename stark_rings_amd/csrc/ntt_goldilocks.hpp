@@ -37,125 +37,55 @@ typedef uint32_t u32;
 
 constexpr int kW16Exp = 156;  // omega_16 = 2^156 (= (8^13)^4)
 
-// coefficient streams are read once and written once per launch: SR_GL_NT = 1 marks them non-temporal (A/B switch)
-#ifndef SR_GL_NT
-#define SR_GL_NT 1
-#endif
-// The workgroups that share a CU all run the same program and start together, so their load, compute and store phases tend to
-// stay aligned for the whole launch (everyone waits on HBM, then everyone competes for the VALU).  SR_GL_STAGGER delays the
-// first-round workgroups of a launch by a quarter of a tile time per resident slot, which de-phases the slots for good (a slot
-// is refilled when its workgroup ends).  Only timing changes.
-#ifndef SR_GL_STAGGER
-#define SR_GL_STAGGER 0
-#endif
-__device__ __forceinline__ void stagger_first_round() {
-#if SR_GL_STAGGER
-    if (blockIdx.x < 1024u) {  // 256 CUs x 4 resident workgroups: the first round
-        const unsigned slot = (blockIdx.x >> 8) & 3u;
-        for (unsigned i = 0; i < slot * SR_GL_STAGGER; i++) __builtin_amdgcn_s_sleep(127);
-    }
-#endif
-}
-// SR_GL_SETPRIO = 1: a wave raises its issue priority while it puts its coefficient loads (and, at the end, its stores) in flight,
-// so that memory requests of a fresh workgroup are not queued behind the butterflies of the resident ones (A/B switch)
-#ifndef SR_GL_SETPRIO
-#define SR_GL_SETPRIO 0
-#endif
-__device__ __forceinline__ void prio_mem() {
-#if SR_GL_SETPRIO
-    __builtin_amdgcn_s_setprio(3);
-#endif
-}
-__device__ __forceinline__ void prio_alu() {
-#if SR_GL_SETPRIO
-    __builtin_amdgcn_s_setprio(0);
-#endif
-}
-__device__ __forceinline__ u64 ld_stream(const u64 *p) {
-#if SR_GL_NT
-    return __builtin_nontemporal_load(p);
-#else
-    return *p;
-#endif
-}
-__device__ __forceinline__ void st_stream(u64 *p, u64 v) {
-#if SR_GL_NT
-    __builtin_nontemporal_store(v, p);
-#else
-    *p = v;
-#endif
-}
-// Intermediates (column-pass output, rows output) are written and read WITHOUT the non-temporal hint, so that they allocate in the
-// 256 MB Infinity Cache: the ring product runs in chunks small enough for a chunk's intermediates to stay there (gl_fast_ring_mul_lanes).
-// Operand reads and result writes keep the hint.  SR_GL_NT_SCRATCH = 1: everything non-temporal (A/B switch).
-#ifndef SR_GL_NT_SCRATCH
-#define SR_GL_NT_SCRATCH 0
-#endif
-__device__ __forceinline__ u64 ld_scratch(const u64 *p) {
-#if SR_GL_NT_SCRATCH
-    return ld_stream(p);
-#else
-    return *p;
-#endif
-}
-__device__ __forceinline__ void st_scratch(u64 *p, u64 v) {
-#if SR_GL_NT_SCRATCH
+// Operand reads and result writes happen once per launch: non-temporal.  Intermediates (column-pass output, rows output) are written
+// and read WITHOUT the hint, so that they allocate in the 256 MB Infinity Cache: the ring product runs in chunks small enough for a
+// chunk's intermediates to stay there (gl_fast_ring_mul_lanes).  Tables keep the default policy and stay in L2.
+__device__ __forceinline__ u64 ld_stream(const u64 *p) { return __builtin_nontemporal_load(p); }
+__device__ __forceinline__ void st_stream(u64 *p, u64 v) { __builtin_nontemporal_store(v, p); }
+__device__ __forceinline__ u64 ld_scratch(const u64 *p) { return *p; }
+__device__ __forceinline__ void st_scratch(u64 *p, u64 v) { *p = v; }
+// a word that leaves the library (a result of sr_ntt_fwd / sr_ntt_inv / sr_ring_mul): canonical by contract
+__device__ __forceinline__ void st_result(u64 *p, u64 v) {
+    repcheck::leaves_library(v);
     st_stream(p, v);
-#else
+}
+// the NTT slots a plain forward transform leaves in place of its operand (default cache policy, as ever)
+__device__ __forceinline__ void st_slots(u64 *p, u64 v) {
+    repcheck::leaves_library(v);
     *p = v;
-#endif
 }
 constexpr int kTile = 4096;
 constexpr int kLdsElems = kTile + kTile / 16;  // padded: pos + (pos >> 4)
 
-// x * 2^E mod p for a compile-time 0 < E < 96; canonical in, canonical out
+// x * 2^E mod p for a compile-time 0 < E < 96.  ANY 64-bit representative in (nothing below assumes x < p: the three branches
+// only need l2 + hl eps < 2^64 + p, which holds for every x -- tools/ubench/field_check.hip runs all 95 exponents on
+// non-canonical operands), canonical out: 5 / 7 / 7 VALU for E < 32 / < 64 / < 96.
 template <int E>
 SR_HD u64 mul_pow2(u64 x) {
     static_assert(E > 0 && E < 96, "shift out of range");
     constexpr int q = E / 32, r = E % 32;
     const u64 xs = x << r;                                  // low 64 bits of x * 2^r
-    const u32 y2 = r ? (u32)(x >> (64 - r)) : 0u;           // bits 64.. of x * 2^r
+    const u32 y2 = r ? (u32)(x >> (64 - r)) : 0u;           // bits 64.. of x * 2^r  (< 2^31)
+    u64 res;
     if constexpr (q == 0) {
-#if defined(__HIP_DEVICE_COMPILE__)
-        return G::mad_eps_fix(xs, y2);  // xs + y2 * EPS: nothing to subtract (reduce128 with a zero top word)
-#else
-        return G::reduce128(xs, (u64)y2);
-#endif
+        res = G::mad_eps_fix(xs, y2);                       // xs + y2 * eps: nothing to subtract (reduce128 with a zero top word)
     } else if constexpr (q == 1) {
-        return G::reduce128(xs << 32, (xs >> 32) | ((u64)y2 << 32));
-    } else {
-#if !defined(SR_GL_POW2_RIGHT)  // (y0 + y1 2^32 + y2 2^64) * 2^64 = y0 * EPS - (y1 + y2 2^32): 7 VALU
+        res = G::reduce128(xs << 32, (xs >> 32) | ((u64)y2 << 32));
+    } else {                                                // (y0 + y1 2^32 + y2 2^64) * 2^64 = y0 * eps - (y1 + y2 2^32)
         const u32 y0 = (u32)xs;
-        const u64 B = ((u64)y0 << 32) - y0;                  // y0 * (2^32 - 1) < p
-        const u64 C = (xs >> 32) | ((u64)y2 << 32);          // < 2^63 < p
-        return G::sub(B, C);
-#else
-        // Round-2 experiment (SR_GL_POW2_RIGHT; also 7 VALU once compiled, so not the default): 64 <= E < 96 as a RIGHT shift:
-        // 2^E = -2^-s with s = 96 - E in (0, 32].  Split x = xh 2^s + xl:
-        // x 2^-s = xh + xl 2^-s, and 2^-s = -2^(96-s) = -2^(32-s) 2^64, so xl 2^-s = -(xl << (32 - s)) EPS = -t EPS with
-        // t < 2^32.  Hence x 2^E = t EPS - xh: one product by 0xFFFFFFFF (t EPS < p) and one subtraction (xh < 2^63 < p).
-        constexpr int sft = 96 - E;
-        const u32 t = sft == 32 ? (u32)x : (u32)x << (32 - sft);
-        const u64 xh = x >> sft;
-        return G::sub((u64)t * 0xFFFFFFFFull, xh);
-#endif
+        const u64 B = ((u64)y0 << 32) - y0;                 // y0 * (2^32 - 1) < p
+        const u64 C = (xs >> 32) | ((u64)y2 << 32);         // < 2^63 < p
+        res = G::sub(B, C);
     }
+    repcheck::canonical_out(res);
+    return res;
 }
 
-// How the butterflies are emitted (round 3; same values, same 7 VALU per butterfly -- what changes is the number of NON-VALU issue
-// slots a wave spends: s_nop wait states and EXEC juggling, 3 031 per 2 915 VALU in rows256_kernel<2> before, 2 164 now):
-//   0  add and sub as two independent routines (rounds 1 and 2)
-//   1  the sum and the difference of a butterfly from ONE asm statement (Goldilocks::addsub): the two carry chains fill each
-//      other's wait states, one EXEC save / restore serves both corrections
-//   2  (default) the butterflies of a whole stage phase by phase (dif_stage_phased / dit_stage_phased below)
-// tools/ubench/gl_bench.hip, config-2 batch on two streams: 16.37 / 16.04 / 15.82 ms for 0 / 1 / 2.
-#ifndef SR_GL_FUSED_BF
-#define SR_GL_FUSED_BF 2
-#endif
-// decimation-in-frequency butterfly: (a, b) -> (a + b, (a - b) * 2^E), E in [0, 192)
+// decimation-in-frequency butterfly: (a, b) -> (a + b, (a - b) * 2^E), E in [0, 192); canonical in, canonical out.
+// FUSED: sum and difference from one statement (Goldilocks::addsub); otherwise add and sub as separate routines (the form the
+// whole-ring-element tiles keep: they are at 160 VGPRs already).
 template <int E, bool FUSED = true>
 SR_HD void bf_dif(u64 &a, u64 &b) {
-#if SR_GL_FUSED_BF
     if constexpr (FUSED && E < 96) {
         u64 s, d;
         G::addsub(a, b, s, d);
@@ -164,7 +94,6 @@ SR_HD void bf_dif(u64 &a, u64 &b) {
         else b = mul_pow2<E>(d);
         return;
     }
-#endif
     const u64 s = G::add(a, b);
     u64 d;
     if constexpr (E == 0) {
@@ -179,13 +108,11 @@ SR_HD void bf_dif(u64 &a, u64 &b) {
     a = s;
     b = d;
 }
-// decimation-in-time butterfly: (u, v) -> (u + v 2^E, u - v 2^E).  LAZY (round 3, SR_GL_LAZY_DIT): a butterfly with a shift
-// (E % 96 != 0) adds and subtracts the CANONICAL v 2^E to any 64-bit representative u with six VALU instead of seven
-// (Goldilocks::addsub_lazy) and leaves arbitrary representatives; butterflies with twiddle 1 keep the canonical form -- in the
-// DFT_16 networks below their inputs always come out of twiddle-1 butterflies (tools/model_fast_goldilocks.py asserts it).
-#ifndef SR_GL_LAZY_DIT
-#define SR_GL_LAZY_DIT 1
-#endif
+// decimation-in-time butterfly: (u, v) -> (u + v 2^E, u - v 2^E).  LAZY: a butterfly with a shift (E % 96 != 0) adds and subtracts
+// the CANONICAL v 2^E to ANY 64-bit representative u with six VALU instead of seven (Goldilocks::addsub_lazy) and leaves arbitrary
+// representatives; butterflies with twiddle 1 keep the canonical form and need canonical inputs -- in the DFT_16 networks below
+// their inputs always come out of twiddle-1 butterflies, all the way back to the network's inputs (tools/model_fast_goldilocks.py
+// asserts it; the SR_GL_CHECK_REPS build counts violations on the device).
 template <int E, bool FUSED = true, bool LAZY = false>
 SR_HD void bf_dit(u64 &u, u64 &v) {
     if constexpr (LAZY && E % 96 != 0) {
@@ -196,7 +123,6 @@ SR_HD void bf_dit(u64 &u, u64 &v) {
         v = E >= 96 ? s : d;
         return;
     }
-#if SR_GL_FUSED_BF
     if constexpr (FUSED && E < 96) {
         u64 t = v;
         if constexpr (E != 0) t = mul_pow2<E>(v);
@@ -214,7 +140,6 @@ SR_HD void bf_dit(u64 &u, u64 &v) {
         v = s;
         return;
     }
-#endif
     if constexpr (E == 0) {
         const u64 s = G::add(u, v), d = G::sub(u, v);
         u = s;
@@ -266,16 +191,17 @@ struct StageNat {
         static constexpr int E = (kW16Exp * half * brv_n(I / half, U)) % 192;
     };
 };
-#if SR_GL_FUSED_BF == 2 && defined(__HIP_DEVICE_COMPILE__)
-// SR_GL_FUSED_BF = 2: the butterflies of a stage run PHASE BY PHASE -- every a + eps, then every pair of carry chains, then every
-// pair of masked corrections, then every shift product -- so that no statement's result is read by the statement right behind it
-// (the compiler's post-asm wait state has nowhere to go) and independent work sits between producer and consumer everywhere.
+// The butterflies of a stage run PHASE BY PHASE -- every a + eps, then every pair of carry chains, then every pair of masked
+// corrections, then every shift product -- so that no statement's result is read by the statement right behind it (the compiler's
+// post-asm wait state has nowhere to go) and independent work sits between producer and consumer everywhere: same values, same
+// seven VALU per butterfly as one Goldilocks::addsub each, a third fewer non-VALU issue slots.
 // BF<I> describes butterfly I of the stage: register slots lo, hi and its twiddle exponent E in [0, 192).
 template <template <int> class BF, int... Is>
-SR_HD void dif_phased(u64 *x, std::integer_sequence<int, Is...>) {  // (a, b) -> (a + b, (a - b) 2^E)
+SR_HD void dif_phased(u64 *x, std::integer_sequence<int, Is...>) {  // (a, b) -> (a + b, (a - b) 2^E); canonical in and out
     constexpr int n = 8;  // indexed by the butterfly number (a group may be any subset of a stage's eight)
     u64 t[n], c1[n], c2[n];
     u32 s0[n], s1[n], d0[n], d1[n];
+    (repcheck::canonical_in(x[BF<Is>::lo], x[BF<Is>::hi]), ...);
     ((t[Is] = G::plus_eps(x[BF<Is>::lo])), ...);
     (G::addsub_chains<(BF<Is>::E >= 96)>(t[Is], x[BF<Is>::lo], x[BF<Is>::hi], s0[Is], s1[Is], d0[Is], d1[Is], c1[Is], c2[Is]), ...);
     ((x[BF<Is>::lo] = (u64)s0[Is] | ((u64)s1[Is] << 32), x[BF<Is>::hi] = (u64)d0[Is] | ((u64)d1[Is] << 32)), ...);
@@ -283,12 +209,17 @@ SR_HD void dif_phased(u64 *x, std::integer_sequence<int, Is...>) {  // (a, b) ->
     ((x[BF<Is>::hi] = shift96<BF<Is>::E % 96>(x[BF<Is>::hi])), ...);
 }
 template <bool LZ>
-__device__ __forceinline__ u64 dit_pre_add(u64 a) {   // the a + eps of the canonical sum; a lazy butterfly has none
-    if constexpr (LZ) return a;
-    else return G::plus_eps(a);
+SR_HD u64 dit_pre_add(u64 a, u64 t) {   // the a + eps of the canonical sum; a lazy butterfly has none
+    if constexpr (LZ) {
+        repcheck::canonical_in(t, t);     // any a, canonical t (the shift product)
+        return a;
+    } else {
+        repcheck::canonical_in(a, t);
+        return G::plus_eps(a);
+    }
 }
 template <bool LZ>
-__device__ __forceinline__ void dit_fix(u64 &s, u64 &d, u64 c1, u64 c2) {
+SR_HD void dit_fix(u64 &s, u64 &d, u64 c1, u64 c2) {
     if constexpr (LZ) G::addsub_lazy_fix(s, d, c1, c2);
     else G::addsub_fix(s, d, c1, c2);
 }
@@ -299,7 +230,7 @@ SR_HD void dit_phased(u64 *x, std::integer_sequence<int, Is...>) {  // (u, v) ->
     u32 s0[n], s1[n], d0[n], d1[n];
     // v 2^E first (E >= 96: v 2^(E - 96), and the legs swap: u - t is the sum leg)
     ((x[BF<Is>::hi] = shift96<BF<Is>::E % 96>(x[BF<Is>::hi])), ...);
-    ((t[Is] = dit_pre_add<(LAZY && BF<Is>::E % 96 != 0)>(x[BF<Is>::lo])), ...);
+    ((t[Is] = dit_pre_add<(LAZY && BF<Is>::E % 96 != 0)>(x[BF<Is>::lo], x[BF<Is>::hi])), ...);
     (G::addsub_chains<false>(t[Is], x[BF<Is>::lo], x[BF<Is>::hi], s0[Is], s1[Is], d0[Is], d1[Is], c1[Is], c2[Is]), ...);
     ((sv[Is] = (u64)s0[Is] | ((u64)s1[Is] << 32), dv[Is] = (u64)d0[Is] | ((u64)d1[Is] << 32)), ...);
     (dit_fix<(LAZY && BF<Is>::E % 96 != 0)>(sv[Is], dv[Is], c1[Is], c2[Is]), ...);
@@ -314,13 +245,11 @@ struct StageOf {
         static constexpr int E = DIT ? (192 - (STEP * (I % HALF)) % 192) % 192 : (STEP * (I % HALF)) % 192;
     };
 };
-// P butterflies go through the phases together: 8 = a whole stage of a DFT_16 (the default, SR_GL_PHASE_GROUP), 4 = half a stage
-// (eight VGPRs fewer in flight); P = 0: butterfly by butterfly (Goldilocks::addsub); P < 0: add and sub as separate routines (round 2).
-// The fused 4096-point product kernels keep a whole transformed tile in registers beside the one in flight and spill under the
-// phased form (28-31 VGPRs): they take P = 0, and the whole-ring-element tiles (D <= 4096, already at 160 VGPRs) P = -1.
-#ifndef SR_GL_PHASE_GROUP
-#define SR_GL_PHASE_GROUP 8
-#endif
+// P butterflies go through the phases together: 8 = a whole stage of a DFT_16 (kPhased, what every kernel but the fused 4096-point
+// products uses); P = 0: butterfly by butterfly (Goldilocks::addsub); P < 0: add and sub as separate routines.  The fused
+// 4096-point product kernels keep a whole transformed tile in registers beside the one in flight and spill under the phased form
+// (28-31 VGPRs): they take P = 0, and the whole-ring-element tiles (D <= 4096, already at 160 VGPRs) P = -1.
+constexpr int kPhased = 8;
 template <int OFF, int... Is>
 constexpr std::integer_sequence<int, (OFF + Is)...> seq_from(std::integer_sequence<int, Is...>) { return {}; }
 template <template <int> class BF, bool DIT, int N, int P, bool LAZY = false>
@@ -334,12 +263,12 @@ SR_HD void stage_in_groups(u64 *x) {
         if constexpr (G < N) dif_phased<BF>(x, seq_from<G>(std::make_integer_sequence<int, N - G>{}));
     }
 }
-template <int HALF, int STEP, int P = SR_GL_PHASE_GROUP, int... Bs>
+template <int HALF, int STEP, int P = kPhased, int... Bs>
 SR_HD void dif_stage(u64 *x, std::integer_sequence<int, Bs...>) {
     if constexpr (P <= 0) (dif_group<HALF, STEP, Bs * 2 * HALF, P == 0>(x, std::make_integer_sequence<int, HALF>{}), ...);
     else stage_in_groups<StageOf<HALF, STEP, false>::template Bf, false, HALF * (int)sizeof...(Bs), P>(x);
 }
-template <int HALF, int STEP, int P = SR_GL_PHASE_GROUP, bool LAZY = false, int... Bs>
+template <int HALF, int STEP, int P = kPhased, bool LAZY = false, int... Bs>
 SR_HD void dit_stage(u64 *x, std::integer_sequence<int, Bs...>) {
     if constexpr (P <= 0) (dit_group<HALF, STEP, Bs * 2 * HALF, P == 0, LAZY>(x, std::make_integer_sequence<int, HALF>{}), ...);
     else stage_in_groups<StageOf<HALF, STEP, true>::template Bf, true, HALF * (int)sizeof...(Bs), P, LAZY>(x);
@@ -348,34 +277,13 @@ template <int U, int P, bool LAZY, int... Is>
 SR_HD void dit_nat_bfs(u64 *x, std::integer_sequence<int, Is...>) {
     (bf_dit<StageNat<U>::template Bf<Is>::E, P == 0, LAZY>(x[StageNat<U>::template Bf<Is>::lo], x[StageNat<U>::template Bf<Is>::hi]), ...);
 }
-template <int U, int P = SR_GL_PHASE_GROUP, bool LAZY = false>
+template <int U, int P = kPhased, bool LAZY = false>
 SR_HD void dit_nat_stage(u64 *x) {
     if constexpr (P <= 0) dit_nat_bfs<U, P, LAZY>(x, std::make_integer_sequence<int, 8>{});
     else stage_in_groups<StageNat<U>::template Bf, true, 8, P, LAZY>(x);
 }
-#else
-#ifndef SR_GL_PHASE_GROUP
-#define SR_GL_PHASE_GROUP 8
-#endif
-template <int HALF, int STEP, int P = SR_GL_PHASE_GROUP, int... Bs>
-SR_HD void dif_stage(u64 *x, std::integer_sequence<int, Bs...>) {
-    (dif_group<HALF, STEP, Bs * 2 * HALF, (P >= 0)>(x, std::make_integer_sequence<int, HALF>{}), ...);
-}
-template <int HALF, int STEP, int P = SR_GL_PHASE_GROUP, bool LAZY = false, int... Bs>
-SR_HD void dit_stage(u64 *x, std::integer_sequence<int, Bs...>) {
-    (dit_group<HALF, STEP, Bs * 2 * HALF, (P >= 0), LAZY>(x, std::make_integer_sequence<int, HALF>{}), ...);
-}
-template <int U, int P, bool LAZY, int... Is>
-SR_HD void dit_nat_bfs(u64 *x, std::integer_sequence<int, Is...>) {
-    (bf_dit<StageNat<U>::template Bf<Is>::E, (P >= 0), LAZY>(x[StageNat<U>::template Bf<Is>::lo], x[StageNat<U>::template Bf<Is>::hi]), ...);
-}
-template <int U, int P = SR_GL_PHASE_GROUP, bool LAZY = false>
-SR_HD void dit_nat_stage(u64 *x) {
-    dit_nat_bfs<U, P, LAZY>(x, std::make_integer_sequence<int, 8>{});
-}
-#endif
 // 16-point cyclic DFT with omega_16 = 2^156: natural order in, bit-reversed order out (unnormalised)
-template <int P = SR_GL_PHASE_GROUP>
+template <int P = kPhased>
 SR_HD void dft16_fwd(u64 *x) {
     dif_stage<8, kW16Exp, P>(x, std::make_integer_sequence<int, 1>{});
     dif_stage<4, (kW16Exp * 2) % 192, P>(x, std::make_integer_sequence<int, 2>{});
@@ -384,7 +292,7 @@ SR_HD void dft16_fwd(u64 *x) {
 }
 // inverse network: bit-reversed order in, natural order out, result = 16 * original.  LAZY: canonical in, arbitrary 64-bit
 // representatives out (slot 0, which only twiddle-1 butterflies touch, stays canonical)
-template <int P = SR_GL_PHASE_GROUP, bool LAZY = false>
+template <int P = kPhased, bool LAZY = false>
 SR_HD void dft16_inv(u64 *x) {
     dit_stage<1, (kW16Exp * 8) % 192, P, LAZY>(x, std::make_integer_sequence<int, 8>{});
     dit_stage<2, (kW16Exp * 4) % 192, P, LAZY>(x, std::make_integer_sequence<int, 4>{});
@@ -392,7 +300,7 @@ SR_HD void dft16_inv(u64 *x) {
     dit_stage<8, kW16Exp, P, LAZY>(x, std::make_integer_sequence<int, 1>{});
 }
 // dft16_fwd as a decimation-in-time network (StageNat): same order in, same order out, same values (mod p)
-template <int P = SR_GL_PHASE_GROUP, bool LAZY = false>
+template <int P = kPhased, bool LAZY = false>
 SR_HD void dft16_fwd_dit(u64 *x) {
     dit_nat_stage<0, P, LAZY>(x);
     dit_nat_stage<1, P, LAZY>(x);
@@ -400,27 +308,24 @@ SR_HD void dft16_fwd_dit(u64 *x) {
     dit_nat_stage<3, P, LAZY>(x);
 }
 // what the D = 2^16 .. 2^20 kernels call: CANON = the results leave the library as they are (plain forward transform)
-template <bool CANON = false>
+template <bool CANON = false, int P = kPhased>
 SR_HD void dft16_fwd_hot(u64 *x) {
-#if SR_GL_LAZY_DIT == 1   // (2: lazy butterflies in the networks that were DIT already, the forward DFT_16 stays DIF: A/B switch)
-    dft16_fwd_dit<SR_GL_PHASE_GROUP, !CANON>(x);
-#else
-    dft16_fwd(x);
-#endif
+    dft16_fwd_dit<P, !CANON>(x);
 }
-SR_HD void dft16_inv_hot(u64 *x) { dft16_inv<SR_GL_PHASE_GROUP, (SR_GL_LAZY_DIT != 0)>(x); }
+template <int P = kPhased>
+SR_HD void dft16_inv_hot(u64 *x) { dft16_inv<P, true>(x); }
 
 // Q leading stages skipped: 2^Q independent cyclic DFTs of size 16 >> Q on consecutive register groups (used when
 // D < 4096 and a tile holds 2^Q ring elements: the stride-256 pass must not mix them); same twiddles as the tail
 // of the full network because omega_(16 >> Q) = omega_16^(2^Q)
-template <int Q, int P = SR_GL_PHASE_GROUP>
+template <int Q, int P = kPhased>
 SR_HD void dft16_fwd_q(u64 *x) {
     if constexpr (Q <= 0) dif_stage<8, kW16Exp, P>(x, std::make_integer_sequence<int, 1>{});
     if constexpr (Q <= 1) dif_stage<4, (kW16Exp * 2) % 192, P>(x, std::make_integer_sequence<int, 2>{});
     if constexpr (Q <= 2) dif_stage<2, (kW16Exp * 4) % 192, P>(x, std::make_integer_sequence<int, 4>{});
     if constexpr (Q <= 3) dif_stage<1, (kW16Exp * 8) % 192, P>(x, std::make_integer_sequence<int, 8>{});
 }
-template <int Q, int P = SR_GL_PHASE_GROUP>
+template <int Q, int P = kPhased>
 SR_HD void dft16_inv_q(u64 *x) {
     if constexpr (Q <= 3) dit_stage<1, (kW16Exp * 8) % 192, P>(x, std::make_integer_sequence<int, 8>{});
     if constexpr (Q <= 2) dit_stage<2, (kW16Exp * 4) % 192, P>(x, std::make_integer_sequence<int, 4>{});
@@ -649,17 +554,10 @@ __device__ __forceinline__ int pad(int pos) { return pos + (pos >> 4); }
 // ------------------------------------------------------------------------------------------------
 constexpr int brv5(int i) { return ((i & 1) << 4) | ((i & 2) << 2) | (i & 4) | ((i & 8) >> 2) | ((i & 16) >> 4); }
 constexpr int cols_tw_exp(int i) { return (39 * brv5(i)) % 192; }
-template <int U, int J>
-SR_HD void cols_bf_fwd(u64 *x) {
-    if constexpr ((J & (8 >> U)) == 0) bf_dit<cols_tw_exp((1 << U) + (J >> (4 - U))), true, (SR_GL_LAZY_DIT != 0)>(x[J], x[J + (8 >> U)]);
-}
-template <int U, int J>
-SR_HD void cols_bf_inv(u64 *x) {
-    if constexpr ((J & (8 >> U)) == 0) bf_dif<(192 - cols_tw_exp((1 << U) + (J >> (4 - U)))) % 192>(x[J], x[J + (8 >> U)]);
-}
-#if SR_GL_FUSED_BF == 2 && defined(__HIP_DEVICE_COMPILE__)
 // the merged negacyclic stages of pass A, phase by phase like the DFT_16 stages (dif_phased / dit_phased above): butterfly I of stage U
-// pairs slots (J, J + (8 >> U)) with J = (I / half) 2 half + I % half and carries the twiddle 2^cols_tw_exp(2^U + (J >> (4 - U)))
+// pairs slots (J, J + (8 >> U)) with J = (I / half) 2 half + I % half and carries the twiddle 2^cols_tw_exp(2^U + (J >> (4 - U))).
+// Forward: decimation in time with lazy legs (any representatives out: the W layer behind it is a general product); inverse:
+// Gentleman-Sande, canonical throughout (its inputs come out of a general product, its results leave the library).
 template <int U, bool INV>
 struct ColsStageOf {
     template <int I>
@@ -670,39 +568,15 @@ struct ColsStageOf {
         static constexpr int E = INV ? (192 - e) % 192 : e;
     };
 };
-template <int U, int... Js>
-SR_HD void cols_stage_fwd(u64 *x, std::integer_sequence<int, Js...>) {
-    dit_phased<ColsStageOf<U, false>::template Bf, (SR_GL_LAZY_DIT != 0)>(x, std::make_integer_sequence<int, 8>{});
+template <int U, int P = kPhased>
+SR_HD void cols_stage_fwd(u64 *x) {
+    stage_in_groups<ColsStageOf<U, false>::template Bf, true, 8, P, true>(x);
 }
-template <int U, int... Js>
-SR_HD void cols_stage_inv(u64 *x, std::integer_sequence<int, Js...>) {
-    dif_phased<ColsStageOf<U, true>::template Bf>(x, std::make_integer_sequence<int, 8>{});
+template <int U, int P = kPhased>
+SR_HD void cols_stage_inv(u64 *x) {
+    stage_in_groups<ColsStageOf<U, true>::template Bf, false, 8, P>(x);
 }
-#else
-template <int U, int... Js>
-SR_HD void cols_stage_fwd(u64 *x, std::integer_sequence<int, Js...>) {
-    (cols_bf_fwd<U, Js>(x), ...);
-}
-template <int U, int... Js>
-SR_HD void cols_stage_inv(u64 *x, std::integer_sequence<int, Js...>) {
-    (cols_bf_inv<U, Js>(x), ...);
-}
-#endif
 
-// SR_GL_TWIST_IN_ROWS = 1 (experiment, round 3): for D = 2^16 the inverse twist gamma_b^-i D^-1 is applied by rows256 to its results
-// instead of by the inverse column pass to its operands (whose 16 table loads then no longer sit in front of its first butterfly)
-// SR_GL_LAZY_TILE: the 4096-point rows kernels behind a column pass (D >= 2^13) take the lazy networks too
-// SR_GL_LAZY_CANON = 0 leaves out the canonicalisation of the product-free value in front of an inverse network: the build
-// tests/test_gpu_parity.py::test_goldilocks_inverse_with_lazy_sums_landing_on_p was checked to FAIL on (test of the test)
-#ifndef SR_GL_LAZY_CANON
-#define SR_GL_LAZY_CANON 1
-#endif
-#ifndef SR_GL_LAZY_TILE
-#define SR_GL_LAZY_TILE 1
-#endif
-#ifndef SR_GL_TWIST_IN_ROWS
-#define SR_GL_TWIST_IN_ROWS 0
-#endif
 // LC = log2 of the columns a workgroup owns: 16 << LC lanes, 256 legs x 2^LC consecutive columns (2^LC x 8-byte segments).
 // Wider segments stream better (tools/ubench/strided_pattern.hip: 4.7 / 5.1 / 6.1 TB/s for 16 / 32 / 64 columns) at the price of
 // fewer, larger workgroups.  LC = 4 pads the LDS tile (a 32-lane LDS group spans two legs); LC >= 5 needs no padding: every
@@ -711,26 +585,12 @@ template <int LC>
 struct ColsTile {
     static constexpr int C = 1 << LC;
     static constexpr int kLanes = 16 * C;
-#if defined(SR_COLS_SWIZZLE)
-    // LC = 4 without padding: 32 KiB per workgroup, five workgroups per CU.  The pass-B pattern (two leg groups 256 words apart
-    // in one 32-lane LDS group) is spread over both bank halves by flipping bit 4 of the position for odd leg groups; the
-    // pass-A pattern (256 consecutive words per instruction) sees a flip that is uniform per instruction.
-    static constexpr int kElems = 256 * C;
-    static __device__ __forceinline__ int idx(int leg, int col) {
-        const int pos = leg * C + col;
-        return LC == 4 ? pos ^ (((pos >> 8) & 1) << 4) : pos;
-    }
-#else
     static constexpr int kElems = LC == 4 ? kLdsElems : 256 * C;
     static __device__ __forceinline__ int idx(int leg, int col) {
         const int pos = leg * C + col;
         return LC == 4 ? pos + (pos >> 4) : pos;
     }
-#endif
 };
-#ifndef SR_COLS_WAVES
-#define SR_COLS_WAVES 4
-#endif
 // tile = position of the workgroup's tile in the launch: ring element tile >> (log2 N2 - LC), column chunk in the low bits
 template <int DIR, int LC>
 __device__ __forceinline__ void cols256_tile(const unsigned tile, u64 *data, const u64 *src, int k, const u64 *__restrict__ wc,
@@ -750,22 +610,17 @@ __device__ __forceinline__ void cols256_tile(const unsigned tile, u64 *data, con
     const unsigned leg = 8u << ls;                                      // bytes between consecutive legs
     const unsigned offA = (((unsigned)rg << ls) + i) * 8u;              // leg rg (+ 16 jj)
     const unsigned offB = (((unsigned)rg << (ls + 4)) + i) * 8u;        // leg 16 rg (+ sigma) = final block b
-    using seq16 = std::make_integer_sequence<int, 16>;
     u64 x[16];
 
     if (DIR == 0) {
-        prio_mem();
 #pragma unroll
         for (int jj = 0; jj < 16; jj++) x[jj] = ld_stream(reinterpret_cast<const u64 *>(ps + (offA + (unsigned)jj * 16u * leg)));
-        prio_alu();
-#ifndef SR_DIAG_COLS_NOCOMPUTE
-        cols_stage_fwd<0>(x, seq16{});
-        cols_stage_fwd<1>(x, seq16{});
-        cols_stage_fwd<2>(x, seq16{});
-        cols_stage_fwd<3>(x, seq16{});
+        cols_stage_fwd<0>(x);
+        cols_stage_fwd<1>(x);
+        cols_stage_fwd<2>(x);
+        cols_stage_fwd<3>(x);
 #pragma unroll
         for (int h = 0; h < 16; h++) x[h] = G::mul(x[h], wc[h * 16 + rg]);
-#endif
 #pragma unroll
         for (int h = 0; h < 16; h++) lds[CT::idx(16 * h + rg, col)] = x[h];  // leg 16 h + rg, column col
         __syncthreads();
@@ -774,32 +629,19 @@ __device__ __forceinline__ void cols256_tile(const unsigned tile, u64 *data, con
         for (int sg = 0; sg < 16; sg++) tw[sg] = *reinterpret_cast<const u64 *>(tb + (offB + (unsigned)sg * leg));
 #pragma unroll
         for (int j = 0; j < 16; j++) x[j] = lds[CT::idx(16 * rg + j, col)];  // block rg, leg j
-#ifndef SR_DIAG_COLS_NOCOMPUTE
         dft16_fwd_hot(x);
 #pragma unroll
         for (int sg = 0; sg < 16; sg++)
             st_scratch(reinterpret_cast<u64 *>(pb + (offB + (unsigned)sg * leg)), G::mul(x[sg], tw[sg]));
-#else
-#pragma unroll
-        for (int sg = 0; sg < 16; sg++) *reinterpret_cast<u64 *>(pb + (offB + (unsigned)sg * leg)) = x[sg] ^ tw[sg];
-#endif
     } else {
-        prio_mem();
-        if (SR_GL_TWIST_IN_ROWS && k == 16) {   // rows256 multiplied its results by gamma_b^-i D^-1 on the way out
+        u64 tw[16];
 #pragma unroll
-            for (int sg = 0; sg < 16; sg++) x[sg] = ld_scratch(reinterpret_cast<const u64 *>(ps + (offB + (unsigned)sg * leg)));
-            prio_alu();
-        } else {
-            u64 tw[16];
-#pragma unroll
-            for (int sg = 0; sg < 16; sg++) {
-                x[sg] = ld_scratch(reinterpret_cast<const u64 *>(ps + (offB + (unsigned)sg * leg)));
-                tw[sg] = *reinterpret_cast<const u64 *>(tb + (offB + (unsigned)sg * leg));
-            }
-            prio_alu();
-#pragma unroll
-            for (int sg = 0; sg < 16; sg++) x[sg] = G::mul(x[sg], tw[sg]);
+        for (int sg = 0; sg < 16; sg++) {
+            x[sg] = ld_scratch(reinterpret_cast<const u64 *>(ps + (offB + (unsigned)sg * leg)));
+            tw[sg] = *reinterpret_cast<const u64 *>(tb + (offB + (unsigned)sg * leg));
         }
+#pragma unroll
+        for (int sg = 0; sg < 16; sg++) x[sg] = G::mul(x[sg], tw[sg]);
         dft16_inv_hot(x);
 #pragma unroll
         for (int j = 0; j < 16; j++) lds[CT::idx(16 * rg + j, col)] = x[j];
@@ -808,27 +650,115 @@ __device__ __forceinline__ void cols256_tile(const unsigned tile, u64 *data, con
         for (int h = 0; h < 16; h++) x[h] = lds[CT::idx(16 * h + rg, col)];
 #pragma unroll
         for (int h = 0; h < 16; h++) x[h] = G::mul(x[h], wc[h * 16 + rg]);
-        cols_stage_inv<3>(x, seq16{});
-        cols_stage_inv<2>(x, seq16{});
-        cols_stage_inv<1>(x, seq16{});
-        cols_stage_inv<0>(x, seq16{});
+        cols_stage_inv<3>(x);
+        cols_stage_inv<2>(x);
+        cols_stage_inv<1>(x);
+        cols_stage_inv<0>(x);
 #pragma unroll
-        for (int jj = 0; jj < 16; jj++) st_stream(reinterpret_cast<u64 *>(pb + (offA + (unsigned)jj * 16u * leg)), x[jj]);
+        for (int jj = 0; jj < 16; jj++) st_result(reinterpret_cast<u64 *>(pb + (offA + (unsigned)jj * 16u * leg)), x[jj]);
     }
 }
 
-// 2^SR_COLS_XCD_GROUP consecutive tiles (column chunks of one ring element: 2 KiB of every leg at 16 columns) per XCD turn
-#ifndef SR_COLS_XCD_GROUP
-#define SR_COLS_XCD_GROUP 4
-#endif
+// 2^kColsXcdGroup consecutive tiles (column chunks of one ring element: 2 KiB of every leg at 16 columns) per XCD turn
+constexpr int kColsXcdGroup = 4;
 template <int DIR, int LC>
-__global__ __launch_bounds__(16 << LC, LC == 4 ? SR_COLS_WAVES : 4) void cols256_kernel(u64 *data, const u64 *src, int k,
-                                                                                       const u64 *__restrict__ wc,
-                                                                                       const u64 *__restrict__ twist,
-                                                                                       unsigned grouped) {
+__global__ __launch_bounds__(16 << LC, 4) void cols256_kernel(u64 *data, const u64 *src, int k, const u64 *__restrict__ wc,
+                                                              const u64 *__restrict__ twist, unsigned grouped) {
     __shared__ u64 lds[ColsTile<LC>::kElems];
-    stagger_first_round();
-    cols256_tile<DIR, LC>(xcd_tile(blockIdx.x, SR_COLS_XCD_GROUP, grouped), data, src, k, wc, twist, lds);
+    cols256_tile<DIR, LC>(xcd_tile(blockIdx.x, kColsXcdGroup, grouped), data, src, k, wc, twist, lds);
+}
+
+// ------------------------------------------------------------------------------------------------
+// cols256_keep: the same column pass for the SMALL launches of the two-lane plans (gl_fast_*_lanes: 64 MiB of coefficients per
+// launch, two streams).  A workgroup OWNS one column chunk ci and walks over the ring elements of the launch: the 16 twist factors a
+// lane needs depend on the column and the leg, not on the ring element, so they are loaded once per workgroup instead of once per
+// tile (one 8-byte L2 read per coefficient and pass otherwise: 26 GB per config-2 batch that no HBM counter shows), and the
+// 256-entry W table sits in 2 KiB of LDS.  Keeping tw[16] beside x[16] through BOTH register passes does not fit 128 VGPRs (the
+// round-4 harness: 4 waves per SIMD spill 48-84 bytes and lose 11 %), so the kernel runs THREE workgroups per CU at up to 168
+// VGPRs: alone on the chip that is slower than cols256_kernel (3.65 against 3.27 ms per config-2 batch: fewer waves to hide its
+// loads behind), beside the other lane's kernels it is faster -- 14.9-15.05 against 15.55 ms per batch in the harness
+// (tools/ubench/gl_bench.hip -DKEEP=8) -- so only the lane plans use it; the one-stream plan keeps cols256_kernel.
+// Workgroup -> (XCD, ci, group): blockIdx & 7 is the XCD the hardware gives the workgroup; inside an XCD slot = blockIdx >> 3 =
+// group * chunks + ci; the workgroup handles ring elements xcd + 8 (group + groups r), r = 0, 1, ...: all column chunks of a ring
+// element are in flight on ONE XCD at the same time (what xcd_tile() arranges for the plain launch).  Same values bit for bit
+// (tests/test_gpu_parity.py: test_keep_and_plain_column_passes_agree).  grid.x = 8 * (N2 / 16) * groups; npoly a multiple of 8.
+// ------------------------------------------------------------------------------------------------
+template <int DIR>
+__global__ __launch_bounds__(256, 3) void cols256_keep_kernel(u64 *data, const u64 *src, int k, const u64 *__restrict__ wc,
+                                                              const u64 *__restrict__ twist, unsigned npoly, unsigned groups) {
+    using CT = ColsTile<4>;
+    __shared__ u64 lds[CT::kElems];
+    __shared__ u64 wl[256];
+    const int t = threadIdx.x;
+    wl[t] = wc[t];
+    const int ls = k - 8;  // log2 N2
+    const unsigned chunks = 1u << (ls - 4);
+    const unsigned xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
+    const unsigned ci = slot & (chunks - 1u), grp = slot >> (ls - 4);
+    const int col = t & 15, rg = t >> 4;
+    const unsigned i = ci * 16u + (unsigned)col;
+    const char *tb = reinterpret_cast<const char *>(twist);
+    const unsigned leg = 8u << ls;
+    const unsigned offA0 = (((unsigned)rg << ls) + i) * 8u;          // leg rg (+ 16 jj)
+    const unsigned offB0 = (((unsigned)rg << (ls + 4)) + i) * 8u;    // leg 16 rg (+ sigma) = final block b
+    u64 x[16], tw[16];
+#pragma unroll
+    for (int sg = 0; sg < 16; sg++) tw[sg] = *reinterpret_cast<const u64 *>(tb + (offB0 + (unsigned)sg * leg));
+    __syncthreads();
+    for (unsigned poly = xcd + 8u * grp; poly < npoly; poly += 8u * groups) {  // uniform per workgroup: every lane reaches every barrier
+        char *pb = reinterpret_cast<char *>(data + ((size_t)poly << k));
+        const char *ps = reinterpret_cast<const char *>(src + ((size_t)poly << k));
+        // opaque per iteration: otherwise the 32 per-access offsets are hoisted out of the loop as invariants and live across it
+        unsigned offA = offA0, offB = offB0;
+        asm volatile("" : "+v"(offA), "+v"(offB));
+        if (DIR == 0) {
+#pragma unroll
+            for (int jj = 0; jj < 16; jj++) x[jj] = ld_stream(reinterpret_cast<const u64 *>(ps + (offA + (unsigned)jj * 16u * leg)));
+            cols_stage_fwd<0>(x);
+            cols_stage_fwd<1>(x);
+            cols_stage_fwd<2>(x);
+            cols_stage_fwd<3>(x);
+#pragma unroll
+            for (int h = 0; h < 16; h++) {
+                x[h] = G::mul(x[h], wl[h * 16 + rg]);
+                if ((h & 3) == 3) __builtin_amdgcn_sched_barrier(0);  // keeps the 16 table reads from all being hoisted in front
+            }
+#pragma unroll
+            for (int h = 0; h < 16; h++) lds[CT::idx(16 * h + rg, col)] = x[h];
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < 16; j++) x[j] = lds[CT::idx(16 * rg + j, col)];
+            dft16_fwd_hot(x);
+#pragma unroll
+            for (int sg = 0; sg < 16; sg++) st_scratch(reinterpret_cast<u64 *>(pb + (offB + (unsigned)sg * leg)), G::mul(x[sg], tw[sg]));
+        } else {
+#pragma unroll
+            for (int sg = 0; sg < 16; sg++) x[sg] = ld_scratch(reinterpret_cast<const u64 *>(ps + (offB + (unsigned)sg * leg)));
+#pragma unroll
+            for (int sg = 0; sg < 16; sg++) {
+                x[sg] = G::mul(x[sg], tw[sg]);
+                if ((sg & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+            }
+            dft16_inv_hot(x);
+#pragma unroll
+            for (int j = 0; j < 16; j++) lds[CT::idx(16 * rg + j, col)] = x[j];
+            __syncthreads();
+#pragma unroll
+            for (int h = 0; h < 16; h++) x[h] = lds[CT::idx(16 * h + rg, col)];
+#pragma unroll
+            for (int h = 0; h < 16; h++) {
+                x[h] = G::mul(x[h], wl[h * 16 + rg]);
+                if ((h & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+            }
+            cols_stage_inv<3>(x);
+            cols_stage_inv<2>(x);
+            cols_stage_inv<1>(x);
+            cols_stage_inv<0>(x);
+#pragma unroll
+            for (int jj = 0; jj < 16; jj++) st_result(reinterpret_cast<u64 *>(pb + (offA + (unsigned)jj * 16u * leg)), x[jj]);
+        }
+        __syncthreads();  // every lane has read the exchange before the next ring element's writes land
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -841,10 +771,10 @@ __global__ __launch_bounds__(16 << LC, LC == 4 ? SR_COLS_WAVES : 4) void cols256
 // CANON (plain forward transform): the slots leave the library as they are, so the last network runs canonical butterflies.
 // Twisted 4096-point blocks (TW = false, Q = 0) take the lazy DIT networks like the D = 2^16 kernels; whole-ring-element tiles and the
 // 512..2048-point blocks of D = 2^17..2^19 keep the DIF ones (their partial networks dft16_fwd_q start in the middle of a DFT_16).
-template <int Q, bool TW, int P = SR_GL_PHASE_GROUP, bool CANON = false>
+template <int Q, bool TW, int P = kPhased, bool CANON = false>
 __device__ __forceinline__ void tile_fwd(const u64 *__restrict__ src, u64 *lds, const int t, const Tables &T, u64 *x,
                                          int nvalid) {
-    constexpr bool LZ = !TW && Q == 0 && SR_GL_LAZY_DIT == 1 && SR_GL_LAZY_TILE;  // Q > 0: 512..2048-point blocks start inside a DFT_16
+    constexpr bool LZ = !TW && Q == 0;  // Q > 0: 512..2048-point blocks start inside a DFT_16
 #pragma unroll
     for (int j = 0; j < 16; j++) {
         const int pos = j * 256 + t;
@@ -879,10 +809,10 @@ __device__ __forceinline__ void tile_fwd(const u64 *__restrict__ src, u64 *lds, 
 
 // inverse of tile_fwd; x[] holds positions 16 t .. 16 t + 15 on entry.  w1i is the plain or the fused-product table.
 // Without TW the result is 4096 x the cyclic inverse and the strided inverse pass finishes the job.
-template <int Q, bool TW, int P = SR_GL_PHASE_GROUP>
+template <int Q, bool TW, int P = kPhased>
 __device__ __forceinline__ void tile_inv(u64 *x, u64 *lds, const int t, const Tables &T, const u64 *w1i,
                                          u64 *__restrict__ dst, int nvalid) {
-    constexpr bool LZ = !TW && Q == 0 && SR_GL_LAZY_DIT != 0 && SR_GL_LAZY_TILE;  // results go on to an inverse column pass that multiplies first
+    constexpr bool LZ = !TW && Q == 0;  // results go on to an inverse column pass that multiplies first
     dft16_inv<P, LZ>(x);
 #pragma unroll
     for (int j = 0; j < 16; j++) lds[17 * t + j] = x[j];
@@ -892,7 +822,7 @@ __device__ __forceinline__ void tile_inv(u64 *x, u64 *lds, const int t, const Ta
     for (int s = 0; s < 16; s++) x[s] = lds[pad(base2 + s * 16)];
 #pragma unroll
     for (int s = 1; s < 16; s++) x[s] = G::mul(x[s], T.w2i[s * 16 + i0]);
-    if (LZ && SR_GL_LAZY_CANON) x[0] = G::canon(x[0]);  // see tile256_inv
+    if (LZ) x[0] = G::canon(x[0]);  // see tile256_inv
     dft16_inv<P, LZ>(x);
 #pragma unroll
     for (int j = 0; j < 16; j++) lds[pad(base2 + j * 16)] = x[j];
@@ -902,7 +832,7 @@ __device__ __forceinline__ void tile_inv(u64 *x, u64 *lds, const int t, const Ta
     if (TW) x[0] = G::mul(x[0], w1i[t]);  // psi^-t * D^-1
 #pragma unroll
     for (int r = 1; r < 16; r++) x[r] = G::mul(x[r], w1i[r * 256 + t]);
-    if (LZ && SR_GL_LAZY_CANON) x[0] = G::canon(x[0]);
+    if (LZ) x[0] = G::canon(x[0]);
     if constexpr (LZ) dft16_inv<P, true>(x);
     else dft16_inv_q<Q, P>(x);
     if (TW) twist_rows<Q, true>(x, std::make_integer_sequence<int, 16>{});
@@ -910,21 +840,16 @@ __device__ __forceinline__ void tile_inv(u64 *x, u64 *lds, const int t, const Ta
     for (int j = 0; j < 16; j++) {
         const int pos = j * 256 + t;
         if (!TW) st_scratch(dst + pos, x[j]);  // goes on to the inverse column pass
-        else if (pos < nvalid) st_stream(dst + pos, x[j]);
+        else if (pos < nvalid) st_result(dst + pos, x[j]);
     }
 }
 
 // MODE 0: a -> crt(a) in place; 1: a -> icrt(a) in place; 2: out = icrt(crt(a) (.) crt(b)) tile by tile;
 // 3: out = icrt(crt(a) (.) b) with b already in CRT/NTT form (the constant-operand product: one transform fewer).
 // n_total = flat coefficient count of the batch (only consulted when TW: ragged last tile).
-#ifndef SR_ROWS_WAVES
-#define SR_ROWS_WAVES 4
-#endif
-#ifndef SR_ROWS_WAVES_TW
-#define SR_ROWS_WAVES_TW 3
-#endif
+// waves per SIMD: 4; whole-ring-element tiles 3 (2 / 3 / 4: 16.0 / 13.9 / 14.1 ms for the fused D = 4096 product, round 1)
 template <int MODE, int Q, bool TW>
-__global__ __launch_bounds__(256, TW ? SR_ROWS_WAVES_TW : SR_ROWS_WAVES) void rows_kernel(u64 *a, const u64 *b, u64 *out, Tables T, const u64 *w1i,
+__global__ __launch_bounds__(256, TW ? 3 : 4) void rows_kernel(u64 *a, const u64 *b, u64 *out, Tables T, const u64 *w1i,
                                                                    size_t n_total) {
     __shared__ u64 lds[kLdsElems];
     const int t = threadIdx.x;
@@ -933,7 +858,7 @@ __global__ __launch_bounds__(256, TW ? SR_ROWS_WAVES_TW : SR_ROWS_WAVES) void ro
     if (TW) nvalid = n_total - base < (size_t)kTile ? (int)(n_total - base) : kTile;
     // the fused products hold a's transformed tile in registers while b's runs: butterfly by butterfly there (no spills); the
     // stand-alone transforms take the phased stages
-    constexpr int P = MODE >= 2 ? (TW ? -1 : 0) : SR_GL_PHASE_GROUP;
+    constexpr int P = MODE >= 2 ? (TW ? -1 : 0) : kPhased;
     u64 A[16];
     if (MODE == 1) {
         // lane-contiguous global load, then an exchange into the 16-contiguous-per-lane layout of the first pass
@@ -955,7 +880,7 @@ __global__ __launch_bounds__(256, TW ? SR_ROWS_WAVES_TW : SR_ROWS_WAVES) void ro
 #pragma unroll
             for (int j = 0; j < 16; j++) {
                 const int pos = j * 256 + t;
-                if (!TW || pos < nvalid) a[base + pos] = lds[pad(pos)];
+                if (!TW || pos < nvalid) st_slots(a + base + pos, lds[pad(pos)]);
             }
             return;
         }
@@ -988,10 +913,8 @@ __global__ __launch_bounds__(256, TW ? SR_ROWS_WAVES_TW : SR_ROWS_WAVES) void ro
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void tile256_load(const u64 *__restrict__ src, const int t, u64 *x) {
     const int i0 = t & 15, base2 = (t >> 4) * 256 + i0;
-    prio_mem();
 #pragma unroll
     for (int j = 0; j < 16; j++) x[j] = ld_scratch(src + base2 + j * 16);
-    prio_alu();
 }
 // x holds the lane's 16 coefficients (tile256_load) on entry, its 16 consecutive NTT slots on return
 // CANON: the slots leave the library as they are (plain forward transform): the last network runs canonical butterflies
@@ -1013,9 +936,7 @@ __device__ __forceinline__ void tile256_fwd(const u64 *__restrict__ src, u64 *ld
     tile256_load(src, t, x);
     tile256_fwd_regs<CANON>(lds, t, T, x);
 }
-// twi: this tile's 4096 entries of the inverse twist table (SR_GL_TWIST_IN_ROWS), or unused
-__device__ __forceinline__ void tile256_inv(u64 *x, u64 *lds, const int t, const Tables &T, u64 *__restrict__ dst,
-                                            const u64 *__restrict__ twi) {
+__device__ __forceinline__ void tile256_inv(u64 *x, u64 *lds, const int t, const Tables &T, u64 *__restrict__ dst) {
     const int i0 = t & 15, base2 = (t >> 4) * 256 + i0;
     dft16_inv_hot(x);
 #pragma unroll
@@ -1027,25 +948,11 @@ __device__ __forceinline__ void tile256_inv(u64 *x, u64 *lds, const int t, const
     for (int s = 1; s < 16; s++) x[s] = G::mul(x[s], T.w2i[s * 16 + i0]);
     // x[0] skips the table product (its factor is 1) but is slot i0 of ANOTHER lane's network, a lazy representative: the twiddle-1
     // butterflies of the next network want it canonical
-    if (SR_GL_LAZY_DIT && SR_GL_LAZY_CANON) x[0] = G::canon(x[0]);
-#if SR_GL_TWIST_IN_ROWS
-    u64 tw[16];
-#pragma unroll
-    for (int j = 0; j < 16; j++) tw[j] = twi[base2 + j * 16];
-#endif
+    x[0] = G::canon(x[0]);
     dft16_inv_hot(x);
-#if SR_GL_TWIST_IN_ROWS
-#pragma unroll
-    for (int j = 0; j < 16; j++) x[j] = G::mul(x[j], tw[j]);
-#endif
 #pragma unroll
     for (int j = 0; j < 16; j++) st_scratch(dst + base2 + j * 16, x[j]);
 }
-// SR_ROWS256_PREFETCH_B = 1: the fused product requests b's tile together with a's (16 more registers in flight) instead of
-// after a's transform
-#ifndef SR_ROWS256_PREFETCH_B
-#define SR_ROWS256_PREFETCH_B 0
-#endif
 template <int MODE>
 __device__ __forceinline__ void rows256_tile(const unsigned tile, u64 *a, const u64 *b, u64 *out, const Tables &T, u64 *lds) {
     const int t = threadIdx.x;
@@ -1059,25 +966,16 @@ __device__ __forceinline__ void rows256_tile(const unsigned tile, u64 *a, const 
 #pragma unroll
         for (int j = 0; j < 16; j++) A[j] = lds[17 * t + j];  // own slots from here on: no barrier before tile256_inv's writes
     } else {
-#if SR_ROWS256_PREFETCH_B
-        u64 B[16];
-        tile256_load(a + base, t, A);
-        if (MODE == 2) tile256_load(b + base, t, B);  // both operands' loads in flight before the first butterfly
-        tile256_fwd_regs<MODE == 0>(lds, t, T, A);
-#else
         tile256_fwd<MODE == 0>(a + base, lds, t, T, A);
-#endif
         if (MODE == 0) {
 #pragma unroll
             for (int j = 0; j < 16; j++) lds[17 * t + j] = A[j];  // own slots
             __syncthreads();
 #pragma unroll
-            for (int j = 0; j < 16; j++) a[base + j * 256 + t] = lds[pad(j * 256 + t)];
+            for (int j = 0; j < 16; j++) st_slots(a + base + j * 256 + t, lds[pad(j * 256 + t)]);
             return;
         }
-#if !SR_ROWS256_PREFETCH_B
         u64 B[16];
-#endif
         __syncthreads();  // every lane has read a's exchange before b's lands
         if (MODE == 3) {  // b already in NTT order (see rows_kernel)
 #pragma unroll
@@ -1086,21 +984,16 @@ __device__ __forceinline__ void rows256_tile(const unsigned tile, u64 *a, const 
 #pragma unroll
             for (int j = 0; j < 16; j++) B[j] = lds[17 * t + j];
         } else {
-#if SR_ROWS256_PREFETCH_B
-            tile256_fwd_regs(lds, t, T, B);
-#else
             tile256_fwd(b + base, lds, t, T, B);
-#endif
         }
 #pragma unroll
         for (int j = 0; j < 16; j++) A[j] = G::mul(A[j], B[j]);
     }
-    tile256_inv(A, lds, t, T, out + base, (MODE == 1 ? T.twist_i_plain : T.twist_i_mul) + (size_t)(tile & 15u) * kTile);
+    tile256_inv(A, lds, t, T, out + base);
 }
 template <int MODE>
 __global__ __launch_bounds__(256, 4) void rows256_kernel(u64 *a, const u64 *b, u64 *out, Tables T) {
     __shared__ u64 lds[kLdsElems];
-    stagger_first_round();
     rows256_tile<MODE>(blockIdx.x, a, b, out, T, lds);
 }
 
@@ -1163,6 +1056,7 @@ struct GoldilocksFastTables {
     int k = -1;
     int c = 0;               // merged stages run by the column passes; the rows kernels see blocks of D >> c coefficients
     bool cols256 = false;    // c == 8 in one cols256 launch (2^16 <= D <= 2^20)
+    bool keep_cols = true;   // lane plans: cols256_keep_kernel (sr_plan flag SR_PLAN_GL_PLAIN_COLS clears it)
     bool ready = false;
     gl::Tables t{};
     size_t chunk_polys = 0;  // ring products: elements per chunk of launches (0 = as many as the scratch holds)
@@ -1276,23 +1170,32 @@ inline int gl_plan(int c, int *ms) {
 // columns per workgroup (2^LC): measured at D = 2^16, batch 2^14 (tools/ubench/gl_bench.hip): forward 3.86 / 3.75 / 4.38 ms and
 // inverse 4.26 / 4.39 / 5.07 ms for LC = 4 / 5 / 6 -- wider segments stream better (strided_pattern.hip) but one or two big
 // workgroups per CU overlap their load, exchange and store phases worse than four small ones.  With non-temporal coefficient
-// accesses (SR_GL_NT) LC = 4 runs 3.70 / 4.09 ms and LC = 5 3.73 / 4.21 ms: LC = 4 both ways.
-#ifndef SR_COLS_LC_FWD
-#define SR_COLS_LC_FWD 4
-#endif
-#ifndef SR_COLS_LC_INV
-#define SR_COLS_LC_INV 4
-#endif
+// accesses LC = 4 runs 3.70 / 4.09 ms and LC = 5 3.73 / 4.21 ms: LC = 4 both ways.
 template <int DIR>
 inline int gl_launch_cols256(const GoldilocksFastTables &f, uint64_t *data, const uint64_t *src, size_t npoly,
                              const uint64_t *wc, const uint64_t *twist, hipStream_t st) {
     GlProfScope ps(f, DIR == 0 ? 0 : 2, st);
-    constexpr int LC = DIR == 0 ? SR_COLS_LC_FWD : SR_COLS_LC_INV;
+    constexpr int LC = 4;
     const size_t blocks = npoly << (f.k - 8 - LC);  // N2 / 2^LC per ring element
     if (blocks == 0 || blocks > 0x7FFFFFFFull) return 1;
-    const unsigned grouped = xcd_grouped_tiles(blocks, SR_COLS_XCD_GROUP);
+    const unsigned grouped = xcd_grouped_tiles(blocks, gl::kColsXcdGroup);
     hipLaunchKernelGGL((gl::cols256_kernel<DIR, LC>), dim3((unsigned)blocks), dim3(16 << LC), 0, st, data, src, f.k, wc, twist,
                        grouped);
+    return hipGetLastError() != hipSuccess;
+}
+// the column pass of a LANE chunk: the workgroup-owns-its-columns kernel when the launch is a whole number of XCD rounds
+template <int DIR>
+inline int gl_launch_cols256_lane(const GoldilocksFastTables &f, uint64_t *data, const uint64_t *src, size_t npoly, const uint64_t *wc,
+                                  const uint64_t *twist, hipStream_t st) {
+    const unsigned chunks = 1u << (f.k - 12);                         // N2 / 16 column chunks per ring element
+    unsigned groups = chunks >= 128 ? 1u : 128u / chunks;             // 1024 workgroups per launch where the elements allow it
+    // worth it only when a workgroup walks over at least two ring elements (one element per workgroup is the plain kernel at three
+    // workgroups per CU: config 4's chunks of 8 elements lost 7 % that way)
+    if (!f.keep_cols || (npoly & 7u) != 0 || npoly < 16u || npoly > 0x7FFFFFFFull) return gl_launch_cols256<DIR>(f, data, src, npoly, wc, twist, st);
+    if (groups > npoly / 16) groups = (unsigned)(npoly / 16);
+    GlProfScope ps(f, DIR == 0 ? 0 : 2, st);
+    hipLaunchKernelGGL((gl::cols256_keep_kernel<DIR>), dim3(8u * chunks * groups), dim3(256), 0, st, data, src, f.k, wc, twist,
+                       (unsigned)npoly, groups);
     return hipGetLastError() != hipSuccess;
 }
 // forward column stages of npoly ring elements: src -> d (src == d: in place).  Only the first pass reads src.
@@ -1419,10 +1322,10 @@ inline int gl_fast_ring_mul_lanes(const GoldilocksFastTables &f, uint64_t *out, 
     for (size_t e = 0; e < batch && !rc; e += L.chunk, c++) {
         const int i = (int)(c % (size_t)L.n);
         const size_t n = batch - e < L.chunk ? batch - e : L.chunk;
-        rc = gl_launch_cols256<0>(f, L.sa[i], a + e * stride, n, f.t.wcf, f.t.twist_f, L.st[i]);
-        if (!rc) rc = gl_launch_cols256<0>(f, L.sb[i], b + e * stride, n, f.t.wcf, f.t.twist_f, L.st[i]);
+        rc = gl_launch_cols256_lane<0>(f, L.sa[i], a + e * stride, n, f.t.wcf, f.t.twist_f, L.st[i]);
+        if (!rc) rc = gl_launch_cols256_lane<0>(f, L.sb[i], b + e * stride, n, f.t.wcf, f.t.twist_f, L.st[i]);
         if (!rc) rc = gl_launch_rows<2>(f, L.sa[i], L.sb[i], L.sa[i], n, true, L.st[i]);
-        if (!rc) rc = gl_launch_cols256<1>(f, out + e * stride, L.sa[i], n, f.t.wci, f.t.twist_i_mul, L.st[i]);
+        if (!rc) rc = gl_launch_cols256_lane<1>(f, out + e * stride, L.sa[i], n, f.t.wci, f.t.twist_i_mul, L.st[i]);
     }
     for (int i = 0; i < L.n; i++) {  // join even after a failed launch: the caller's stream must not run ahead of the lanes
         if (hipEventRecord(L.join[i], L.st[i]) != hipSuccess) rc = 1;
@@ -1448,11 +1351,11 @@ inline int gl_fast_transform_lanes(const GoldilocksFastTables &f, uint64_t *d, c
         const size_t n = batch - e < L.chunk ? batch - e : L.chunk;
         uint64_t *dc = d + e * stride;
         if (DIR == 0) {
-            rc = gl_launch_cols256<0>(f, dc, dc, n, f.t.wcf, f.t.twist_f, L.st[i]);
+            rc = gl_launch_cols256_lane<0>(f, dc, dc, n, f.t.wcf, f.t.twist_f, L.st[i]);
             if (!rc) rc = gl_launch_rows<0>(f, dc, nullptr, dc, n, false, L.st[i]);
         } else {
             rc = gl_launch_rows<1>(f, dc, nullptr, dc, n, false, L.st[i]);
-            if (!rc) rc = gl_launch_cols256<1>(f, dc, dc, n, f.t.wci, f.t.twist_i_plain, L.st[i]);
+            if (!rc) rc = gl_launch_cols256_lane<1>(f, dc, dc, n, f.t.wci, f.t.twist_i_plain, L.st[i]);
         }
     }
     for (int i = 0; i < L.n; i++) {
@@ -1476,9 +1379,9 @@ inline int gl_fast_ring_mul_rhs_lanes(const GoldilocksFastTables &f, uint64_t *o
     for (size_t e = 0; e < batch && !rc; e += L.chunk, c++) {
         const int i = (int)(c % (size_t)L.n);
         const size_t n = batch - e < L.chunk ? batch - e : L.chunk;
-        rc = gl_launch_cols256<0>(f, L.sa[i], a + e * stride, n, f.t.wcf, f.t.twist_f, L.st[i]);
+        rc = gl_launch_cols256_lane<0>(f, L.sa[i], a + e * stride, n, f.t.wcf, f.t.twist_f, L.st[i]);
         if (!rc) rc = gl_launch_rows<3>(f, L.sa[i], b_ntt + e * stride, L.sa[i], n, true, L.st[i]);
-        if (!rc) rc = gl_launch_cols256<1>(f, out + e * stride, L.sa[i], n, f.t.wci, f.t.twist_i_mul, L.st[i]);
+        if (!rc) rc = gl_launch_cols256_lane<1>(f, out + e * stride, L.sa[i], n, f.t.wci, f.t.twist_i_mul, L.st[i]);
     }
     for (int i = 0; i < L.n; i++) {
         if (hipEventRecord(L.join[i], L.st[i]) != hipSuccess) rc = 1;

@@ -41,68 +41,26 @@ __device__ __forceinline__ int pad(int pos) { return pos + (pos >> 4); }
 struct Boundary {};
 struct Packed {};
 template <class F, class V> struct View;
-// Coefficient streams are read once and written once per launch: SR_RT_NT = 1 marks them non-temporal (the same hint took the
-// Goldilocks column passes from 3.90 to 3.75 ms; tables keep the default policy and stay in L2).
-#ifndef SR_RT_NT
-#define SR_RT_NT 1
-#endif
+// Boundary words are read once and written once per launch: non-temporal (the same hint took the Goldilocks column passes from
+// 3.90 to 3.75 ms; tables keep the default policy and stay in L2).
 template <class F> struct View<F, Boundary> {
     typedef typename F::storage T;
     static __device__ __forceinline__ typename F::elem ld(const T *p) {
-#if SR_RT_NT
         const T v = __builtin_nontemporal_load(p);
         return F::load(&v);
-#else
-        return F::load(p);
-#endif
     }
     static __device__ __forceinline__ void st(T *p, const typename F::elem &v) {
-#if SR_RT_NT
         T w;
         F::store(&w, v);
         __builtin_nontemporal_store(w, p);
-#else
-        F::store(p, v);
-#endif
     }
 };
 // The packed scratch holds a chunk's intermediates; without the hint they allocate in the Infinity Cache, which is what the two-lane
-// ring product wants (capi.hip: rt_ring_mul).  SR_RT_NT_SCRATCH = 1: non-temporal like the boundary words (A/B switch).
-#ifndef SR_RT_NT_SCRATCH
-#define SR_RT_NT_SCRATCH 0
-#endif
-typedef unsigned int rt_u32x2 __attribute__((ext_vector_type(2)));
+// ring product wants (capi.hip: rt_ring_mul).
 template <class F> struct View<F, Packed> {
     typedef typename F::elem T;
-    // two neighbouring 4-byte words as one 8-byte access (cols256x2_kernel)
-    static __device__ __forceinline__ rt_u32x2 ld2(const T *p) {
-#if SR_RT_NT_SCRATCH
-        return __builtin_nontemporal_load(reinterpret_cast<const rt_u32x2 *>(p));
-#else
-        return *reinterpret_cast<const rt_u32x2 *>(p);
-#endif
-    }
-    static __device__ __forceinline__ void st2(T *p, rt_u32x2 v) {
-#if SR_RT_NT_SCRATCH
-        __builtin_nontemporal_store(v, reinterpret_cast<rt_u32x2 *>(p));
-#else
-        *reinterpret_cast<rt_u32x2 *>(p) = v;
-#endif
-    }
-    static __device__ __forceinline__ typename F::elem ld(const T *p) {
-#if SR_RT_NT_SCRATCH
-        return __builtin_nontemporal_load(p);
-#else
-        return *p;
-#endif
-    }
-    static __device__ __forceinline__ void st(T *p, const typename F::elem &v) {
-#if SR_RT_NT_SCRATCH
-        __builtin_nontemporal_store(v, p);
-#else
-        *p = v;
-#endif
-    }
+    static __device__ __forceinline__ typename F::elem ld(const T *p) { return *p; }
+    static __device__ __forceinline__ void st(T *p, const typename F::elem &v) { *p = v; }
 };
 
 // Packed words at the BOUNDARY (the opt-in packed-u32 entry points, sr_*_packed32_*: the caller's operands and results are bare
@@ -111,34 +69,8 @@ template <class F> struct View<F, Packed> {
 struct PackedStream {};
 template <class F> struct View<F, PackedStream> {
     typedef typename F::elem T;
-    static __device__ __forceinline__ rt_u32x2 ld2(const T *p) {
-#if SR_RT_NT
-        return __builtin_nontemporal_load(reinterpret_cast<const rt_u32x2 *>(p));
-#else
-        return *reinterpret_cast<const rt_u32x2 *>(p);
-#endif
-    }
-    static __device__ __forceinline__ void st2(T *p, rt_u32x2 v) {
-#if SR_RT_NT
-        __builtin_nontemporal_store(v, reinterpret_cast<rt_u32x2 *>(p));
-#else
-        *reinterpret_cast<rt_u32x2 *>(p) = v;
-#endif
-    }
-    static __device__ __forceinline__ typename F::elem ld(const T *p) {
-#if SR_RT_NT
-        return __builtin_nontemporal_load(p);
-#else
-        return *p;
-#endif
-    }
-    static __device__ __forceinline__ void st(T *p, const typename F::elem &v) {
-#if SR_RT_NT
-        __builtin_nontemporal_store(v, p);
-#else
-        *p = v;
-#endif
-    }
+    static __device__ __forceinline__ typename F::elem ld(const T *p) { return __builtin_nontemporal_load(p); }
+    static __device__ __forceinline__ void st(T *p, const typename F::elem &v) { __builtin_nontemporal_store(v, p); }
 };
 
 // the 15 twiddles of four merged stages starting at global stage s0 for a lane working in block blk0 of stage s0:
@@ -228,8 +160,11 @@ __device__ __forceinline__ void inv16(typename F::elem *x, const typename F::ele
 
 // MODE 0: forward in place; 1: inverse in place; 2: out = icrt(crt(a) (.) crt(b)) for this tile
 // C0: D = 4096 (c = 0), the tile is a whole ring element and its last inverse pass contains global stage 0
+// waves per SIMD the kernels are compiled for: four; the fused product of a two-word field (Goldilocks on this path: the cross-check
+// plan SR_PLAN_GL_REGTILE) holds two 16-coefficient tiles of 8-byte words plus their twiddles and gets the registers of two
+constexpr int rows_waves(int elem_bytes, int mode) { return (mode == 2 && elem_bytes > 4) ? 2 : 4; }
 template <class F, int MODE, class VI, class VO, bool C0>
-__global__ __launch_bounds__(256, 4) void rows_kernel(const typename View<F, VI>::T *a, const typename View<F, VI>::T *b,
+__global__ __launch_bounds__(256, rows_waves(sizeof(typename F::elem), MODE)) void rows_kernel(const typename View<F, VI>::T *a, const typename View<F, VI>::T *b,
                                                       typename View<F, VO>::T *out, Params<F> p) {
     using E = typename F::elem;
     using In = View<F, VI>;
@@ -433,107 +368,15 @@ __global__ __launch_bounds__(16 * COLS) void cols256_kernel(const typename View<
     }
 }
 
-// The same pass when BOTH sides hold 4-byte words (the packed-u32 boundary, sr_*_packed32_*): a lane owns TWO neighbouring
-// columns, so a workgroup of 512 lanes covers 256 legs x 64 columns and every leg is touched in 256-byte segments with 8-byte
-// accesses per lane (128-byte segments and 4-byte accesses in cols256_kernel: the strided pattern streams better the longer its
-// segments are, tools/ubench/strided_pattern.hip).  One set of twiddles serves both columns.  64 KiB of LDS, two workgroups per CU.
-// Measured on the packed BabyBear workload (D = 2^16, batch 2^14, one stream): forward passes 2 x 1.77 ms against 2 x 1.68 ms for
-// cols256_kernel, inverse 1.85 against 1.77 ms -- two workgroups of eight waves per CU overlap their load, exchange and store phases
-// worse than four do (the same finding as the 32- and 64-column Goldilocks tiles), so it stays OFF;
-// SR_RT_COLS256X2 = 1 builds it in (A/B switch).
-#ifndef SR_RT_COLS256X2
-#define SR_RT_COLS256X2 0
-#endif
-template <class F, int DIR, class VI, class VO>
-__global__ __launch_bounds__(512) void cols256x2_kernel(const typename View<F, VI>::T *src, typename View<F, VO>::T *dst,
-                                                        Params<F> p, unsigned grouped) {
-    using E = typename F::elem;
-    static_assert(sizeof(E) == 4 && sizeof(typename View<F, VI>::T) == 4 && sizeof(typename View<F, VO>::T) == 4, "4-byte words on both sides");
-    __shared__ rt_u32x2 lds[256 * 32];  // [leg][lane column] pairs
-    const int t = threadIdx.x;
-    const int ls = p.k - 8;  // log2 N2
-    const unsigned tile = xcd_tile(blockIdx.x, kXcdGroup, grouped);
-    const unsigned ci = tile & ((1u << (ls - 6)) - 1u);
-    const size_t poly = tile >> (ls - 6);
-    const int lc = t & 31, rg = t >> 5;
-    const size_t off = (poly << p.k) + ci * 64u + (unsigned)(2 * lc);
-    E x[16], y[16], w[15];
-    if (DIR == 0) {
-#pragma unroll
-        for (int jj = 0; jj < 16; jj++) {
-            const rt_u32x2 v = View<F, VI>::ld2(src + off + ((size_t)(rg + 16 * jj) << ls));
-            x[jj] = v.x;
-            y[jj] = v.y;
-        }
-        load_tw16<F>(w, p.tw, 0, 0u);
-        fwd16<F>(x, w);
-        fwd16<F>(y, w);
-        load_tw16<F>(w, p.tw, 4, (unsigned)rg);
-#pragma unroll
-        for (int h = 0; h < 16; h++) {
-            rt_u32x2 v;
-            v.x = x[h];
-            v.y = y[h];
-            lds[(16 * h + rg) * 32 + lc] = v;
-        }
-        __syncthreads();
-#pragma unroll
-        for (int j = 0; j < 16; j++) {
-            const rt_u32x2 v = lds[(16 * rg + j) * 32 + lc];
-            x[j] = v.x;
-            y[j] = v.y;
-        }
-        fwd16<F>(x, w);
-        fwd16<F>(y, w);
-#pragma unroll
-        for (int j = 0; j < 16; j++) {
-            rt_u32x2 v;
-            v.x = x[j];
-            v.y = y[j];
-            View<F, VO>::st2(dst + off + ((size_t)(16 * rg + j) << ls), v);
-        }
-    } else {
-#pragma unroll
-        for (int j = 0; j < 16; j++) {
-            const rt_u32x2 v = View<F, VI>::ld2(src + off + ((size_t)(16 * rg + j) << ls));
-            x[j] = v.x;
-            y[j] = v.y;
-        }
-        load_tw16<F>(w, p.itw, 4, (unsigned)rg);
-        inv16<F, false>(x, w, p);
-        inv16<F, false>(y, w, p);
-        load_tw16<F>(w, p.itw, 0, 0u);
-#pragma unroll
-        for (int j = 0; j < 16; j++) {
-            rt_u32x2 v;
-            v.x = x[j];
-            v.y = y[j];
-            lds[(16 * rg + j) * 32 + lc] = v;
-        }
-        __syncthreads();
-#pragma unroll
-        for (int h = 0; h < 16; h++) {
-            const rt_u32x2 v = lds[(16 * h + rg) * 32 + lc];
-            x[h] = v.x;
-            y[h] = v.y;
-        }
-        inv16<F, true>(x, w, p);
-        inv16<F, true>(y, w, p);
-#pragma unroll
-        for (int jj = 0; jj < 16; jj++) {
-            rt_u32x2 v;
-            v.x = x[jj];
-            v.y = y[jj];
-            View<F, VO>::st2(dst + off + ((size_t)(rg + 16 * jj) << ls), v);
-        }
-    }
-}
+// (A variant of this pass for the packed-u32 boundary in which a lane owns two neighbouring columns -- 256-byte segments, 8-byte
+// accesses, 512-lane workgroups -- measured 2 x 1.77 / 1.85 ms against 2 x 1.68 / 1.77 ms for this kernel on the packed BabyBear
+// workload and is not kept: two workgroups of eight waves per CU overlap their load, exchange and store phases worse than four do.)
 
 // D = 2^16 behind cols256: a 4096-coefficient tile is 16 blocks of 256 coefficients that only need stages 8..15:
 // the last two register passes of rows_kernel (Params::c = k - 12 as usual, so the twiddle indices are the same),
 // one LDS exchange per transform.  Lane (rho, i0) starts in block rho of the tile.
 template <class F, int MODE, class VI, class VO>
-__global__ __launch_bounds__(256, 4) void rows256_kernel(const typename View<F, VI>::T *a, const typename View<F, VI>::T *b,
+__global__ __launch_bounds__(256, rows_waves(sizeof(typename F::elem), MODE)) void rows256_kernel(const typename View<F, VI>::T *a, const typename View<F, VI>::T *b,
                                                          typename View<F, VO>::T *out, Params<F> p) {
     using E = typename F::elem;
     using In = View<F, VI>;
@@ -549,31 +392,15 @@ __global__ __launch_bounds__(256, 4) void rows256_kernel(const typename View<F, 
     E x[16], y[16], w[15], wn[15];
     const unsigned blk2 = (tile_blk << 4) + (unsigned)(t >> 4), blk3 = (tile_blk << 8) + (unsigned)t;
 
-    // STAGED = send the tile through LDS so that global accesses are lane-contiguous instead of 64-byte segments (4-byte
-    // elements).  Measured on BabyBear D = 2^16: 11.1 ms against 4.8 ms for the direct form (the extra exchanges and the
-    // registers they hold cost more than the half-line accesses), so it stays off.
-    constexpr bool STAGED = false;
+    // (Sending the tile through LDS so that global accesses are lane-contiguous instead of 64-byte segments measured 11.1 ms against
+    // 4.8 ms on BabyBear D = 2^16: the extra exchanges and the registers they hold cost more than the half-line accesses.)
     if (MODE != 1) {
         load_tw16<F>(wn, p.tw, p.c + 4, blk2);
         load_tw16<F>(w, p.tw, p.c + 8, blk3);
-        if (STAGED) {
 #pragma unroll
-            for (int j = 0; j < 16; j++) {
-                la[pad(j * 256 + t)] = In::ld(a + base + j * 256 + t);
-                if (MODE == 2) lb[pad(j * 256 + t)] = In::ld(b + base + j * 256 + t);
-            }
-            __syncthreads();
-#pragma unroll
-            for (int j = 0; j < 16; j++) {
-                x[j] = la[pad(base2 + j * 16)];
-                if (MODE == 2) y[j] = lb[pad(base2 + j * 16)];
-            }
-        } else {
-#pragma unroll
-            for (int j = 0; j < 16; j++) {
-                x[j] = In::ld(a + base + base2 + j * 16);
-                if (MODE == 2) y[j] = In::ld(b + base + base2 + j * 16);
-            }
+        for (int j = 0; j < 16; j++) {
+            x[j] = In::ld(a + base + base2 + j * 16);
+            if (MODE == 2) y[j] = In::ld(b + base + base2 + j * 16);
         }
         fwd16<F>(x, wn);
         if (MODE == 2) fwd16<F>(y, wn);
@@ -617,16 +444,8 @@ __global__ __launch_bounds__(256, 4) void rows256_kernel(const typename View<F, 
 #pragma unroll
     for (int s = 0; s < 16; s++) x[s] = la[pad(base2 + s * 16)];
     inv16<F, false>(x, w, p);
-    if (STAGED) {
 #pragma unroll
-        for (int j = 0; j < 16; j++) la[pad(base2 + j * 16)] = x[j];  // the very slots this lane just read
-        __syncthreads();
-#pragma unroll
-        for (int j = 0; j < 16; j++) Out::st(out + base + j * 256 + t, la[pad(j * 256 + t)]);
-    } else {
-#pragma unroll
-        for (int j = 0; j < 16; j++) Out::st(out + base + base2 + j * 16, x[j]);
-    }
+    for (int j = 0; j < 16; j++) Out::st(out + base + base2 + j * 16, x[j]);
 }
 
 // ---- host-side launchers ---------------------------------------------------------------------------
@@ -681,14 +500,6 @@ inline bool use_cols256(const Params<F> &p) {
 template <class F, int DIR, class VI, class VO>
 inline int launch_cols256(const Hooks &hk, const typename View<F, VI>::T *src, typename View<F, VO>::T *dst, size_t npoly,
                           const Params<F> &p, hipStream_t st) {
-    if constexpr (SR_RT_COLS256X2 && sizeof(typename F::elem) == 4 && sizeof(typename View<F, VI>::T) == 4 && sizeof(typename View<F, VO>::T) == 4) {
-        const size_t blocks2 = (npoly << (p.k - 8)) / 64;  // two columns per lane, 64 per workgroup
-        if (blocks2 == 0 || blocks2 > 0x7FFFFFFFull) return 1;
-        Scope sc2(hk, DIR == 0 ? 0 : 2, st);
-        hipLaunchKernelGGL((cols256x2_kernel<F, DIR, VI, VO>), dim3((unsigned)blocks2), dim3(512), 0, st, src, dst, p,
-                           xcd_grouped_tiles(blocks2, kXcdGroup));
-        return hipGetLastError() != hipSuccess;
-    }
     constexpr int COLS = sizeof(typename F::elem) == 4 ? 32 : 16;
     const size_t blocks = (npoly << (p.k - 8)) / COLS;
     if (blocks == 0 || blocks > 0x7FFFFFFFull) return 1;

@@ -255,9 +255,7 @@ struct Tile {
     }
 };
 
-#ifndef SR_ST_WAVES
-#define SR_ST_WAVES 3  /* 512-tiles at D = 2^12, batch 2^12: 1.72 ms with 2 waves per SIMD, 1.64 with 3, 1.79 with 4 */
-#endif
+constexpr int kTileWaves = 3;  // waves per SIMD of the tiles up to 1024 points; 512-tiles at D = 2^12, batch 2^12: 1.72 / 1.64 / 1.79 ms with 2 / 3 / 4
 // D = 1024 tiles (256 lanes, 40 KB): 3 waves per SIMD without spills beat 4 with (1.84 against 1.96 ms per 2^24 coefficients);
 // D = 2048 (512 lanes, 80 KB) needs the 128-register budget for its second workgroup per CU (2.13 against 2.55 ms).
 constexpr int tiles_per_wg(int logt) { return logt >= 9 ? 1 : 256 >> (logt - 2); }
@@ -265,7 +263,7 @@ constexpr int tiles_per_wg(int logt) { return logt >= 9 ? 1 : 256 >> (logt - 2);
 // Lanes of a tile past the end (ragged last workgroup, TPW > 1) compute on zeros and store nothing: every lane reaches every
 // barrier.
 template <int LOGT, int MODE, bool WHOLE>
-__global__ __launch_bounds__((1 << (LOGT - 2)) * tiles_per_wg(LOGT), (LOGT <= 10 ? SR_ST_WAVES : 4)) void tile_kernel(S *a, const S *b, S *out,
+__global__ __launch_bounds__((1 << (LOGT - 2)) * tiles_per_wg(LOGT), (LOGT <= 10 ? kTileWaves : 4)) void tile_kernel(S *a, const S *b, S *out,
                                                                                                                    size_t n_tiles, P p) {
     constexpr int TPW = tiles_per_wg(LOGT);
     using T = Tile<LOGT, TPW>;

@@ -165,26 +165,12 @@ struct StarkL {
         return same;
     }
 
-    // a * w * 2^-280 mod p (see the header comment for the operand ranges).  One 64-bit accumulator runs through all eighteen
-    // columns; on the device the multiply-adds are single-instruction asm statements, because left to itself the compiler
-    // starts every column in a fresh accumulator and joins it to the running one with an extra 64-bit add (18 per product).
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(SR_ST_NO_ASM_MAD)
-    static __device__ __forceinline__ void mac_s(int64_t &acc, int32_t x, int32_t y) {
-        uint64_t cy;
-        asm("v_mad_i64_i32 %0, %1, %2, %3, %0" : "+v"(acc), "=s"(cy) : "v"(x), "v"(y));
-    }
-    static __device__ __forceinline__ void mac_u(int64_t &acc, uint32_t x, uint32_t y) {
-        uint64_t cy;
-        asm("v_mad_u64_u32 %0, %1, %2, %3, %0" : "+v"(acc), "=s"(cy) : "v"(x), "s"(y));
-    }
-#else
-    SR_HD static void mac_s(int64_t &acc, int32_t x, int32_t y) { acc += (int64_t)x * (int64_t)y; }
-    SR_HD static void mac_u(int64_t &acc, uint32_t x, uint32_t y) { acc = (int64_t)((uint64_t)acc + (uint64_t)x * y); }
-#endif
-    // Round 3, device build: ONE asm statement per column (generated: tools/gen_stark_mul_cols.py -> stark_mul_cols.inc).  As one
-    // statement per multiply-add the compiler padded nearly every one of them with a wait state it could not know to be unnecessary
-    // (112 s_nop per 174 VALU); the accumulator dependency is interlocked by the hardware.  SR_ST_NO_COLS_ASM: the former form.
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(SR_ST_NO_ASM_MAD) && !defined(SR_ST_NO_COLS_ASM)
+    // a * w * 2^-280 mod p (see the header comment for the operand ranges).  One 64-bit accumulator runs through all eighteen columns.
+    // Device build: ONE asm statement per column (generated: tools/gen_stark_mul_cols.py -> stark_mul_cols.inc).  Left to itself the
+    // compiler starts every column in a fresh accumulator and joins it to the running one with an extra 64-bit add (18 per
+    // product); as one statement per multiply-add it padded nearly every one of them with a wait state it could not know to be
+    // unnecessary (112 s_nop per 174 VALU) -- the accumulator dependency is interlocked by the hardware.
+#if defined(__HIP_DEVICE_COMPILE__)
     static __device__ __forceinline__ elem mul_tw(const elem &a, const elem &w) {
         const uint32_t c24 = 1u << 24, c27 = 1u << 27;
         int64_t acc = 0;
@@ -195,13 +181,10 @@ struct StarkL {
         return r;
     }
 #else
-    SR_HD static elem mul_tw(const elem &a, const elem &w) {
-        uint32_t c24 = 1u << 24, c27 = 1u << 27, c1 = 1u;
-#if defined(__HIP_DEVICE_COMPILE__)
-        asm("" : "+s"(c24));  // opaque scalars: m * 2^24 etc. stay one v_mad_u64_u32 instead of a 64-bit shift and a two-word add
-        asm("" : "+s"(c27));
-        asm("" : "+s"(c1));
-#endif
+    static void mac_s(int64_t &acc, int32_t x, int32_t y) { acc += (int64_t)x * (int64_t)y; }
+    static void mac_u(int64_t &acc, uint32_t x, uint32_t y) { acc = (int64_t)((uint64_t)acc + (uint64_t)x * y); }
+    static elem mul_tw(const elem &a, const elem &w) {
+        const uint32_t c24 = 1u << 24, c27 = 1u << 27, c1 = 1u;
         int64_t acc = 0;
         uint32_t m[10];
         elem r;

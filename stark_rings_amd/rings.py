@@ -162,6 +162,32 @@ class CyclotomicRing:
         self._check(self._lib.sr_sub_batch(self._ctx, _np_ptr(lhs), _np_ptr(rhs), self._batch_of(lhs.size)))
         return lhs
 
+    def _scalar(self, scalar):
+        """one base-field element as the library takes it: `limbs` u64 words, the Montgomery memory image of Fp::from(rhs)"""
+        s = np.ascontiguousarray(np.asarray(scalar, dtype=np.uint64).reshape(-1))
+        if s.size != self.limbs:
+            raise RingError("scalar must be %d u64 limb(s)" % self.limbs)
+        return s
+
+    def neg(self, data):
+        """Neg (coeff_form.rs:270-278, ntt_form.rs:191-203): data = -data word-wise, in place, either form."""
+        self._check(self._lib.sr_neg_batch(self._ctx, _np_ptr(data), self._batch_of(data.size)))
+        return data
+
+    def scale(self, data, scalar):
+        """Mul<Fp> / Mul<primitive> / MulAssign (coeff_form.rs:390-408, 610-650; ntt_form.rs:373-425): every coefficient (slot
+        component) times one base-field scalar given as its Montgomery image; in place, either form."""
+        s = self._scalar(scalar)
+        self._check(self._lib.sr_scale_batch(self._ctx, _np_ptr(data), _np_ptr(s), self._batch_of(data.size)))
+        return data
+
+    def add_scalar(self, data, scalar, ntt_form):
+        """Add<primitive> (coeff_form.rs:652-700: coefficient 0 of every element; ntt_form.rs:427-505: component 0 of every slot);
+        Sub: pass the negated scalar.  In place."""
+        s = self._scalar(scalar)
+        self._check(self._lib.sr_add_scalar_batch(self._ctx, _np_ptr(data), _np_ptr(s), 1 if ntt_form else 0, self._batch_of(data.size)))
+        return data
+
     def mul(self, a, b, out=None):
         """Coefficient-form product a * b (coeff_form.rs:250-258) via icrt(crt(a) * crt(b))."""
         if a.size != b.size:
@@ -473,6 +499,23 @@ class CyclotomicRing:
             raise RingError("operand lengths differ")
         self._check(self._lib.sr_sub_batch_dev(self._ctx, pl, pr, self._batch_of(n), self._stream(stream)))
         return lhs
+
+    def neg_dev(self, t, stream=None):
+        p, n = self._dev(t)
+        self._check(self._lib.sr_neg_batch_dev(self._ctx, p, self._batch_of(n), self._stream(stream)))
+        return t
+
+    def scale_dev(self, t, scalar, stream=None):
+        p, n = self._dev(t)
+        s = self._scalar(scalar)
+        self._check(self._lib.sr_scale_batch_dev(self._ctx, p, _np_ptr(s), self._batch_of(n), self._stream(stream)))
+        return t
+
+    def add_scalar_dev(self, t, scalar, ntt_form, stream=None):
+        p, n = self._dev(t)
+        s = self._scalar(scalar)
+        self._check(self._lib.sr_add_scalar_batch_dev(self._ctx, p, _np_ptr(s), 1 if ntt_form else 0, self._batch_of(n), self._stream(stream)))
+        return t
 
     def matvec_ntt_dev(self, y, m, v, nrows, ncols, stream=None):
         """y = M v for M (nrows x ncols ring elements, row-major) and v (ncols elements), all in CRT/NTT form:

@@ -55,6 +55,38 @@ def test_inline_asm_declares_scc_and_vcc_clobbers():
     assert _violations(fields.replace(': "scc");', ');'))[0]
 
 
+def _sgpr_outputs_without_early_clobber(text, path="<text>"):
+    """A multi-instruction statement whose SGPR output is written before its last "s" input is read must mark that output
+    early-clobber ("=&s"): otherwise the register allocator may hand the output the registers of such an input (ADVICE r3:
+    the generated Stark column statements write their carry pair in the first instruction and read 2^24 / 2^27 from SGPRs in
+    later ones).  Conservative rule: more than one instruction + any "s" input => every "=s" output needs the '&'."""
+    out = []
+    for stmt in asm_statements(text):
+        parts = stmt.split(":")
+        if len(parts) < 3:
+            continue
+        body = "".join(re.findall(r'"((?:[^"\\]|\\.)*)"', parts[0])).replace("\\n", "\n")
+        n_instr = len([ln for ln in body.split("\n") if ln.strip()])
+        if n_instr < 2:
+            continue
+        if re.search(r'"s"\s*\(', parts[2]) and re.search(r'"=s"\s*\(', parts[1]):
+            out.append("%s: SGPR output without early-clobber in a multi-instruction asm that reads SGPR inputs:\n%s" % (path, stmt))
+    return out
+
+
+def test_sgpr_outputs_of_multi_instruction_statements_are_early_clobber():
+    checked = 0
+    for path in glob.glob(os.path.join(ROOT, "stark_rings_amd", "csrc", "*")):
+        text = open(path).read()
+        bad = _sgpr_outputs_without_early_clobber(text, path)
+        assert not bad, "\n".join(bad)
+        checked += 1
+    assert checked >= 5
+    inc = open(os.path.join(ROOT, "stark_rings_amd", "csrc", "stark_mul_cols.inc")).read()
+    assert '"=&s"(cy)' in inc
+    assert _sgpr_outputs_without_early_clobber(inc.replace('"=&s"(cy)', '"=s"(cy)'))  # negative control
+
+
 def test_sgpr_carry_reaches_its_reader_after_two_wait_states(tmp_path):
     """Goldilocks::mul hands the middle carry from a v_mad_u64_u32 (SGPR-pair carry-out) to a v_subb_co_u32 (borrow-in) in ANOTHER
     asm statement; gfx950 wants 2 wait states between a VALU write of an SGPR and a VALU read of it, and the compiler's hazard

@@ -1,0 +1,41 @@
+"""The invariant-checking build (VERDICT r3 #1a).  The lazy butterflies of the tuned Goldilocks path leave 64-bit representatives
+that differ from the canonical value with probability 2^-32 per value on uniform data: a kernel that feeds such a representative to
+a butterfly that assumes canonical inputs is wrong, and no uniform-data parity test can see it (round 3 shipped one for 31 minutes).
+libstarkrings_hip_check.so is the product's own source compiled with -DSR_GL_CHECK_REPS: every canonical butterfly counts a
+non-canonical input, every lazy butterfly a second wrap or borrow, every result store a word >= p, while the real kernels run.
+The GPU test drives it, in a process of its own (SR_LIB_PATH), over uniform, edge, structured and crafted operands of every tuned
+plan and requires all counters to stay zero -- and a raw operand word >= p to be counted."""
+import ctypes
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CHECK_SO = os.path.join(ROOT, "stark_rings_amd", "libstarkrings_hip_check.so")
+
+
+def test_checking_build_exports_the_whole_abi_and_the_product_carries_no_checks():
+    from stark_rings_amd import _lib
+
+    assert os.path.exists(CHECK_SO), "build() did not produce the checking build"
+    syms = subprocess.run(["nm", "-D", "--defined-only", CHECK_SO], check=True, stdout=subprocess.PIPE).stdout.decode()
+    for name in _lib.SYMBOLS:
+        assert " T %s\n" % name in syms, "checking build lacks %s" % name
+    buf = (ctypes.c_uint64 * 8)()
+    rc = _lib.load().sr_selftest_rep_counters(buf, 0)   # the product library: no counters, no checks, and it says so
+    assert rc == 5 and "SR_GL_CHECK_REPS" in _lib.last_error()
+    src = open(os.path.join(ROOT, "stark_rings_amd", "csrc", "fields.hpp")).read()
+    assert "SR_GL_CHECK_REPS" in src and "atomicAdd(&g_counters" in src
+
+
+@pytest.mark.gpu
+def test_every_tuned_goldilocks_plan_keeps_its_representative_invariants():
+    env = dict(os.environ)
+    env["SR_LIB_PATH"] = CHECK_SO
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "rep_invariants_worker.py")], env=env, cwd=ROOT,
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=1500)
+    out = r.stdout.decode()
+    assert r.returncode == 0 and "rep_invariants: OK" in out, out[-4000:]
+    assert out.count(" clean") >= 11 and "negative control" in out, out[-4000:]

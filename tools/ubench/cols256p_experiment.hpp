@@ -21,7 +21,6 @@ __global__ __launch_bounds__(16 << LC, 4) void cols256p_kernel(u64 *data, int k,
     const int col = t & (C - 1), rg = t >> LC;
     const char *tb = reinterpret_cast<const char *>(twist);
     const unsigned leg = 8u << ls;
-    using seq16 = std::make_integer_sequence<int, 16>;
     u64 x[16], nx[16];
     unsigned tile = blockIdx.x;
     if (tile >= ntiles) return;
@@ -45,10 +44,10 @@ __global__ __launch_bounds__(16 << LC, 4) void cols256p_kernel(u64 *data, int k,
             const unsigned offB = (((unsigned)rg << (ls + 4)) + i) * 8u;
 #pragma unroll
             for (int jj = 0; jj < 16; jj++) x[jj] = nx[jj];
-            cols_stage_fwd<0>(x, seq16{});
-            cols_stage_fwd<1>(x, seq16{});
-            cols_stage_fwd<2>(x, seq16{});
-            cols_stage_fwd<3>(x, seq16{});
+            cols_stage_fwd<0>(x);
+            cols_stage_fwd<1>(x);
+            cols_stage_fwd<2>(x);
+            cols_stage_fwd<3>(x);
 #pragma unroll
             for (int h = 0; h < 16; h++) x[h] = G::mul(x[h], wl[h * 16 + rg]);
 #pragma unroll
@@ -111,10 +110,10 @@ __global__ __launch_bounds__(16 << LC, 4) void cols256p_kernel(u64 *data, int k,
             __syncthreads();
 #pragma unroll
             for (int h = 0; h < 16; h++) x[h] = G::mul(x[h], wl[h * 16 + rg]);
-            cols_stage_inv<3>(x, seq16{});
-            cols_stage_inv<2>(x, seq16{});
-            cols_stage_inv<1>(x, seq16{});
-            cols_stage_inv<0>(x, seq16{});
+            cols_stage_inv<3>(x);
+            cols_stage_inv<2>(x);
+            cols_stage_inv<1>(x);
+            cols_stage_inv<0>(x);
 #pragma unroll
             for (int jj = 0; jj < 16; jj++) *reinterpret_cast<u64 *>(pb + (offA + (unsigned)jj * 16u * leg)) = x[jj];
         }

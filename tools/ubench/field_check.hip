@@ -20,8 +20,8 @@ __global__ void knet(const uint64_t *x, uint64_t *o, int n) {
     uint64_t u[16], v[16], w[16];
     for (int j = 0; j < 16; j++) u[j] = v[j] = w[j] = x[16 * i + j];
     sr::gl::dft16_fwd(u);
-    sr::gl::dft16_fwd_dit<SR_GL_PHASE_GROUP, true>(v);
-    sr::gl::dft16_inv<SR_GL_PHASE_GROUP, true>(w);
+    sr::gl::dft16_fwd_dit<sr::gl::kPhased, true>(v);
+    sr::gl::dft16_inv<sr::gl::kPhased, true>(w);
     for (int j = 0; j < 16; j++) {
         o[48 * i + j] = u[j];
         o[48 * i + 16 + j] = v[j];
@@ -54,6 +54,28 @@ __global__ void k(const uint64_t *a, const uint64_t *b, uint64_t *o, int n, uint
     o[i * 6 + 4] = G::mul(a[i], cst);            // constant in SGPRs
     o[i * 6 + 5] = G::add(G::add(0ull, G::sub(a[i], b[i])), G::sub(G::sub(b[i], a[i]), G::add(a[i], 0ull)));  // carry-op chains
 }
+// round 4: everything a lazy representative can reach, on NON-canonical operands (any 64-bit word): the general product, the folds
+// behind it and every compile-time shift product.  Device against the host build AND against plain 128-bit integer arithmetic.
+__global__ void kraw(const uint64_t *a, const uint64_t *b, uint64_t *o, int n) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const unsigned long long bo = __ballot((b[i] >> 63) != 0);   // a lane mask, as the borrow of a carry chain is
+    o[4 * i + 0] = G::mul(a[i], b[i]);
+    o[4 * i + 1] = G::mad_eps_fix(a[i], (uint32_t)b[i]);
+    o[4 * i + 2] = G::fix_fold(a[i], bo, (uint32_t)b[i]);
+    o[4 * i + 3] = G::reduce128(a[i], b[i]);
+}
+template <int... Es>
+__global__ void kpow2(const uint64_t *a, uint64_t *o, int n, std::integer_sequence<int, Es...>) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    ((o[95 * (size_t)i + Es] = sr::gl::mul_pow2<Es + 1>(a[i])), ...);
+}
+template <int... Es>
+static void host_pow2(uint64_t x, uint64_t *o, std::integer_sequence<int, Es...>) {
+    ((o[Es] = sr::gl::mul_pow2<Es + 1>(x)), ...);
+}
+static uint64_t mulmod(uint64_t x, uint64_t y) { return (uint64_t)(((unsigned __int128)(x % G::P) * (y % G::P)) % G::P); }
 static uint64_t mix(uint64_t z) { z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; return z ^ (z >> 31); }
 int main() {
     const int n = 1 << 16;
@@ -130,6 +152,49 @@ int main() {
                 if (!(f0 && f1 && f2 && c0) && bad++ < 12) printf("MISMATCH network i=%d slot %d dif %d dit-lazy %d inv-lazy %d slot0-canonical %d\n", i, j, f0, f1, f2, c0);
             }
         }
+    }
+    {   // non-canonical operands: p, p + 1, 2^64 - 1, 2^64 - 2^32 ... and uniform 64-bit words
+        const uint64_t rv[] = {0, 1, G::P - 1, G::P, G::P + 1, G::P + 0xFFFFFFFEull, ~0ull, ~0ull - 1, 0xFFFFFFFF00000000ull, 0xFFFFFFFEFFFFFFFFull,
+                               0xFFFFFFFFull, 0x100000000ull, 1ull << 63, (1ull << 63) - 1, 0x8000000080000000ull, 0xFFFFFFFF80000000ull};
+        const int nr = 16, m = 1 << 14;
+        std::vector<uint64_t> ra(m), rb(m), ro(4 * (size_t)m), po(95 * (size_t)m);
+        for (int i = 0; i < m; i++) {
+            ra[i] = i < nr * nr ? rv[i / nr] : mix(i + 0xABC);   // any u64
+            rb[i] = i < nr * nr ? rv[i % nr] : mix(i + 0xDEF);
+        }
+        uint64_t *dp;
+        hipMalloc(&dp, 95 * (size_t)m * 8);
+        hipMemcpy(da, ra.data(), m * 8, hipMemcpyHostToDevice); hipMemcpy(db, rb.data(), m * 8, hipMemcpyHostToDevice);
+        hipLaunchKernelGGL(kraw, dim3(m / 256), dim3(256), 0, 0, da, db, dout, m);
+        hipMemcpy(ro.data(), dout, (size_t)m * 32, hipMemcpyDeviceToHost);
+        hipLaunchKernelGGL(kpow2, dim3(m / 256), dim3(256), 0, 0, da, dp, m, std::make_integer_sequence<int, 95>{});
+        hipMemcpy(po.data(), dp, 95 * (size_t)m * 8, hipMemcpyDeviceToHost);
+        const char *rn[] = {"mul(any, any)", "mad_eps_fix", "fix_fold", "reduce128"};
+        uint64_t two[96];
+        two[0] = 1;
+        for (int e = 1; e < 96; e++) two[e] = mulmod(two[e - 1], 2);
+        for (int i = 0; i < m; i++) {
+            const uint64_t x = ra[i], y = rb[i], hl = (uint32_t)y, bo = y >> 63;
+            const uint64_t rfix = bo ? x + G::P : x;                                     // wraps like the masked 64-bit add
+            const unsigned __int128 P = G::P;
+            const uint64_t host[4] = {G::mul(x, y), G::mad_eps_fix(x, (uint32_t)hl), G::fix_fold(x, bo, (uint32_t)hl), G::reduce128(x, y)};
+            const uint64_t want[4] = {mulmod(x, y), (uint64_t)(((unsigned __int128)x + (unsigned __int128)hl * G::EPS) % P),
+                                      (uint64_t)(((unsigned __int128)rfix + (unsigned __int128)hl * G::EPS) % P),
+                                      (uint64_t)((((unsigned __int128)y << 64) | x) % P)};
+            for (int j = 0; j < 4; j++)
+                if ((ro[4 * i + j] != host[j] || host[j] != want[j]) && bad++ < 12)
+                    printf("MISMATCH %s x=%016llx y=%016llx dev=%016llx host=%016llx integers=%016llx\n", rn[j], (unsigned long long)x, (unsigned long long)y,
+                           (unsigned long long)ro[4 * i + j], (unsigned long long)host[j], (unsigned long long)want[j]);
+            uint64_t hp[95];
+            host_pow2(x, hp, std::make_integer_sequence<int, 95>{});
+            for (int e = 1; e <= 95; e++) {
+                const uint64_t w = mulmod(x, two[e]);
+                if ((po[95 * (size_t)i + e - 1] != hp[e - 1] || hp[e - 1] != w) && bad++ < 12)
+                    printf("MISMATCH mul_pow2<%d> x=%016llx dev=%016llx host=%016llx integers=%016llx\n", e, (unsigned long long)x,
+                           (unsigned long long)po[95 * (size_t)i + e - 1], (unsigned long long)hp[e - 1], (unsigned long long)w);
+            }
+        }
+        printf("non-canonical operands: %d x (mul, mad_eps_fix, fix_fold, reduce128, 95 shift products) checked\n", m);
     }
     printf("field_check: %d mismatches\n", bad);
     return bad != 0;

@@ -12,6 +12,35 @@
 #if defined(MIXED) || defined(PIPE)
 #include "mixed256_experiment.hpp"
 #endif
+#ifdef KEEP
+#include "cols256_keep_experiment.hpp"
+// KEEP = ring-element groups per XCD and column chunk (8 = 1024 workgroups at D = 2^16: one round of resident workgroups)
+static inline unsigned keep_groups(size_t np) { size_t g = np / 8; if (g < 1) g = 1; if (g > KEEP) g = KEEP; return (unsigned)g; }
+#ifndef KEEP_DIRS
+#define KEEP_DIRS 3
+#endif
+#define KEEP_LAUNCH(DIRV, st_, buf, srcbuf, np, wcp, twp)                                                                                         \
+    do {                                                                                                                                          \
+        if ((KEEP_DIRS >> DIRV) & 1)                                                                                                              \
+            hipLaunchKernelGGL((cols256_keep_kernel<DIRV>), dim3(8u * (1u << (k - 12)) * keep_groups(np)), dim3(256), 0, st_, buf, srcbuf, k, wcp, \
+                               twp, (unsigned)(np), keep_groups(np));                                                                             \
+        else                                                                                                                                      \
+            hipLaunchKernelGGL((cols256_kernel<DIRV, 4>), dim3((unsigned)((np) << (k - 12))), dim3(256), 0, st_, buf, srcbuf, k, wcp, twp,         \
+                               sr::xcd_grouped_tiles((np) << (k - 12), sr::gl::kColsXcdGroup));                                                   \
+    } while (0)
+#endif
+#ifdef COLS_W3
+// the plain column pass at three workgroups per CU (168 VGPRs): separates "fewer, fatter waves" from "factors kept in registers"
+using namespace sr::gl;
+template <int DIR>
+__global__ __launch_bounds__(256, 3) void cols256_w3_kernel(u64 *data, const u64 *src, int k, const u64 *__restrict__ wc,
+                                                            const u64 *__restrict__ twist, unsigned grouped) {
+    __shared__ u64 lds[ColsTile<4>::kElems];
+    cols256_tile<DIR, 4>(sr::xcd_tile(blockIdx.x, kColsXcdGroup, grouped), data, src, k, wc, twist, lds);
+}
+#define KEEP_LAUNCH(DIRV, st_, buf, srcbuf, np, wcp, twp) hipLaunchKernelGGL((cols256_w3_kernel<DIRV>), dim3((unsigned)((np) << (k - 12))), dim3(256), 0, st_, buf, srcbuf, k, wcp, twp, sr::xcd_grouped_tiles((np) << (k - 12), sr::gl::kColsXcdGroup))
+#define KEEP 1
+#endif
 using namespace sr::gl;
 #ifdef PAIR
 // forward column passes of a and b as ONE launch (one tail and one launch gap fewer per chunk)
@@ -20,7 +49,7 @@ __global__ __launch_bounds__(256, 4) void cols256_pair_kernel(u64 *da, const u64
     __shared__ u64 lds[ColsTile<4>::kElems];
     const bool second = blockIdx.x >= tiles;
     const unsigned bid = second ? blockIdx.x - tiles : blockIdx.x;
-    cols256_tile<0, 4>(sr::xcd_tile(bid, SR_COLS_XCD_GROUP, grouped), second ? db : da, second ? sb_ : sa_, k, wc, twist, lds);
+    cols256_tile<0, 4>(sr::xcd_tile(bid, sr::gl::kColsXcdGroup, grouped), second ? db : da, second ? sb_ : sa_, k, wc, twist, lds);
 }
 #endif
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); return 1; } } while (0)
@@ -60,8 +89,10 @@ int main(int argc, char **argv) {
     const unsigned ntiles = cblocks;
     const unsigned pgrid = PERSIST * (LCV == 6 ? 1 : LCV == 5 ? 2 : 4);  // PERSIST = number of CUs to fill
 #define COLS(DIRV, buf, srcbuf, np, wcp, twp) hipLaunchKernelGGL((cols256p_kernel<DIRV, LCV>), dim3(pgrid < ntiles ? pgrid : ntiles), dim3(16 << LCV), 0, 0, buf, k, wcp, twp, ntiles)
+#elif defined(KEEP)
+#define COLS(DIRV, buf, srcbuf, np, wcp, twp) KEEP_LAUNCH(DIRV, 0, buf, srcbuf, np, wcp, twp)
 #else
-#define COLS(DIRV, buf, srcbuf, np, wcp, twp) hipLaunchKernelGGL((cols256_kernel<DIRV, LCV>), dim3((unsigned)((np) << (k - 8 - LCV))), dim3(16 << LCV), 0, 0, buf, srcbuf, k, wcp, twp, sr::xcd_grouped_tiles((np) << (k - 8 - LCV), SR_COLS_XCD_GROUP))
+#define COLS(DIRV, buf, srcbuf, np, wcp, twp) hipLaunchKernelGGL((cols256_kernel<DIRV, LCV>), dim3((unsigned)((np) << (k - 8 - LCV))), dim3(16 << LCV), 0, 0, buf, srcbuf, k, wcp, twp, sr::xcd_grouped_tiles((np) << (k - 8 - LCV), sr::gl::kColsXcdGroup))
 #endif
     double acc[4] = {0, 0, 0, 0};
 #ifdef INPLACE
@@ -98,7 +129,7 @@ int main(int argc, char **argv) {
             {
                 const unsigned tiles = (unsigned)(np << (k - 12));
                 hipLaunchKernelGGL(cols256_pair_kernel, dim3(2 * tiles), dim3(256), 0, 0, sa, ac, sb, bc, k, T.wcf, T.twist_f, tiles,
-                                   sr::xcd_grouped_tiles(tiles, SR_COLS_XCD_GROUP));
+                                   sr::xcd_grouped_tiles(tiles, sr::gl::kColsXcdGroup));
             }
 #else
             COLS(0, sa, ac, np, T.wcf, T.twist_f);
@@ -132,7 +163,7 @@ int main(int argc, char **argv) {
                 const size_t np = (c + 1) * ch <= npoly ? ch : npoly - c * ch;
                 u64 *ac = a + ((c * ch) << k), *bc = b + ((c * ch) << k);
                 const unsigned cb = (unsigned)(np << (k - 8 - LCV));
-                const unsigned grp = sr::xcd_grouped_tiles(cb, SR_COLS_XCD_GROUP);
+                const unsigned grp = sr::xcd_grouped_tiles(cb, sr::gl::kColsXcdGroup);
 #ifdef LIBFLOW  // the library's flow for a *= b: a's intermediates live in a itself, only b's go through the lane's scratch
                 u64 *ia = ac;
 #else
@@ -140,12 +171,20 @@ int main(int argc, char **argv) {
 #endif
 #ifdef PAIR
                 hipLaunchKernelGGL(cols256_pair_kernel, dim3(2 * cb), dim3(256), 0, st[si], ia, ac, ssb[si], bc, k, T.wcf, T.twist_f, cb, grp);
+#elif defined(KEEP)
+                (void)cb; (void)grp;
+                KEEP_LAUNCH(0, st[si], ia, ac, np, T.wcf, T.twist_f);
+                KEEP_LAUNCH(0, st[si], ssb[si], bc, np, T.wcf, T.twist_f);
 #else
                 hipLaunchKernelGGL((cols256_kernel<0, LCV>), dim3(cb), dim3(16 << LCV), 0, st[si], ia, ac, k, T.wcf, T.twist_f, grp);
                 hipLaunchKernelGGL((cols256_kernel<0, LCV>), dim3(cb), dim3(16 << LCV), 0, st[si], ssb[si], bc, k, T.wcf, T.twist_f, grp);
 #endif
                 hipLaunchKernelGGL((rows256_kernel<2>), dim3((unsigned)(np << (k - 12))), dim3(256), 0, st[si], ia, ssb[si], ia, T);
+#if defined(KEEP)
+                KEEP_LAUNCH(1, st[si], ac, ia, np, T.wci, T.twist_i_mul);
+#else
                 hipLaunchKernelGGL((cols256_kernel<1, LCV>), dim3(cb), dim3(16 << LCV), 0, st[si], ac, ia, k, T.wci, T.twist_i_mul, grp);
+#endif
             }
             CK(hipDeviceSynchronize());
             if (r >= 0) tot += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
