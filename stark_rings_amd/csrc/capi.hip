@@ -1412,7 +1412,7 @@ int sr_ctx_create_ex(int ring, int log2_degree, int device, const sr_plan *plan,
     if (!out) return fail(SR_E_INVALID, "null out pointer");
     *out = nullptr;
     if (plan) {
-        if (plan->flags >> 7) return fail(SR_E_INVALID, "sr_plan: unknown flag bits");
+        if (plan->flags >> 8) return fail(SR_E_INVALID, "sr_plan: unknown flag bits");
         if (plan->log_tile && (plan->log_tile < 8 || plan->log_tile > 12)) return fail(SR_E_INVALID, "sr_plan: log_tile must be 0 or 8..12");
         if (plan->stark_whole_max && (plan->stark_whole_max < 9 || plan->stark_whole_max > 12))
             return fail(SR_E_INVALID, "sr_plan: stark_whole_max must be 0 or 9..12");

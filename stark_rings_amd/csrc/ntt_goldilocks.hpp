@@ -665,7 +665,10 @@ template <int DIR, int LC>
 __global__ __launch_bounds__(16 << LC, 4) void cols256_kernel(u64 *data, const u64 *src, int k, const u64 *__restrict__ wc,
                                                               const u64 *__restrict__ twist, unsigned grouped) {
     __shared__ u64 lds[ColsTile<LC>::kElems];
-    cols256_tile<DIR, LC>(xcd_tile(blockIdx.x, kColsXcdGroup, grouped), data, src, k, wc, twist, lds);
+    __shared__ u64 wl[256];  // the W layer's table (16 of a lane's 48 global loads per tile)
+    if (threadIdx.x < 256) wl[threadIdx.x] = wc[threadIdx.x];
+    __syncthreads();
+    cols256_tile<DIR, LC>(xcd_tile(blockIdx.x, kColsXcdGroup, grouped), data, src, k, wl, twist, lds);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -673,11 +676,13 @@ __global__ __launch_bounds__(16 << LC, 4) void cols256_kernel(u64 *data, const u
 // launch, two streams).  A workgroup OWNS one column chunk ci and walks over the ring elements of the launch: the 16 twist factors a
 // lane needs depend on the column and the leg, not on the ring element, so they are loaded once per workgroup instead of once per
 // tile (one 8-byte L2 read per coefficient and pass otherwise: 26 GB per config-2 batch that no HBM counter shows), and the
-// 256-entry W table sits in 2 KiB of LDS.  Keeping tw[16] beside x[16] through BOTH register passes does not fit 128 VGPRs (the
-// round-4 harness: 4 waves per SIMD spill 48-84 bytes and lose 11 %), so the kernel runs THREE workgroups per CU at up to 168
-// VGPRs: alone on the chip that is slower than cols256_kernel (3.65 against 3.27 ms per config-2 batch: fewer waves to hide its
-// loads behind), beside the other lane's kernels it is faster -- 14.9-15.05 against 15.55 ms per batch in the harness
-// (tools/ubench/gl_bench.hip -DKEEP=8) -- so only the lane plans use it; the one-stream plan keeps cols256_kernel.
+// 256-entry W table sits in 2 KiB of LDS.  Compiled for four workgroups per CU (a 128-VGPR budget) the scheduler trades registers
+// for spills (48-84 bytes; the round-4 harness lost 11 %); compiled for THREE (__launch_bounds__(256, 3): up to 168) the allocator
+// ends at 120 / 126 VGPRs with nothing spilled -- which the hardware still packs four to a CU (tests/test_isa_budget.py holds it
+// there).  Alone on the chip the kernel is slower than cols256_kernel (3.65 against 3.27 ms per config-2 batch on one stream: one
+// more barrier per tile, no fresh workgroup overlapping the old one's tail); beside the other lane's kernels it is faster -- 14.9-15.05
+// against 15.55 ms per batch in the harness, 14.96-15.08 against 15.64-15.70 ms through the library (tools/bench_keep_cols.py,
+// DESIGN.md 6) -- so only the lane plans use it; the one-stream plan keeps cols256_kernel.
 // Workgroup -> (XCD, ci, group): blockIdx & 7 is the XCD the hardware gives the workgroup; inside an XCD slot = blockIdx >> 3 =
 // group * chunks + ci; the workgroup handles ring elements xcd + 8 (group + groups r), r = 0, 1, ...: all column chunks of a ring
 // element are in flight on ONE XCD at the same time (what xcd_tile() arranges for the plain launch).  Same values bit for bit
@@ -852,7 +857,13 @@ template <int MODE, int Q, bool TW>
 __global__ __launch_bounds__(256, TW ? 3 : 4) void rows_kernel(u64 *a, const u64 *b, u64 *out, Tables T, const u64 *w1i,
                                                                    size_t n_total) {
     __shared__ u64 lds[kLdsElems];
+    __shared__ u64 wl[512];  // the two 256-entry table layers w2f, w2i (as in rows256_kernel)
     const int t = threadIdx.x;
+    wl[t] = T.w2f[t];
+    wl[256 + t] = T.w2i[t];
+    __syncthreads();
+    T.w2f = wl;
+    T.w2i = wl + 256;
     const size_t base = (size_t)blockIdx.x * kTile;
     int nvalid = kTile;
     if (TW) nvalid = n_total - base < (size_t)kTile ? (int)(n_total - base) : kTile;
@@ -991,9 +1002,18 @@ __device__ __forceinline__ void rows256_tile(const unsigned tile, u64 *a, const 
     }
     tile256_inv(A, lds, t, T, out + base);
 }
+// The two 256-entry table layers (w2f, w2i: 45 of the fused product's 93 global loads per lane and tile, 24 GB of L2 reads per
+// config-2 batch) are copied into 4 KiB of LDS first: 38 KiB per workgroup, four still fit a CU; -0.9 % on the two-lane step
+// (harness, three alternations: 14.97 / 15.04 / 14.97 against 15.10 / 15.16 / 15.24 ms), 97 instead of 112 VGPRs.
 template <int MODE>
 __global__ __launch_bounds__(256, 4) void rows256_kernel(u64 *a, const u64 *b, u64 *out, Tables T) {
     __shared__ u64 lds[kLdsElems];
+    __shared__ u64 wl[512];
+    wl[threadIdx.x] = T.w2f[threadIdx.x];
+    wl[256 + threadIdx.x] = T.w2i[threadIdx.x];
+    __syncthreads();
+    T.w2f = wl;
+    T.w2i = wl + 256;
     rows256_tile<MODE>(blockIdx.x, a, b, out, T, lds);
 }
 
@@ -1191,7 +1211,10 @@ inline int gl_launch_cols256_lane(const GoldilocksFastTables &f, uint64_t *data,
     unsigned groups = chunks >= 128 ? 1u : 128u / chunks;             // 1024 workgroups per launch where the elements allow it
     // worth it only when a workgroup walks over at least two ring elements (one element per workgroup is the plain kernel at three
     // workgroups per CU: config 4's chunks of 8 elements lost 7 % that way)
-    if (!f.keep_cols || (npoly & 7u) != 0 || npoly < 16u || npoly > 0x7FFFFFFFull) return gl_launch_cols256<DIR>(f, data, src, npoly, wc, twist, st);
+    // D = 2^16 only: at 2^17 .. 2^19 (32 .. 128 column chunks per element, two elements per workgroup at the default lane chunks) the
+    // library-level A/B lost 3-4 % (tools/bench_keep_cols.py)
+    if (!f.keep_cols || f.k != 16 || (npoly & 7u) != 0 || npoly < 16u || npoly > 0x7FFFFFFFull)
+        return gl_launch_cols256<DIR>(f, data, src, npoly, wc, twist, st);
     if (groups > npoly / 16) groups = (unsigned)(npoly / 16);
     GlProfScope ps(f, DIR == 0 ? 0 : 2, st);
     hipLaunchKernelGGL((gl::cols256_keep_kernel<DIR>), dim3(8u * chunks * groups), dim3(256), 0, st, data, src, f.k, wc, twist,

@@ -1257,7 +1257,7 @@ def test_plan_struct_is_validated_and_env_free(torch_cuda):
     """sr_ctx_create_ex refuses malformed plans; the library exports no behaviour switch through the environment."""
     from stark_rings_amd import CyclotomicRing, RingError
 
-    for bad in (_plan(flags=1 << 7), _plan(log_tile=7), _plan(log_tile=13), _plan(stark_whole_max=8), _plan(lanes=3)):
+    for bad in (_plan(flags=1 << 8), _plan(log_tile=7), _plan(log_tile=13), _plan(stark_whole_max=8), _plan(lanes=3)):
         with pytest.raises(RingError):
             CyclotomicRing("goldilocks", 10, device=0, plan=bad)
     import glob

@@ -16,9 +16,13 @@ DEPS = [SRC] + [os.path.join(ROOT, "stark_rings_amd", "csrc", f) for f in ("fiel
 # kernel (mangled-name fragment) -> (max VALU instructions in the listing, max VGPRs)
 BUDGET = {
     "rows256_kernelILi2E": (2830, 128),        # fused product: two forward 256-point transforms, slot product, inverse
-    "rows256_kernelILi3E": (2060, 128),        # the same with the right operand already in NTT form
+    "rows256_kernelILi3E": (2080, 128),        # the same with the right operand already in NTT form
     "cols256_kernelILi0ELi4E": (1200, 128),    # forward column pass
     "cols256_kernelILi1ELi4E": (1235, 128),    # inverse column pass
+    # the lane plans' column passes (twist factors kept in registers): compiled for three workgroups per CU (up to 168 VGPRs), the
+    # allocator needs 120 / 126 -- within 128, so four still share a CU; compiled for four it spills
+    "cols256_keep_kernelILi0E": (1300, 128),
+    "cols256_keep_kernelILi1E": (1330, 128),
 }
 
 

@@ -110,14 +110,14 @@ def test_bench_single_rank_reports_the_plan_the_library_chose():
     import subprocess
 
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "SR_LANES")}
-    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--batch", "600", "--steps", "3", "--warmup", "1", "--parity-sample", "5",
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--batch", "1100", "--steps", "3", "--warmup", "1", "--parity-sample", "5",
            "--cpu-seconds", "0.5", "--calibrate"]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 1 and d["config"]["global_batch"] == 600
+    assert d["n_gpus"] == 1 and d["config"]["global_batch"] == 1100   # eight lane chunks and more: the probe runs
     assert "5 sampled elements per rank" in d["parity"]
     plan = d["config"]["plan"]
     assert plan.startswith("library default (sr_plan.lanes = 0, auto): ") and "its probe took" in plan

@@ -13,7 +13,7 @@
 #include "mixed256_experiment.hpp"
 #endif
 #ifdef KEEP
-#include "cols256_keep_experiment.hpp"
+// the lane plans' column pass (gl::cols256_keep_kernel, in the library since round 4) against the plain one
 // KEEP = ring-element groups per XCD and column chunk (8 = 1024 workgroups at D = 2^16: one round of resident workgroups)
 static inline unsigned keep_groups(size_t np) { size_t g = np / 8; if (g < 1) g = 1; if (g > KEEP) g = KEEP; return (unsigned)g; }
 #ifndef KEEP_DIRS
@@ -29,6 +29,7 @@ static inline unsigned keep_groups(size_t np) { size_t g = np / 8; if (g < 1) g 
                                sr::xcd_grouped_tiles((np) << (k - 12), sr::gl::kColsXcdGroup));                                                   \
     } while (0)
 #endif
+#define ROWS_KERNEL (rows256_kernel<2>)
 #ifdef COLS_W3
 // the plain column pass at three workgroups per CU (168 VGPRs): separates "fewer, fatter waves" from "factors kept in registers"
 using namespace sr::gl;
@@ -102,7 +103,7 @@ int main(int argc, char **argv) {
         CK(hipEventRecord(ev[1]));
         COLS(0, b, b, npoly, T.wcf, T.twist_f);
         CK(hipEventRecord(ev[2]));
-        hipLaunchKernelGGL((rows256_kernel<2>), dim3(blocks), dim3(256), 0, 0, a, b, a, T);
+        hipLaunchKernelGGL(ROWS_KERNEL, dim3(blocks), dim3(256), 0, 0, a, b, a, T);
         CK(hipEventRecord(ev[3]));
         COLS(1, a, a, npoly, T.wci, T.twist_i_mul);
         CK(hipEventRecord(ev[4]));
@@ -137,7 +138,7 @@ int main(int argc, char **argv) {
             COLS(0, sb, bc, np, T.wcf, T.twist_f);
 #endif
             CK(hipEventRecord(cev[c * 5 + 2]));
-            hipLaunchKernelGGL((rows256_kernel<2>), dim3((unsigned)(np << (k - 12))), dim3(256), 0, 0, sa, sb, sa, T);
+            hipLaunchKernelGGL(ROWS_KERNEL, dim3((unsigned)(np << (k - 12))), dim3(256), 0, 0, sa, sb, sa, T);
             CK(hipEventRecord(cev[c * 5 + 3]));
             COLS(1, ac, sa, np, T.wci, T.twist_i_mul);
             CK(hipEventRecord(cev[c * 5 + 4]));
@@ -179,7 +180,7 @@ int main(int argc, char **argv) {
                 hipLaunchKernelGGL((cols256_kernel<0, LCV>), dim3(cb), dim3(16 << LCV), 0, st[si], ia, ac, k, T.wcf, T.twist_f, grp);
                 hipLaunchKernelGGL((cols256_kernel<0, LCV>), dim3(cb), dim3(16 << LCV), 0, st[si], ssb[si], bc, k, T.wcf, T.twist_f, grp);
 #endif
-                hipLaunchKernelGGL((rows256_kernel<2>), dim3((unsigned)(np << (k - 12))), dim3(256), 0, st[si], ia, ssb[si], ia, T);
+                hipLaunchKernelGGL(ROWS_KERNEL, dim3((unsigned)(np << (k - 12))), dim3(256), 0, st[si], ia, ssb[si], ia, T);
 #if defined(KEEP)
                 KEEP_LAUNCH(1, st[si], ac, ia, np, T.wci, T.twist_i_mul);
 #else
