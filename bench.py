@@ -233,7 +233,7 @@ def main():
         plan_used = "sr_plan.lanes = %d given on the command line (A/B run)" % args.lanes
     elif probe:
         plan_used = ("library default (sr_plan.lanes = 0, auto): %s -- its probe took %.2f ms on two lanes against %.2f ms on one stream for %d ring products"
-                     " (steady state of each plan)" % ("two lanes" if lanes_now == 2 else "one stream", probe["two_lanes_ms"], probe["one_stream_ms"], probe["elems"]))
+                     " (each plan warmed up and run as it runs a batch)" % ("two lanes" if lanes_now == 2 else "one stream", probe["two_lanes_ms"], probe["one_stream_ms"], probe["elems"]))
     elif lanes_now == 0 and k > 12 and ring_name in ("goldilocks", "babybear"):
         plan_used = "library default (sr_plan.lanes = 0, auto): two lanes, unmeasured -- the batch is below the eight chunks the probe wants"
     else:

@@ -95,7 +95,7 @@ typedef struct sr_plan {
     uint64_t scratch_limit_bytes; /* cap of the operand scratch (0 = default 16 GiB); larger batches run in chunks             */
     uint32_t host_chunk_mb;       /* chunk of the host-pointer pipeline in MiB (0 = default 128)                               */
     uint32_t lanes;               /* chunked products (tuned Goldilocks 2^16 <= D <= 2^20, register-tiled BabyBear): 0 = AUTO -- the
-                                     library times the steady state of both plans once on this process's real stream-to-hardware-
+                                     library times both plans, warmed up and run as they will run, once on this process's real stream-to-hardware-
                                      queue mapping and keeps the faster.  The measurement runs ONLY inside sr_ctx_reserve_scratch
                                      (a blocking call anyway); a context whose host never reserves runs two lanes, unmeasured --
                                      no asynchronous _dev call ever probes, blocks on a measurement or breaks a stream capture;
@@ -111,9 +111,9 @@ int sr_ctx_create_ex(int ring, int log2_degree, int device, const sr_plan *plan,
 int sr_ctx_reserve_scratch(sr_ctx *ctx, size_t batch);
 /* The plan the context runs: *plan = the sr_plan it was created with, with lanes resolved to 1 or 2 once the library has settled it
  * (lanes stays 0 while sr_plan.lanes = 0 and sr_ctx_reserve_scratch has not run: such a context runs two lanes).  probe_ms
- * (optional): what the probe measured, [0] two lanes (steady state: twelve chunks with both lanes busy, scaled), [1] one stream,
- * milliseconds for probe_elems ring products (0 = not measured: the plan was given explicitly, the ring has no chunked product,
- * the batch reserved for is below eight chunks, or the probe's temporaries could not be allocated). */
+ * (optional): what the probe measured, [0] two lanes, [1] one stream: milliseconds per call of probe_elems ring products, each plan
+ * run as it will run (mean of four calls after four warm-up calls; 0 = not measured: the plan was given explicitly, the ring has no
+ * chunked product, the batch reserved for is below eight chunks, or the probe's temporaries could not be allocated). */
 int sr_ctx_plan_in_use(sr_ctx *ctx, sr_plan *plan, double probe_ms[2], size_t *probe_elems);
 int sr_ctx_destroy(sr_ctx *ctx);
 /* D, u64 limbs per coefficient, u64 words per ring element */

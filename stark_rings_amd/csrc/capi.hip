@@ -1202,10 +1202,11 @@ int dev_matvec(sr_ctx *c, uint64_t *y, const uint64_t *m, const uint64_t *v, siz
 // on one queue -- and then the one-stream plan is the faster one (20.4 against 17.9 ms per config-2 batch).  The library
 // therefore times both plans itself, once per context, on the context's real lanes, with a private non-blocking stream standing in
 // for the caller's, on device-generated uniform operands in temporary buffers.
-//   What is timed is the STEADY STATE of each plan (round 4; the round-3 probe timed 16 chunks once, whose first and last ran
-//   alone, and needed a 7 % fudge): after four warm-up calls, four calls back to back of n = up to 32 chunks.  Two lanes:
-//   t(n) - t(n / 4), the cost of 3/4 n with both lanes busy and no ramp, scaled to n; one stream: t(n), sets of launches back to
-//   back, which is how that plan runs a batch.  The faster plan wins, no margin.
+//   What is timed (round 4; the round-3 probe timed 16 chunks once, cold, and needed a 7 % fudge): each plan exactly as it will run,
+//   on n = up to 32 lane chunks -- after four warm-up calls, four calls back to back, the mean.  Two lanes: every call forks and
+//   joins like a real one (its last chunk runs alone on its lane: 1 / 32 of the call here, 1 / 128 of a config-2 batch -- the probe
+//   reads about 1 % against the lanes); one stream: sets of launches of the REAL batch's set size, back to back.  The faster plan
+//   wins, no margin.
 //   Where it runs: ONLY inside sr_ctx_reserve_scratch (a blocking call by contract: it allocates).  A context whose host never
 //   reserves runs two lanes, unmeasured -- an asynchronous _dev call never probes (it may be under stream capture, and its latency
 //   belongs to the caller).  sr_ctx_plan_in_use reports the outcome.
@@ -1224,11 +1225,10 @@ int lanes_autoselect(sr_ctx *c, size_t batch) {
     if (c->plan.lanes || c->lanes_choice || c->probing || !lanes_candidate(c, batch)) return SR_OK;
     const size_t chunk = lanes_chunk_of(c);
     if (batch < 8 * chunk) return SR_OK;  // too small for a steady state: two lanes, unmeasured (effective_lanes)
-    // up to 32 chunks per call (2 GiB per buffer), a quarter of them for the "head" call
+    // up to 32 chunks per call (2 GiB per buffer)
     size_t nch = batch / chunk;
     if (nch > 32) nch = 32;
-    nch &= ~(size_t)3;
-    const size_t n = nch * chunk, n_head = n / 4;
+    const size_t n = nch * chunk;
     const size_t elem = c->degree * c->limbs * 8, bytes = n * elem;
     void *buf[3] = {nullptr, nullptr, nullptr};
     hipEvent_t ev[2] = {nullptr, nullptr};
@@ -1239,7 +1239,7 @@ int lanes_autoselect(sr_ctx *c, size_t batch) {
     bool ok = hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess;
     for (auto &p : buf) ok = ok && hipMalloc(&p, bytes) == hipSuccess;
     for (auto &e : ev) ok = ok && hipEventCreate(&e) == hipSuccess;
-    double t2_full = 0, t2_head = 0, t1_set = 0;  // milliseconds per call, averaged over kCalls back-to-back calls
+    double t_plan[2] = {0, 0};  // milliseconds per call of n elements: [0] two lanes, [1] one stream
     constexpr int kWarm = 4, kCalls = 4;
     if (ok) {
         const size_t words = n * c->degree;
@@ -1250,13 +1250,13 @@ int lanes_autoselect(sr_ctx *c, size_t batch) {
             }
         };
         ok = fill(buf[1], 0x9E3779B97F4A7C15ull) == SR_OK && fill(buf[2], 0xD1B54A32D192ED03ull) == SR_OK;
-        // `calls` products of `elems` elements back to back; the clock the chip holds under this load settles within the warm-up
-        // (the step runs at the socket's power cap: a cold 2 ms sample reads 3-4 % fast)
-        auto timed = [&](size_t elems, int calls, double &per_call) {
+        // `calls` products of n elements back to back; the clock the chip holds under this load settles within the warm-up (the step
+        // runs at the socket's power cap: a cold 2 ms sample reads 3-4 % fast)
+        auto timed = [&](int calls, double &per_call) {
             float ms = 0;
             ok = ok && hipEventRecord(ev[0], st) == hipSuccess;
             for (int i = 0; i < calls; i++)
-                ok = ok && dev_ring_mul(c, (uint64_t *)buf[0], (const uint64_t *)buf[1], (const uint64_t *)buf[2], elems, st) == SR_OK;
+                ok = ok && dev_ring_mul(c, (uint64_t *)buf[0], (const uint64_t *)buf[1], (const uint64_t *)buf[2], n, st) == SR_OK;
             ok = ok && hipEventRecord(ev[1], st) == hipSuccess && hipEventSynchronize(ev[1]) == hipSuccess &&
                  hipEventElapsedTime(&ms, ev[0], ev[1]) == hipSuccess;
             if (ok) per_call = ms / calls;
@@ -1269,13 +1269,8 @@ int lanes_autoselect(sr_ctx *c, size_t batch) {
                 c->probe_chunk = real < n ? real : n;
             }
             double warm = 0;
-            timed(n, kWarm, warm);               // allocates the plan's scratch, warms the caches and settles the clock
-            if (plan == 0) {
-                timed(n, kCalls, t2_full);
-                timed(n_head, kCalls, t2_head);
-            } else {
-                timed(n, kCalls, t1_set);        // sets of launches back to back on one stream: exactly how the plan runs a batch
-            }
+            timed(kWarm, warm);  // allocates the plan's scratch, warms the caches and settles the clock
+            timed(kCalls, t_plan[plan]);
         }
         ok = ok && hipStreamSynchronize(st) == hipSuccess;
     }
@@ -1296,12 +1291,11 @@ int lanes_autoselect(sr_ctx *c, size_t batch) {
     c->probe_chunk = 0;
     c->probing = false;
     c->prof.on = prof_was;
-    if (ok && t2_full > t2_head && t2_head > 0 && t1_set > 0) {
-        // two lanes: the cost of the 3/4 n elements that a full call runs beyond a head call -- both lanes busy, no ramp -- scaled to n
-        c->lanes_probe_ms[0] = (t2_full - t2_head) * (4.0 / 3.0);
-        c->lanes_probe_ms[1] = t1_set;
+    if (ok && t_plan[0] > 0 && t_plan[1] > 0) {
+        c->lanes_probe_ms[0] = t_plan[0];
+        c->lanes_probe_ms[1] = t_plan[1];
         c->lanes_probe_elems = n;
-        c->lanes_choice = c->lanes_probe_ms[1] < c->lanes_probe_ms[0] ? 1 : 2;
+        c->lanes_choice = t_plan[1] < t_plan[0] ? 1 : 2;
     } else {
         // no memory for the probe's temporaries (or a launch failed: the real call will report that): keep the default, unmeasured
         (void)hipGetLastError();

@@ -102,6 +102,30 @@ def test_bench_launches_its_own_ranks_and_checks_every_shard():
 
 
 @pytest.mark.gpu
+def test_sharded_path_at_config_4_degree_every_shard_sampled():
+    """BASELINE config 4's degree (D = 2^20, 42 MB of tables to broadcast) through the sharded path before an 8-GPU
+    node ever runs it: `bench.py --gpus 2 --workload goldilocks_d1048576_b8192 --batch 16` launches its two ranks itself (children,
+    never a re-exec of a process that touched the GPU), rank 0 broadcasts the table block over gloo, each rank multiplies ITS 16
+    elements of degree 2^20 (two lane chunks of 8) and checks every one of them against the oracle."""
+    import json
+    import subprocess
+
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--workload", "goldilocks_d1048576_b8192",
+           "--batch", "16", "--steps", "2", "--warmup", "1", "--parity-sample", "16", "--cpu-seconds", "0.5"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 32 and "1048576" in d["config"]["workload"]
+    assert d["multi_gpu"]["ranks_seen"] == 2 and d["multi_gpu"]["data_path_collectives"] == 0
+    assert d["multi_gpu"]["twiddle_broadcast_bytes"] > 40 << 20
+    assert "16 sampled elements per rank (2 ranks)" in d["parity"]
+    assert d["value"] > 0
+
+
+@pytest.mark.gpu
 def test_bench_single_rank_reports_the_plan_the_library_chose():
     """`python bench.py` on a batch of several chunks: bench.py has no probe of its own -- the library settled the plan inside
     sr_ctx_reserve_scratch (sr_plan.lanes = 0) and config.plan quotes its measurement; the sampled elements are bit-exact against the
