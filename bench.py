@@ -27,7 +27,7 @@ import sys
 import time
 
 # The HIP runtime multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues (4 by default); PyTorch's stream, the context's two
-# streams (the lanes of the tuned ring product) and a timing stream need one each, or two of them serialise.
+# streams (the lanes of the tuned ring product) and a timing stream need one each, or two of them serialise (DESIGN_APPENDIX.md A.2).
 # A host setting for the runtime, made before anything initialises HIP; the library itself reads no environment variable.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
@@ -282,7 +282,7 @@ def main():
     torch.cuda.synchronize()
     prof = ring.profile_read()
     ring.profile_enable(False)
-    # The tuned Goldilocks product runs its chunks on two internal streams: the event-timed duration of a launch is
+    # The tuned Goldilocks product runs its chunks on two internal streams (DESIGN_APPENDIX.md A.2): the event-timed duration of a launch is
     # then time IN FLIGHT next to the other lane's kernels, not exclusive GPU time.  For a kernel-quality figure that can be compared
     # with earlier rounds the same steps are also profiled on a second context whose plan pins ONE stream (sr_plan.lanes = 1) --
     # a calibration outside the timed region, reported separately as roofline.single_stream, never as the headline.
@@ -436,7 +436,7 @@ def main():
                 valu = {"bound": "valu-issue", "achieved": rate, "peak": peak, "unit": "wave-instructions/s", "frac": rate / peak,
                         "valu_instructions_per_wave": kv["valu_per_wave"], "waves_per_launch": kv["waves_per_launch"],
                         "note": "supplementary, replayed like roofline.traffic: one wave-instruction per 4 cycles per SIMD at the nominal 2.4 GHz as the "
-                                "peak; under this integer-dense kernel the chip holds about 2.0 GHz (profiles/r02/clock_*.txt, DESIGN.md 6.0)"}
+                                "peak; under this integer-dense kernel the chip holds about 2.0 GHz (profiles/r02/clock_*.txt, DESIGN_APPENDIX.md A.2)"}
     except (OSError, ValueError, KeyError, IndexError, NameError):
         pass
 

@@ -1378,7 +1378,9 @@ inline int gl_fast_transform_lanes(const GoldilocksFastTables &f, uint64_t *d, c
             if (!rc) rc = gl_launch_rows<0>(f, dc, nullptr, dc, n, false, L.st[i]);
         } else {
             rc = gl_launch_rows<1>(f, dc, nullptr, dc, n, false, L.st[i]);
-            if (!rc) rc = gl_launch_cols256_lane<1>(f, dc, dc, n, f.t.wci, f.t.twist_i_plain, L.st[i]);
+            // the plain inverse pass here: behind the light rows256_kernel<1> of a stand-alone icrt the workgroup-owns-its-columns
+            // kernel lost 2.4 % (6.06-6.13 against 5.94-5.95 ms per config-2 batch); the forward one above gains 1.2 %
+            if (!rc) rc = gl_launch_cols256<1>(f, dc, dc, n, f.t.wci, f.t.twist_i_plain, L.st[i]);
         }
     }
     for (int i = 0; i < L.n; i++) {

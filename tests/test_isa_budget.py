@@ -1,5 +1,5 @@
 """Static budget of the headline kernels (no GPU): hipcc -S of tools/ubench/gl_isa.hip (the Goldilocks D = 2^16 kernels alone) and
-a count of what the listing holds.  The step is bound by VALU issue / energy (DESIGN.md 6.0), so an instruction that creeps back in,
+a count of what the listing holds.  The step is bound by VALU issue / energy (DESIGN.md 6.2), so an instruction that creeps back in,
 a spill or a scratch allocation is a performance regression the parity tests cannot see."""
 import os
 import re

@@ -84,7 +84,7 @@ def tag_of(kernel):
     k = kernel.replace("void ", "")
     if "build" in k or "fill_uniform" in k or "count_noncanonical" in k or "addsub" in k or "__amd" in k:
         return None
-    m = re.match(r"sr::gl::cols256_kernel<(\d)", k) or re.match(r"sr::gl::strided\w*_kernel<(?:\d+, )?(\d)", k)
+    m = re.match(r"sr::gl::cols256(?:_keep)?_kernel<(\d)", k) or re.match(r"sr::gl::strided\w*_kernel<(?:\d+, )?(\d)", k)
     if m:
         return "fwd_cols" if m.group(1) == "0" else "inv_cols"
     m = re.match(r"sr::rt::(?:cols256|strided)_kernel<sr::\w+, (?:\d+, )?(\d)", k)
@@ -258,23 +258,9 @@ def readme(outdir):
         if os.path.exists(sp):
             md.append(open(sp).read())
     md.append("## other files\n")
-    md.append("* `kernel_stats_goldilocks_d65536_b16384_one_stream.csv`, `bench_one_stream_under_trace.json` -- the headline workload with `sr_plan.lanes = 1`")
-    md.append("  (one stream, eight large chunks) under `rocprofv3 --kernel-trace --stats`: the kernels' exclusive durations (tools/collect_profiles.sh).")
-    md.append("* raw CSVs are cut to their first 4000 rows (the two-lane plans launch hundreds of chunk kernels per step); summaries were computed on the GPU box from the complete files.")
-    md.append("* `bench_default.json` -- plain `python bench.py --steps 10 --warmup 3` (with the CPU baseline leg; the plan is the library's own choice, quoted in `config.plan`);")
-    md.append("  `bench_one_stream.json` -- `--lanes 1`; `bench_ntt_rhs.json` -- `--variant mul_ntt_rhs`; `bench_force_dist.json` -- `--force-dist` (one-rank `nccl` group: the RCCL path on one GPU);")
-    md.append("  `bench_babybear.json`, `bench_babybear_packed.json` (the opt-in packed-u32 boundary), `bench_stark.json`, `bench_c4_shard.json`, `bench_config0.json` (BASELINE configs[0]: D = 2^10, batch 1) -- the other")
-    md.append("  BASELINE configs; `bench_2rank_gloo.json`, `bench_4rank_gloo.json` -- `python bench.py --gpus 2 --backend gloo --batch 4096` / `--gpus 4 ... --batch 2048` (bench.py launching its own ranks on the one GPU of the box: a rehearsal of the sharding and of the rank bookkeeping, not a scaling figure).")
-    md.append("* `bench_under_trace_<workload>.json`, `bench_under_pmc_SQ_<workload>.json` -- bench.py's own lines from inside the profiler runs (plan pinned with `--lanes` to what the library chose in a plain run).")
-    md.append("* `arith_variants.txt` -- tools/ubench/arith_variants.hip: the current arithmetic against radix-64 passes and 24-bit limbs modulo 2^96 + 1, register-only (DESIGN.md 6.0);")
-    md.append("  `stark_f64_product.txt` -- tools/ubench/stark_f64_product.hip: product part of a 260-bit multiplication on doubles against the nine-limb integer form; `stark_lazy_check.txt` -- device against host build of `StarkL::mul_tw`;")
-    md.append("  `experiments_gl_bench.txt` -- tools/ubench/gl_bench.hip A/B runs of the butterfly scheduling variants; `bench_babybear_packed_sweep.jsonl`, `bench_stark_cols_ab.jsonl` -- chunk sweep / `cols256x2_kernel` and the per-column Stark product, same-box A/B.")
-    md.append("* `ab_lazy_dit.txt`, `ab_mul_lohi.txt`, `ab_twist_in_rows.txt`, `ab_chunks_and_streams.txt` -- same-box alternations of tools/ubench/gl_bench.hip builds (`-DSR_GL_LAZY_DIT=0/1/2`, `-DSR_GL_MUL_LOHI=1`, `-DSR_GL_TWIST_IN_ROWS=1`), DESIGN.md 6.0;")
-    md.append("  `pmc_icache_waits.txt` -- `SQC_ICACHE_*`, `SQ_WAVE_CYCLES`, `SQ_WAIT_INST_ANY`, `SQ_ACTIVE_INST_VALU` per kernel of the headline workload (tools/pmc_by_kernel.py).")
-    md.append("* `power_goldilocks_d65536_b16384.txt` (+ the two raw rocm-smi sample files) -- socket power, sclk and joules per batch of the headline workload, two lanes and one stream (tools/power_trace.sh).")
-    md.append("* `bench_matvec.txt` (mat-vec and mat-mat, incl. the three reference rings as integer sums), `bench_small_rings.txt`, `bench_transforms.txt`, `bench_host_boundary.txt` (caller pages registered against pageable) -- the tools/bench_*.py scripts.")
-    md.append("* `full_parity_extra.txt` -- every word of products and transforms at Goldilocks degrees 2^10 ... 2^20 outside the suite's BASELINE shapes (tools/fuzz_full_parity.py); `fuzz_random.txt` -- 500 s of random ring / degree / batch / operation against the oracle.")
-    md.append("* `gpu_tests.log` -- `python -m pytest tests -m gpu -x -q` at the final tree: 326 passed, 2 min 47 s.")
+    other = os.path.join(outdir, "OTHER_FILES.md")   # written by hand per round: what the remaining files of the directory are
+    if os.path.exists(other):
+        md.append(open(other).read())
     open(os.path.join(outdir, "README.md"), "w").write("\n".join(md) + "\n")
     print("\n".join(md[:22]))
 

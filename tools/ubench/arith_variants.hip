@@ -1,5 +1,5 @@
 // Register-only micro-benchmark of the two formulations VERDICT r2 asked to be BUILT and timed next to the current arithmetic
-// (DESIGN.md 6.0, round 3): the same sixteen radix-2 stages of one transform's worth of butterflies and table products per
+// (DESIGN_APPENDIX.md A.3, round 3): the same sixteen radix-2 stages of one transform's worth of butterflies and table products per
 // coefficient, with every memory access taken out (operands live in registers for `reps` rounds; table words come from an
 // L2-resident array like the real twiddles), so that only the instruction streams and their register footprints differ.
 //

@@ -1,4 +1,4 @@
-// Round-2 experiment, NOT part of the library (measured slower): a persistent, register-prefetching form of
+// Round-2 experiment, NOT part of the library (measured slower, see DESIGN_APPENDIX.md A.2): a persistent, register-prefetching form of
 // gl::cols256_kernel.  Included by gl_bench.hip when built with -DPERSIST=<CUs>.
 #pragma once
 namespace sr {

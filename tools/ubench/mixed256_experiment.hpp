@@ -1,4 +1,4 @@
-// Round-2 experiment, NOT part of the library (measured: no gain): one launch whose workgroups take four roles
+// Round-2 experiment, NOT part of the library (measured: no gain, DESIGN_APPENDIX.md A.2): one launch whose workgroups take four roles
 // (forward column tiles of a and b, fused rows tiles, inverse column tiles), alone and as a software pipeline over chunks of the batch.
 // Included by gl_bench.hip when built with -DMIXED or -DPIPE.
 #pragma once
