@@ -1104,9 +1104,11 @@ int neg_dev(sr_ctx *c, uint64_t *d, size_t n_words, hipStream_t st) {
 }
 template <class F>
 int load_scalar(const uint64_t *scalar, typename F::storage *out) {
-    typename F::storage s;
+    typename F::storage s, back;
     memcpy(&s, scalar, sizeof(s));
-    if (!F::valid(F::load(&s))) return fail(SR_E_INVALID, "scalar is not a canonical Montgomery image (>= p)");
+    const typename F::elem e = F::load(&s);
+    F::store(&back, e);  // a BabyBear limb with bits above the low word is no field element's image either
+    if (!F::valid(e) || memcmp(&back, &s, sizeof(s)) != 0) return fail(SR_E_INVALID, "scalar is not a canonical Montgomery image (>= p)");
     *out = s;
     return SR_OK;
 }

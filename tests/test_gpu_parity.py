@@ -2154,6 +2154,9 @@ def test_neg_scale_and_add_scalar_match_integer_arithmetic(torch_cuda, name, k):
         ring.scale(a.copy(), bad)
     with pytest.raises(Exception, match="limb"):
         ring.scale(a.copy(), np.zeros(L + 1, dtype=np.uint64))
+    if base == "babybear":   # bits above the 31-bit residue: not an Fp64 image of a BabyBear element
+        with pytest.raises(Exception, match="canonical"):
+            ring.scale(a.copy(), np.array([(1 << 32) + 5], dtype=np.uint64))
 
 
 # ----------------------------------------------------------------------------- round 4: the column pass that keeps its twist factors

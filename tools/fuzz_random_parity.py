@@ -45,7 +45,8 @@ while time.time() < t_end:
         special = [0, 1, p - 1, p - 2, (p - 1) // 2, (1 << 32) % p, ((1 << 32) - 1) % p, ((1 << 64) - 1) % p]
         vals = [special[int(rng.integers(0, len(special)))] for _ in range(d)]
         a[:d * O.LIMBS[F]] = O.to_mont(F, vals)
-    op = ["crt", "icrt", "mul", "ntt_mul", "add", "sub", "reduce", "decompose", "rot", "matvec", "wire"][int(rng.integers(0, 11))]
+    op = ["crt", "icrt", "mul", "ntt_mul", "add", "sub", "reduce", "decompose", "rot", "matvec", "wire", "neg", "scale", "add_scalar",
+          "mul_ntt_rhs"][int(rng.integers(0, 15))]
     ok = True
     if op == "crt":
         ok = np.array_equal(r.elementwise_crt(a.copy()), O.pow2_fwd(F, a, k, batch, 4)) if batch else True
@@ -97,6 +98,20 @@ while time.time() < t_end:
                 prod = O.from_mont(F, O.pow2_pointwise(F, m[c * d * L:(c + 1) * d * L], v[c * d * L:(c + 1) * d * L]))
                 acc = [(x + y) % p for x, y in zip(acc, prod)]
             ok = O.from_mont(F, got[:d * L]) == acc
+    elif op in ("neg", "scale", "add_scalar") and batch:
+        sa = O.from_mont(F, a)
+        sc = int(rng.integers(0, 1 << 62)) % p if rng.random() < 0.7 else [0, 1, p - 1][int(rng.integers(0, 3))]
+        img = O.to_mont(F, [sc])
+        if op == "neg":
+            ok = O.from_mont(F, r.neg(a.copy())) == [(p - x) % p for x in sa]
+        elif op == "scale":
+            ok = O.from_mont(F, r.scale(a.copy(), img)) == [x * sc % p for x in sa]
+        else:
+            ntt = bool(rng.integers(0, 2))
+            want = [(x + sc) % p if (ntt or i % d == 0) else x for i, x in enumerate(sa)]   # power-of-two rings: one word per slot
+            ok = O.from_mont(F, r.add_scalar(a.copy(), img, ntt)) == want
+    elif op == "mul_ntt_rhs" and batch:
+        ok = np.array_equal(r.mul_ntt_rhs(a, O.pow2_fwd(F, b, k, batch, 4)), O.pow2_ring_mul(F, a, b, k, batch, 4))
     elif op == "wire" and batch:
         wire = r.serialize(a)
         ok = np.array_equal(wire, O.serialize(F, a)) and np.array_equal(r.deserialize(wire), a)
