@@ -231,18 +231,15 @@ def readme(outdir):
         pj = json.load(open(os.path.join(outdir, "pmc_%s.json" % w)))
         r = bj["roofline"]
         batch = bench.WORKLOADS[w][2]
-        # launches per step of the dominant kernel and its full-batch trace average
-        tpath = os.path.join(outdir, "kernel_trace_%s.csv" % w)
-        trace = list(csv.DictReader(open(tpath))) if os.path.exists(tpath) else []
+        # the dominant kernel's average duration over the COMPLETE trace: kernel_stats_<workload>.csv (rocprofv3 --stats of the same run;
+        # the raw kernel_trace CSV kept beside it is only a sample); of the kernels with the dominant tag, the one with the most time
+        spath = os.path.join(outdir, "kernel_stats_%s.csv" % w)
         avg_ms = None
-        if trace:
-            gk = "Grid_Size_X" if "Grid_Size_X" in trace[0] else "Grid_Size"
-            dur = collections.defaultdict(list)
-            for row in full_batch(trace, gk):
-                if tag_of(row["Kernel_Name"]) == r["kernel"]:
-                    dur[row["Kernel_Name"]].append(int(row["End_Timestamp"]) - int(row["Start_Timestamp"]))
-            big = max(dur.values(), key=lambda v: sum(v)) if dur else []
-            avg_ms = sum(big) / len(big) / 1e6 if big else None
+        if os.path.exists(spath):
+            rows = [row for row in csv.DictReader(open(spath)) if tag_of(row["Name"]) == r["kernel"]]
+            if rows:
+                big = max(rows, key=lambda row: float(row["TotalDurationNs"]))
+                avg_ms = float(big["AverageNs"]) / 1e6
         per_launch = r["dominant_kernel_bytes_per_ring_mul"] * batch / r["launches_per_step"]
         ach = per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms else float("nan")
         md.append("| %s | `%s` | %s | %.2f | %s | %.0f | %.3f | %.3f | %.2f |" % (
