@@ -2205,3 +2205,34 @@ def test_keep_and_plain_column_passes_agree(torch_cuda, k, batch, chunk):
     for i, e in enumerate(sample):
         assert np.array_equal(res[0][0][e * d:(e + 1) * d].cpu().numpy().view(np.uint64), want[i * d:(i + 1) * d]), e
         assert np.array_equal(res[0][1][e * d:(e + 1) * d].cpu().numpy().view(np.uint64), wf[i * d:(i + 1) * d]), e
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,k", [("goldilocks24", 0), ("babybear72", 0), ("frog16", 0), ("stark", 4), ("goldilocks", 10)])
+def test_primitive_ops_like_the_reference(torch_cuda, name, k):
+    """coeff_form.rs:736-746 `test_primitive_ops` (on the Goldilocks ring there), for every ring family: R::one() + 1u32 == R::one() + R::one(),
+    R::one() * 1u32 == R::one(), R::one() * 0u32 == R::zero(), R::one() - 0u32 == R::one(), R::one() - 1u32 == R::zero() -- and the NTT-form
+    counterparts through crt (ntt_form.rs:373-505: adding a primitive to an RqNTT adds it to every slot, which is crt of adding it to
+    coefficient 0)."""
+    base = {"goldilocks24": "goldilocks", "babybear72": "babybear", "frog16": "frog"}.get(name, name)
+    F = O.FIELD_ID[base]
+    p = P.PRIMES[base][0] if base in P.PRIMES else P.FROG_P
+    ring = ring_for(name, k)
+    d = ring.degree
+    one = O.to_mont(F, [1] + [0] * (d - 1))
+    zero = O.to_mont(F, [0] * d)
+    img = lambda v: O.to_mont(F, [v % p])
+    assert np.array_equal(ring.add_scalar(one.copy(), img(1), False), ring.add(one.copy(), one))
+    assert np.array_equal(ring.scale(one.copy(), img(1)), one)
+    assert np.array_equal(ring.scale(one.copy(), img(0)), zero)
+    assert np.array_equal(ring.add_scalar(one.copy(), img(-0), False), one)          # one - 0
+    assert np.array_equal(ring.add_scalar(one.copy(), img(-1), False), zero)         # one - 1: Sub passes the negated scalar
+    assert np.array_equal(ring.neg(one.copy()), ring.sub(zero.copy(), one))
+    # the NTT-form operators are the coefficient-form ones seen through crt
+    a = O.fill_uniform(F, 0x515, 0, 3 * d)
+    for v in (1, 7, p - 1):
+        lhs = ring.add_scalar(ring.elementwise_crt(a.copy()), img(v), True)
+        rhs = ring.elementwise_crt(ring.add_scalar(a.copy(), img(v), False))
+        assert np.array_equal(lhs, rhs), v
+        assert np.array_equal(ring.scale(ring.elementwise_crt(a.copy()), img(v)), ring.elementwise_crt(ring.scale(a.copy(), img(v))))
+    assert np.array_equal(ring.neg(ring.elementwise_crt(a.copy())), ring.elementwise_crt(ring.neg(a.copy())))
