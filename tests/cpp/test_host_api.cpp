@@ -76,6 +76,51 @@ static void pow2_suite(sr_ring ring, int field, int log2d, size_t batch) {
         EXPECT(std::move(rhs).elementwise_icrt() == orig);
     }
 
+    // Neg, Mul<primitive>, Add / Sub<primitive> (round 4; coeff_form.rs:270-278, 610-700 and test_primitive_ops :736-746; ntt_form.rs:191-203,
+    // 373-505): one * 1 == one, one * 0 == zero, one + 1 == one + one, one - 1 == zero; a + (-a) == 0; crt commutes with all three
+    {
+        std::vector<uint64_t> img1(L), img0(L, 0), imgm1(L), one_el(d * L, 0), tmp(L);
+        const uint64_t std1[4] = {1, 0, 0, 0};
+        sro_to_mont(field, std1, img1.data(), 1);
+        std::copy(img1.begin(), img1.end(), one_el.begin());
+        RqPolyVec one(cfg, one_el), zero(cfg, std::vector<uint64_t>(d * L, 0));
+        {
+            RqPolyVec m1 = -RqPolyVec(cfg, one_el);                 // the image of -1 is coefficient 0 of -one
+            std::copy(m1.words().begin(), m1.words().begin() + L, imgm1.begin());
+        }
+        RqPolyVec t = one;
+        t *= img1;
+        EXPECT(t == one);
+        t *= img0;
+        EXPECT(t == zero);
+        RqPolyVec two = one;
+        two += img1;
+        RqPolyVec oo = one;
+        oo += one;
+        EXPECT(two == oo);
+        two += imgm1;                                               // Sub passes the negated scalar
+        two += imgm1;
+        EXPECT(two == zero);
+        RqPolyVec s = RqPolyVec(cfg, a);
+        s += -RqPolyVec(cfg, a);
+        EXPECT(s == RqPolyVec(cfg, std::vector<uint64_t>(a.size(), 0)));
+        // through crt: scaling and negation commute with it; adding c to coefficient 0 is adding c to every slot
+        std::vector<uint64_t> c7(L);
+        const uint64_t std7[4] = {7, 0, 0, 0};
+        sro_to_mont(field, std7, c7.data(), 1);
+        RqPolyVec pa(cfg, a);
+        pa *= c7;
+        RqNTTVec na = RqPolyVec(cfg, a).elementwise_crt();
+        na *= c7;
+        EXPECT(std::move(pa).elementwise_crt() == na);
+        RqPolyVec pb(cfg, a);
+        pb += c7;
+        RqNTTVec nb2 = RqPolyVec(cfg, a).elementwise_crt();
+        nb2 += c7;
+        EXPECT(std::move(pb).elementwise_crt() == nb2);
+        EXPECT((-RqPolyVec(cfg, a)).elementwise_crt() == -(RqPolyVec(cfg, a).elementwise_crt()));
+    }
+
     // flatten / promote (flatten.rs:128-138)
     auto flat = flatten_to_coeffs(RqPolyVec(cfg, a));
     EXPECT(flat == a);
