@@ -4,6 +4,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
+#include <array>
 #include <chrono>
 #include "../../stark_rings_amd/csrc/ntt_goldilocks.hpp"
 #ifdef PERSIST
@@ -159,10 +160,28 @@ int main(int argc, char **argv) {
         for (int r = -1; r < reps; r++) {
             CK(hipDeviceSynchronize());
             auto t0 = std::chrono::steady_clock::now();
-            for (size_t c = 0; c < nch; c++) {
-                const int si = (int)(c % STREAMS);
-                const size_t np = (c + 1) * ch <= npoly ? ch : npoly - c * ch;
-                u64 *ac = a + ((c * ch) << k), *bc = b + ((c * ch) << k);
+            // the chunk schedule: (first element, elements, stream).  HALF_FIRST: the second lane starts with half a chunk, so that the
+            // two lanes run half a chunk out of phase (one in its column passes while the other is in its rows kernel)
+            std::vector<std::array<size_t, 3>> sched;
+            {
+                size_t pos = 0;
+                int si = 0;
+#ifdef HALF_FIRST
+                sched.push_back({0, ch, 0});
+                sched.push_back({ch, ch / 2, 1});
+                pos = ch + ch / 2;
+#endif
+                while (pos < npoly) {
+                    const size_t np = npoly - pos < ch ? npoly - pos : ch;
+                    sched.push_back({pos, np, (size_t)si});
+                    si = (si + 1) % STREAMS;
+                    pos += np;
+                }
+            }
+            for (const auto &it : sched) {
+                const int si = (int)it[2];
+                const size_t np = it[1];
+                u64 *ac = a + (it[0] << k), *bc = b + (it[0] << k);
                 const unsigned cb = (unsigned)(np << (k - 8 - LCV));
                 const unsigned grp = sr::xcd_grouped_tiles(cb, sr::gl::kColsXcdGroup);
 #ifdef LIBFLOW  // the library's flow for a *= b: a's intermediates live in a itself, only b's go through the lane's scratch
