@@ -57,6 +57,12 @@ inline unsigned xcd_grouped_tiles(size_t tiles, int cl) { return (unsigned)(tile
 //       handed a representative >= p;
 //   [1] a lazy sum whose + eps wrapped a second time;   [2] a lazy difference whose + p borrowed a second time;
 //   [3] a word >= p leaving the library;                 [4] a routine documented "canonical out" that returned >= p.
+// The lazy nine-limb Stark arithmetic (stark_lazy.hpp) has invariants of the same kind -- bounds no parity test can see until they
+// break -- and the same build counts them:
+//   [5] a limb-wise add / sub whose exact sum left the int32 range the invariants promise (|l| < 2^31 - 16);
+//   [6] a Montgomery product whose operands could overflow the 64-bit column accumulator (9 max|a.l| max|w.l| + 2^58 >= 2^63);
+//   [7] is not a violation count but the high-water mark of |limb| over every add / sub since the last reset (the tests report the
+//       headroom the kernels' reduction schedule leaves below 2^31).
 // sr_selftest_rep_counters reads and clears them; tests/test_rep_invariants.py asserts zeros over crafted, structured, edge and
 // uniform operands of every tuned plan.
 // ------------------------------------------------------------------------------------------
@@ -81,11 +87,28 @@ __device__ __forceinline__ void leaves_library(unsigned long long v) {
 __device__ __forceinline__ void canonical_out(unsigned long long v) {
     if (v >= kP) count(4);
 }
+__device__ __forceinline__ void stark_limb(long long exact) {
+    const unsigned long long m = (unsigned long long)(exact < 0 ? -exact : exact);
+    if (m > 2147483647ull - 16) count(5);
+    if (m > *(volatile unsigned long long *)&g_counters[7]) atomicMax(&g_counters[7], m);   // high-water mark
+}
+__device__ __forceinline__ void stark_columns(const int *a, const int *w) {
+    unsigned long long ma = 0, mw = 0;
+    for (int i = 0; i < 9; i++) {
+        const unsigned long long x = (unsigned long long)(a[i] < 0 ? -(long long)a[i] : (long long)a[i]);
+        const unsigned long long y = (unsigned long long)(w[i] < 0 ? -(long long)w[i] : (long long)w[i]);
+        ma = x > ma ? x : ma;
+        mw = y > mw ? y : mw;
+    }
+    if (ma * mw >= ((1ull << 63) - (1ull << 58)) / 9) count(6);
+}
 #else
 SR_HD void canonical_in(unsigned long long, unsigned long long) {}
 SR_HD void lazy_fix(unsigned long long, unsigned long long, unsigned long long, unsigned long long) {}
 SR_HD void leaves_library(unsigned long long) {}
 SR_HD void canonical_out(unsigned long long) {}
+SR_HD void stark_limb(long long) {}
+SR_HD void stark_columns(const int *, const int *) {}
 #endif
 }  // namespace repcheck
 

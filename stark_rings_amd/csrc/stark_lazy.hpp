@@ -94,13 +94,19 @@ struct StarkL {
     SR_HD static elem add(const elem &a, const elem &b) {
         elem r;
 #pragma unroll
-        for (int i = 0; i < 9; i++) r.l[i] = (int32_t)((uint32_t)a.l[i] + (uint32_t)b.l[i]);  // wraps, never UB, on garbage input
+        for (int i = 0; i < 9; i++) {
+            r.l[i] = (int32_t)((uint32_t)a.l[i] + (uint32_t)b.l[i]);  // wraps, never UB, on garbage input
+            repcheck::stark_limb((long long)a.l[i] + (long long)b.l[i]);
+        }
         return r;
     }
     SR_HD static elem sub(const elem &a, const elem &b) {
         elem r;
 #pragma unroll
-        for (int i = 0; i < 9; i++) r.l[i] = (int32_t)((uint32_t)a.l[i] - (uint32_t)b.l[i]);
+        for (int i = 0; i < 9; i++) {
+            r.l[i] = (int32_t)((uint32_t)a.l[i] - (uint32_t)b.l[i]);
+            repcheck::stark_limb((long long)a.l[i] - (long long)b.l[i]);
+        }
         return r;
     }
     SR_HD static elem relax(const elem &a) {
@@ -177,6 +183,7 @@ struct StarkL {
         uint64_t cy;
         uint32_t m[10];
         elem r;
+        repcheck::stark_columns(a.l, w.l);
 #include "stark_mul_cols.inc"
         return r;
     }

@@ -25,7 +25,8 @@ from test_gpu_parity import _structured_operands, edge_and_random  # noqa: E402
 F = O.GOLDILOCKS
 P = 0xFFFFFFFF00000001
 NAMES = ["canonical routine handed a representative >= p", "lazy sum wrapped twice", "lazy difference borrowed twice",
-         "word >= p left the library", "'canonical out' routine returned >= p"]
+         "word >= p left the library", "'canonical out' routine returned >= p",
+         "Stark limb sum left the int32 range of the invariants", "Stark product operands could overflow the column accumulator"]
 
 
 def counters(reset=True):
@@ -37,8 +38,9 @@ def counters(reset=True):
 
 def expect_clean(what):
     c = counters()
-    bad = ["%s: %d" % (NAMES[i], c[i]) for i in range(5) if c[i]]
+    bad = ["%s: %d" % (NAMES[i], c[i]) for i in range(len(NAMES)) if c[i]]
     assert not bad, "%s: %s" % (what, "; ".join(bad))
+    return c[7]     # the Stark limb high-water mark since the last reset
 
 
 def canonical(a):
@@ -145,6 +147,111 @@ def run_lanes(k, batch):
     print("%-28s clean" % ("D=2^%d x %d on two lanes" % (k, batch)), flush=True)
 
 
+def max_limb_images(d, flavour):
+    """Stark memory images (4 u64 words per coefficient, any canonical value is some element's Montgomery image) whose nine 28-bit
+    limbs are as large as canonical values get: 2^251 - 1 (all limbs 0xfffffff, the top one 2^27 - 1), its negative, and values
+    with every limb's top bits set."""
+    PS = (1 << 251) + 17 * (1 << 192) + 1
+    hi = (1 << 251) - 1
+    vals = {"max": [hi] * d,
+            "alternating": [hi if i & 1 else PS - hi for i in range(d)],
+            "topbits": [(hi - (i * 0x0123456789ABCDEF % (1 << 24)) * sum(1 << (28 * j) for j in range(9))) % PS for i in range(d)]}[flavour]
+    out = np.empty(4 * d, dtype=np.uint64)
+    for i, v in enumerate(vals):
+        for j in range(4):
+            out[4 * i + j] = (v >> (64 * j)) & 0xFFFFFFFFFFFFFFFF
+    return out
+
+
+def run_stark(k, env=None):
+    """The Stark rings compute in nine signed 28-bit limbs with postponed carries (csrc/stark_lazy.hpp): the invariants are limb bounds
+    (no add / sub may leave int32, no product may overflow its 64-bit column accumulator) which the kernels keep by reducing weakly
+    every few stages.  Uniform data stays far from the bounds; the operands here are memory images with every limb at its maximum."""
+    S = O.STARK
+    for key, val in (env or {}).items():
+        os.environ[key] = val
+    try:
+        ring = CyclotomicRing("stark", k, device=0)
+    finally:
+        for key in (env or {}):
+            del os.environ[key]
+    tag = "Stark D=2^%d%s" % (k, (" " + ",".join("%s=%s" % kv for kv in env.items())) if env else "")
+    counters()
+    d = 1 << k
+    batch = 6
+    a = edge_and_random(S, k, batch, 0x3A0 + k)
+    b = edge_and_random(S, k, batch, 0x3B0 + k)
+    for e, flavour in enumerate(("max", "alternating", "topbits")):
+        a[(e + 2) * 4 * d:(e + 3) * 4 * d] = max_limb_images(d, flavour)                    # elements 2..4 of a
+        b[((e + 1) % 3 + 2) * 4 * d:((e + 1) % 3 + 3) * 4 * d] = max_limb_images(d, flavour)  # meet another flavour in b
+    fa = ring.elementwise_crt(a.copy())
+    prod = ring.mul(a, b)
+    assert np.array_equal(ring.elementwise_icrt(fa.copy()), a)
+    assert np.array_equal(ring.mul_ntt_rhs(a, ring.elementwise_crt(b.copy())), prod)
+    if k <= 12:
+        assert np.array_equal(fa, O.pow2_fwd(S, a, k, batch, 4))
+        assert np.array_equal(prod, O.pow2_ring_mul(S, a, b, k, batch, 4))
+    else:
+        for e in (2, 3, 4):
+            sl = slice(e * 4 * d, (e + 1) * 4 * d)
+            assert np.array_equal(fa[sl], O.pow2_fwd(S, a[sl], k, 1))
+            assert np.array_equal(prod[sl], O.pow2_ring_mul(S, a[sl], b[sl], k, 1, 4))
+    # the inverse transform fed max-limb NTT-domain words, then the forward one on what comes out
+    raw = np.concatenate([max_limb_images(d, f) for f in ("max", "alternating", "topbits")])
+    back = ring.elementwise_icrt(raw.copy())
+    assert np.array_equal(ring.elementwise_crt(back.copy()), raw)
+    if k <= 12:
+        assert np.array_equal(back, O.pow2_inv(S, raw, k, 3, 4))
+    high = expect_clean(tag)
+    ring.close()
+    print("%-36s clean; largest |limb| in any add / sub %d = 2^31 - %.2f x 2^28" % (tag, high, ((1 << 31) - high) / (1 << 28)), flush=True)
+    return high
+
+
+def run_stark_sums():
+    """the linear-algebra kernels sum Montgomery products lazily (a weak reduction every four terms): long rows of max-limb images"""
+    import torch
+
+    S = O.STARK
+    PS = (1 << 251) + 17 * (1 << 192) + 1
+    k, nrows, ncols = 4, 3, 41
+    d = 1 << k
+    ring = CyclotomicRing("stark", k, device=0)
+    counters()
+    flav = ("max", "alternating", "topbits")
+    m = np.concatenate([max_limb_images(d, flav[(r + c) % 3]) for r in range(nrows) for c in range(ncols)])
+    v = np.concatenate([max_limb_images(d, flav[c % 2]) for c in range(ncols)])
+    rinv = pow(1 << 256, -1, PS)
+
+    def ints(img):
+        return [int(img[4 * i]) | int(img[4 * i + 1]) << 64 | int(img[4 * i + 2]) << 128 | int(img[4 * i + 3]) << 192 for i in range(len(img) // 4)]
+
+    mi, vi = ints(m), ints(v)
+    want = []
+    for r in range(nrows):
+        for i in range(d):
+            want.append(sum(mi[(r * ncols + c) * d + i] * vi[c * d + i] for c in range(ncols)) * rinv % PS)   # images: (a R)(b R) / R
+    tm = torch.from_numpy(m.view(np.int64)).cuda()
+    tv = torch.from_numpy(v.view(np.int64)).cuda()
+    ty = torch.empty(nrows * 4 * d, dtype=torch.int64, device="cuda")
+    ring.matvec_ntt_dev(ty, tm, tv, nrows, ncols)
+    assert ints(ty.cpu().numpy().view(np.uint64)) == want
+    bm = np.concatenate([max_limb_images(d, flav[(c + q) % 3]) for c in range(ncols) for q in range(2)])    # ncols x 2, row-major
+    bi = ints(bm)
+    want2 = []
+    for r in range(nrows):
+        for q in range(2):
+            for i in range(d):
+                want2.append(sum(mi[(r * ncols + c) * d + i] * bi[(c * 2 + q) * d + i] for c in range(ncols)) * rinv % PS)
+    tb = torch.from_numpy(bm.view(np.int64)).cuda()
+    tc = torch.empty(nrows * 2 * 4 * d, dtype=torch.int64, device="cuda")
+    ring.matmul_ntt_dev(tc, tm, tb, nrows, ncols, 2)
+    assert ints(tc.cpu().numpy().view(np.uint64)) == want2
+    high = expect_clean("Stark matrix products over rows of %d max-limb images" % ncols)
+    ring.close()
+    print("%-36s clean; largest |limb| in any add / sub %d" % ("Stark sums of %d products" % ncols, high), flush=True)
+
+
 def negative_control():
     """the hooks are live: raw operand words >= p (not a field element's image) must be counted wherever a canonical routine takes
     them -- the inverse transform's first network starts with twiddle-1 butterflies, the ring add is Goldilocks::add.  (The FORWARD
@@ -166,13 +273,21 @@ def negative_control():
 
 def main():
     assert os.environ.get("SR_LIB_PATH", "").endswith("_check.so"), "run with SR_LIB_PATH=<the checking build>"
-    negative_control()
-    for k in (10, 12, 13, 16, 17, 20, 21):
-        run_plan(k)
-    for k in (16, 20):
-        run_plan(k, {"SR_GL_COLS256": "0"})     # the older plan: strided passes + lazy 4096-point tiles
-    run_lanes(16, 264)     # two chunks of 128 and one of 8: cols256_keep_kernel on both lanes
-    run_lanes(20, 17)      # chunks of 8, 8 and 1 at D = 2^20
+    which = sys.argv[1:] or ["goldilocks", "stark"]
+    if "goldilocks" in which:
+        negative_control()
+        for k in (10, 12, 13, 16, 17, 20, 21):
+            run_plan(k)
+        for k in (16, 20):
+            run_plan(k, {"SR_GL_COLS256": "0"})     # the older plan: strided passes + lazy 4096-point tiles
+        run_lanes(16, 264)     # two chunks of 128 and one of 8: cols256_keep_kernel on both lanes
+        run_lanes(20, 17)      # chunks of 8, 8 and 1 at D = 2^20
+    if "stark" in which:
+        highs = [run_stark(k) for k in (4, 8, 10, 11, 12, 13, 14, 15, 16)]   # one tile per element, then 1, 2 or 3 strided stages in front
+        highs += [run_stark(k, {"SR_STARK_TUNED": "0"}) for k in (6, 10, 12)]   # the generic LDS kernels on the same lazy arithmetic
+        highs += [run_stark(k, {"SR_ST_WHOLE_MAX": v}) for k, v in ((10, "9"), (12, "12"))]
+        run_stark_sums()
+        print("Stark limb high-water mark over all plans: %d of %d (2^31 - 16)" % (max(highs), (1 << 31) - 16), flush=True)
     print("rep_invariants: OK", flush=True)
 
 

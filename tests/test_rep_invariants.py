@@ -4,7 +4,9 @@ a butterfly that assumes canonical inputs is wrong, and no uniform-data parity t
 libstarkrings_hip_check.so is the product's own source compiled with -DSR_GL_CHECK_REPS: every canonical butterfly counts a
 non-canonical input, every lazy butterfly a second wrap or borrow, every result store a word >= p, while the real kernels run.
 The GPU test drives it, in a process of its own (SR_LIB_PATH), over uniform, edge, structured and crafted operands of every tuned
-plan and requires all counters to stay zero -- and a raw operand word >= p to be counted."""
+plan and requires all counters to stay zero -- and a raw operand word >= p to be counted.  The same build counts the bound
+violations of the lazy nine-limb Stark arithmetic (limb sums leaving int32, products that could overflow a column accumulator) and
+records the largest limb seen: a second test drives every Stark kernel family over max-limb operands."""
 import ctypes
 import os
 import subprocess
@@ -30,12 +32,27 @@ def test_checking_build_exports_the_whole_abi_and_the_product_carries_no_checks(
     assert "SR_GL_CHECK_REPS" in src and "atomicAdd(&g_counters" in src
 
 
-@pytest.mark.gpu
-def test_every_tuned_goldilocks_plan_keeps_its_representative_invariants():
+def _worker(which):
     env = dict(os.environ)
     env["SR_LIB_PATH"] = CHECK_SO
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "rep_invariants_worker.py")], env=env, cwd=ROOT,
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "rep_invariants_worker.py"), which], env=env, cwd=ROOT,
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=1500)
     out = r.stdout.decode()
     assert r.returncode == 0 and "rep_invariants: OK" in out, out[-4000:]
+    return out
+
+
+@pytest.mark.gpu
+def test_every_tuned_goldilocks_plan_keeps_its_representative_invariants():
+    out = _worker("goldilocks")
     assert out.count(" clean") >= 11 and "negative control" in out, out[-4000:]
+
+
+@pytest.mark.gpu
+def test_every_stark_plan_keeps_its_limb_bounds():
+    """The nine-limb lazy Stark arithmetic (csrc/stark_lazy.hpp) postpones carries and reductions; its invariants are bounds (no limb sum
+    leaves int32, no product overflows its 64-bit column accumulator) that the kernels keep by reducing weakly every few stages -- and
+    that uniform data never approaches.  The checking build counts violations and records the largest |limb| any add / sub produced,
+    over memory images with every limb at its maximum, through every Stark kernel family and the lazily summed matrix products."""
+    out = _worker("stark")
+    assert out.count(" clean") >= 15 and "Stark limb high-water mark" in out, out[-4000:]
