@@ -313,8 +313,9 @@ int sr_selftest_field_op(int field, int op, const uint64_t *a, const uint64_t *b
 
 /* Test hook of the CHECKING build (libstarkrings_hip_check.so = the same sources compiled with -DSR_GL_CHECK_REPS): while the real
  * kernels of the tuned Goldilocks path run, every canonical butterfly counts a non-canonical input, every lazy butterfly a second
- * wrap or borrow, every result store a word >= p (csrc/fields.hpp: repcheck).  counters[0..4] as documented there; reset != 0
- * clears them.  Synchronises the device.  The product library returns SR_E_UNSUPPORTED: it carries no checks.
+ * wrap or borrow, every result store a word >= p; the lazy nine-limb Stark arithmetic counts limb sums that leave int32 and
+ * products that could overflow a column accumulator (csrc/fields.hpp: repcheck).  counters[0..6] as documented there, counters[7]
+ * = the largest |limb| any Stark add / sub produced; reset != 0 clears them.  Synchronises the device.  The product library returns SR_E_UNSUPPORTED: it carries no checks.
  * Not a compute path. */
 int sr_selftest_rep_counters(uint64_t counters[8], int reset);
 
