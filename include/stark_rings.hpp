@@ -24,6 +24,8 @@
 //   Matrix<RqNTT> (linear_algebra)       matrix.rs:14-20             class MatrixNTT        (dense, row-major, flat)
 //     checked_mul_vec / try_mul_vec      matrix.rs:168-183             checked_mul_vec -> std::optional (nullopt: DifferentLengths), try_mul_vec throws
 //     checked_mul_mat                    matrix.rs:148-166             checked_mul_mat -> std::optional
+//     MulAssign<&R> (Matrix, Sparse)     matrix.rs:207-211,            operator*=(const RqNTTVec &one_element): every entry times one ring element
+//                                        sparse_matrix.rs:303-307
 //   GadgetDecompose / GadgetRecompose    balanced_decomposition/     gadget_decompose(const RqPolyVec&, b, k) / gadget_recompose(...)
 //     for &[R] / Vec<R>                  mod.rs:163-206                (digit j of element e = element e * k + j; throws where it panics)
 //   SparseMatrix<RqNTT>                  sparse_matrix.rs:17-22      class SparseMatrixNTT  (coeffs: rows of (element, column))
@@ -138,6 +140,7 @@ public:
     // Neg, Mul<scalar>, Add<scalar> (coeff_form.rs:270-278, 390-408, 610-700; ntt_form.rs:191-203, 373-505); scalar: host pointer to the
     // Montgomery image of the base-field element
     void neg_dev(uint64_t *d, size_t batch, void *stream) const { check(sr_neg_batch_dev(raw(), d, batch, stream), "neg_dev"); }
+    void mul_elem_dev(uint64_t *d, const uint64_t *d_elem, size_t batch, void *stream) const { check(sr_mul_elem_batch_dev(raw(), d, d_elem, batch, stream), "mul_elem_dev"); }
     void scale_dev(uint64_t *d, const uint64_t *scalar, size_t batch, void *stream) const { check(sr_scale_batch_dev(raw(), d, scalar, batch, stream), "scale_dev"); }
     void add_scalar_dev(uint64_t *d, const uint64_t *scalar, bool ntt_form, size_t batch, void *stream) const {
         check(sr_add_scalar_batch_dev(raw(), d, scalar, ntt_form ? 1 : 0, batch, stream), "add_scalar_dev");
@@ -284,6 +287,12 @@ public:
         CyclotomicConfig::check(sr_scale_batch(cfg_.raw(), w_.data(), scalar.data(), len()), "RqNTT *= scalar");
         return *this;
     }
+    // every element of the vector times ONE ring element r (r.len() == 1), slot-wise: the loop body of `Matrix<R> *= &R`
+    RqNTTVec &mul_assign_elem(const RqNTTVec &r) {
+        if (r.len() != 1) throw std::length_error("mul_assign_elem: the multiplier is not one ring element");
+        CyclotomicConfig::check(sr_mul_elem_batch(cfg_.raw(), w_.empty() ? dummy_word() : w_.data(), r.w_.data(), len()), "RqNTT[] *= &RqNTT");
+        return *this;
+    }
     RqNTTVec &operator+=(const std::vector<uint64_t> &scalar) {  // component 0 of every slot (ntt_form.rs:427-505)
         if (scalar.size() != (size_t)cfg_.limbs()) throw std::length_error("scalar: wrong number of limbs");
         CyclotomicConfig::check(sr_add_scalar_batch(cfg_.raw(), w_.data(), scalar.data(), 1, len()), "RqNTT += scalar");
@@ -292,6 +301,10 @@ public:
     std::vector<uint64_t> into_words() && { return std::move(w_); }
 
 private:
+    static uint64_t *dummy_word() {
+        static uint64_t z = 0;
+        return &z;
+    }
     CyclotomicConfig cfg_;
     std::vector<uint64_t> w_;
 };
@@ -514,6 +527,12 @@ public:
                                 "Matrix * Matrix");
         return MatrixNTT(cfg_, nrows_, m.ncols_, std::move(y));
     }
+    MatrixNTT &operator*=(const RqNTTVec &r) {  // MulAssign<&R> for Matrix<R> (matrix.rs:207-211): every entry *= r
+        if (r.len() != 1) throw std::length_error("Matrix *= &R: the multiplier is not one ring element");
+        std::vector<uint64_t> dummy(1);
+        CyclotomicConfig::check(sr_mul_elem_batch(cfg_.raw(), w_.empty() ? dummy.data() : w_.data(), r.words().data(), nrows_ * ncols_), "Matrix *= &R");
+        return *this;
+    }
 
 private:
     CyclotomicConfig cfg_;
@@ -556,6 +575,13 @@ public:
         auto r = checked_mul_vec(v);
         if (!r) throw std::length_error("DifferentLengths");
         return std::move(*r);
+    }
+    SparseMatrixNTT &operator*=(const RqNTTVec &r) {  // MulAssign<&R> for SparseMatrix<R> (sparse_matrix.rs:303-307): every stored entry *= r
+        if (r.len() != 1) throw std::length_error("SparseMatrix *= &R: the multiplier is not one ring element");
+        std::vector<uint64_t> dummy(1);
+        CyclotomicConfig::check(sr_mul_elem_batch(cfg_.raw(), vals_.empty() ? dummy.data() : vals_.data(), r.words().data(), cols_.size()),
+                                "SparseMatrix *= &R");
+        return *this;
     }
 
 private:

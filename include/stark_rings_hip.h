@@ -156,6 +156,11 @@ int sr_sub_batch(sr_ctx *ctx, uint64_t *lhs_inout, const uint64_t *rhs, size_t b
 int sr_neg_batch(sr_ctx *ctx, uint64_t *data, size_t batch);
 int sr_scale_batch(sr_ctx *ctx, uint64_t *data, const uint64_t *scalar, size_t batch);
 int sr_add_scalar_batch(sr_ctx *ctx, uint64_t *data, const uint64_t *scalar, int ntt_form, size_t batch);
+/* Every element of the batch (CRT/NTT form) times ONE ring element, slot-wise: `MulAssign<&R> for Matrix<R>`
+ * (linear_algebra/src/matrix.rs:207-211) and `for SparseMatrix<R>` (sparse_matrix.rs:303-307) on the matrix's flat storage --
+ * `row.iter_mut().for_each(|r_m| *r_m *= r)`.  Every ring id (Fq3 / Fq9 / Fq4 slot products for the reference's own rings).
+ * elem: D coefficients; it must not lie inside the batch it multiplies (the _dev form: a DEVICE pointer). */
+int sr_mul_elem_batch(sr_ctx *ctx, uint64_t *data_inout, const uint64_t *elem, size_t batch);
 /* RqPoly * RqPoly == icrt(crt(a) * crt(b)) (coeff_form.rs:250-258; identity tested at
  * stark_prime/mod.rs:161-177).  out may alias a.                                          */
 int sr_ring_mul_batch(sr_ctx *ctx, uint64_t *out, const uint64_t *a, const uint64_t *b, size_t batch);
@@ -173,6 +178,7 @@ int sr_sub_batch_dev(sr_ctx *ctx, uint64_t *d_lhs_inout, const uint64_t *d_rhs, 
 int sr_neg_batch_dev(sr_ctx *ctx, uint64_t *d_data, size_t batch, void *stream);
 int sr_scale_batch_dev(sr_ctx *ctx, uint64_t *d_data, const uint64_t *host_scalar, size_t batch, void *stream);
 int sr_add_scalar_batch_dev(sr_ctx *ctx, uint64_t *d_data, const uint64_t *host_scalar, int ntt_form, size_t batch, void *stream);
+int sr_mul_elem_batch_dev(sr_ctx *ctx, uint64_t *d_data_inout, const uint64_t *d_elem, size_t batch, void *stream);
 /* First "next" row: y = M * v for a dense nrows x ncols matrix of ring elements in CRT/NTT form
  * (row-major, each entry one ring element) and a vector of ncols elements -- Matrix<RqNTT>::checked_mul_vec,
  * crates/linear_algebra/src/matrix.rs:168-178 -- as one fused multiply-accumulate pass over M.  Every ring id: the fully

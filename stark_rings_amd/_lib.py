@@ -36,6 +36,8 @@ SYMBOLS = {
     "sr_add_scalar_batch": (_c.c_int, [_c.c_void_p, u64p, u64p, _c.c_int, _c.c_size_t]),
     "sr_neg_batch_dev": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_size_t, _c.c_void_p]),
     "sr_scale_batch_dev": (_c.c_int, [_c.c_void_p, _c.c_void_p, u64p, _c.c_size_t, _c.c_void_p]),
+    "sr_mul_elem_batch": (_c.c_int, [_c.c_void_p, u64p, u64p, _c.c_size_t]),
+    "sr_mul_elem_batch_dev": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_size_t, _c.c_void_p]),
     "sr_add_scalar_batch_dev": (_c.c_int, [_c.c_void_p, _c.c_void_p, u64p, _c.c_int, _c.c_size_t, _c.c_void_p]),
     "sr_reduce_batch": (_c.c_int, [_c.c_void_p, u64p, _c.c_size_t, u64p, _c.c_size_t]),
     "sr_ntt_fwd_batch_dev": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_size_t, _c.c_void_p]),

@@ -359,6 +359,16 @@ int inv_dev(sr_ctx *c, uint64_t *d, size_t batch, hipStream_t st) {
     return SR_OK;
 }
 template <class F>
+int pointwise_bcast_dev(sr_ctx *c, uint64_t *lhs, const uint64_t *r, size_t n_coeffs, hipStream_t st) {
+    if (n_coeffs == 0) return SR_OK;
+    ProfScope ps(c, st, K_POINTWISE);
+    hipLaunchKernelGGL(sr::pointwise_bcast_kernel<F>, dim3(sr::stream_blocks<F>(n_coeffs)), dim3(256), 0, st,
+                       reinterpret_cast<typename F::storage *>(lhs), reinterpret_cast<const typename F::storage *>(r), n_coeffs,
+                       (size_t)c->degree - 1);
+    HIP_TRY(hipGetLastError());
+    return SR_OK;
+}
+template <class F>
 int pointwise_dev(sr_ctx *c, uint64_t *lhs, const uint64_t *rhs, size_t n_coeffs, hipStream_t st) {
     if (n_coeffs == 0) return SR_OK;
     const unsigned blocks = sr::stream_blocks<F>(n_coeffs);
@@ -1072,6 +1082,13 @@ int dev_pointwise(sr_ctx *c, uint64_t *l, const uint64_t *r, size_t batch, hipSt
     if (c->ring == SR_RING_BABYBEAR_72) return sr::small_launch(c->small, sr::SMALL_B72_MUL, l, r, 0, l, batch, st) ? fail(SR_E_HIP, "small-ring launch failed") : SR_OK;
     DISPATCH_POW2(c, (pointwise_dev<F>(c, l, r, batch << c->k, st)));
 }
+// every element of the batch *= ONE ring element r, slot-wise (CRT / NTT form): Matrix<R> *= &R, SparseMatrix<R> *= &R
+int dev_mul_elem(sr_ctx *c, uint64_t *l, const uint64_t *r, size_t batch, hipStream_t st) {
+    if (c->ring == SR_RING_FROG_16) return sr::frog_launch(c->frog, sr::FROG_MULB, l, r, 0, l, batch, st) ? fail(SR_E_HIP, "frog-ring launch failed") : SR_OK;
+    if (c->ring == SR_RING_GOLDILOCKS_24 || c->ring == SR_RING_BABYBEAR_72)
+        return sr::small_launch_mul_bcast(c->small, c->ring == SR_RING_BABYBEAR_72, l, r, batch, st) ? fail(SR_E_HIP, "small-ring launch failed") : SR_OK;
+    DISPATCH_POW2(c, (pointwise_bcast_dev<F>(c, l, r, batch << c->k, st)));
+}
 int dev_addsub(sr_ctx *c, uint64_t *l, const uint64_t *r, size_t batch, bool sub, hipStream_t st) {
     const size_t n = batch * c->degree;
     switch (c->ring) {
@@ -1596,6 +1613,15 @@ int sr_pointwise_mul_batch_dev(sr_ctx *c, uint64_t *l, const uint64_t *r, size_t
     std::lock_guard<std::mutex> lk(c->mu);
     DeviceGuard g(c->device);
     return dev_pointwise(c, l, r, batch, (hipStream_t)stream);
+}
+int sr_mul_elem_batch_dev(sr_ctx *c, uint64_t *d, const uint64_t *elem, size_t batch, void *stream) {
+    if (int rc = check(c, d, elem)) return rc;
+    if (int rc = check_count(c, batch)) return rc;
+    const size_t w = (size_t)c->degree * c->limbs;
+    if (elem + w > d && d + batch * w > elem) return fail(SR_E_INVALID, "mul_elem: the element must not lie inside the batch it multiplies");
+    std::lock_guard<std::mutex> lk(c->mu);
+    DeviceGuard g(c->device);
+    return dev_mul_elem(c, d, elem, batch, (hipStream_t)stream);
 }
 int sr_add_batch_dev(sr_ctx *c, uint64_t *l, const uint64_t *r, size_t batch, void *stream) {
     if (int rc = check(c, l, r)) return rc;
@@ -2286,6 +2312,22 @@ int sr_neg_batch(sr_ctx *c, uint64_t *data, size_t batch) { return host_unary(c,
 int sr_scale_batch(sr_ctx *c, uint64_t *data, const uint64_t *scalar, size_t batch) { return host_unary(c, data, scalar, batch, 1); }
 int sr_add_scalar_batch(sr_ctx *c, uint64_t *data, const uint64_t *scalar, int ntt_form, size_t batch) {
     return host_unary(c, data, scalar, batch, ntt_form ? 3 : 2);
+}
+// host buffers: the one element goes to a device temporary of its own, the batch through the staged pipeline
+int sr_mul_elem_batch(sr_ctx *c, uint64_t *data, const uint64_t *elem, size_t batch) {
+    if (int rc = check(c, data, elem)) return rc;
+    if (int rc = check_count(c, batch)) return rc;
+    std::lock_guard<std::mutex> lk(c->mu);
+    DeviceGuard g(c->device);
+    const size_t bytes = (size_t)c->degree * c->limbs * 8;
+    uint64_t *dr = nullptr;
+    HIP_TRY(hipMalloc((void **)&dr, bytes));
+    hipError_t e = hipMemcpy(dr, elem, bytes, hipMemcpyHostToDevice);
+    int rc = e == hipSuccess ? host_pipeline(c, data, data, nullptr, batch, [&](uint64_t *s0, uint64_t *, size_t n, hipStream_t st) {
+        return dev_mul_elem(c, s0, dr, n, st);
+    }) : fail(SR_E_HIP, std::string("mul_elem: ") + hipGetErrorString(e));
+    (void)hipFree(dr);   // host_pipeline returned with its stream synchronised
+    return rc;
 }
 int sr_ntt_fwd_batch(sr_ctx *c, uint64_t *data, size_t batch) { return host_inplace(c, data, batch, true); }
 int sr_ntt_inv_batch(sr_ctx *c, uint64_t *data, size_t batch) { return host_inplace(c, data, batch, false); }

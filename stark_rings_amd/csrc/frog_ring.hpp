@@ -9,7 +9,7 @@
 
 namespace sr {
 
-enum { FROG_CRT = 0, FROG_ICRT = 1, FROG_MUL = 2, FROG_RINGMUL = 3, FROG_REDUCE = 4 };
+enum { FROG_CRT = 0, FROG_ICRT = 1, FROG_MUL = 2, FROG_RINGMUL = 3, FROG_REDUCE = 4, FROG_MULB = 5 };  // MULB: slot product with ONE element b
 
 struct FrogConsts {
     uint64_t R[8];  // ROOTS_OF_UNITY_8[k] = w^k, w = 3^((p-1)/8), Montgomery form (ntt.rs:15-24)
@@ -111,9 +111,9 @@ __global__ __launch_bounds__(64) void frog16_kernel(FrogConsts k, const uint64_t
     for (int i = 0; i < 16; i++) x[i] = a[e * 16 + i];
     if (OP == FROG_CRT) frog_fwd(x, k);
     if (OP == FROG_ICRT) frog_inv(x, k);
-    if (OP == FROG_MUL || OP == FROG_RINGMUL) {
+    if (OP == FROG_MUL || OP == FROG_RINGMUL || OP == FROG_MULB) {
 #pragma unroll
-        for (int i = 0; i < 16; i++) y[i] = b[e * 16 + i];
+        for (int i = 0; i < 16; i++) y[i] = b[(OP == FROG_MULB ? 0 : e * 16) + i];
         if (OP == FROG_RINGMUL) {
             frog_fwd(x, k);
             frog_fwd(y, k);
@@ -164,6 +164,7 @@ inline int frog_launch(const FrogConsts &c, int op, const uint64_t *a, const uin
         case FROG_ICRT: hipLaunchKernelGGL(frog16_kernel<FROG_ICRT>, g, t, 0, st, c, a, b, out, batch); break;
         case FROG_MUL: hipLaunchKernelGGL(frog16_kernel<FROG_MUL>, g, t, 0, st, c, a, b, out, batch); break;
         case FROG_RINGMUL: hipLaunchKernelGGL(frog16_kernel<FROG_RINGMUL>, g, t, 0, st, c, a, b, out, batch); break;
+        case FROG_MULB: hipLaunchKernelGGL(frog16_kernel<FROG_MULB>, g, t, 0, st, c, a, b, out, batch); break;
         default: return 1;
     }
     return hipGetLastError() != hipSuccess;

@@ -239,6 +239,14 @@ __global__ __launch_bounds__(256) void pointwise_kernel(typename F::storage *lhs
     elementwise2<F>(lhs, rhs, n, [](const typename F::elem &a, const typename F::elem &b) { return F::mul_boundary(a, b); });
 }
 
+// lhs[e D + i] = lhs[e D + i] * r[i]: every element of the batch times ONE ring element, slot-wise -- `Matrix<R> *= &R`
+// (linear_algebra/src/matrix.rs:207-211), `SparseMatrix<R> *= &R` (sparse_matrix.rs:303-307).  D is a power of two; r stays in L2.
+template <class F>
+__global__ __launch_bounds__(256) void pointwise_bcast_kernel(typename F::storage *lhs, const typename F::storage *r, size_t n, size_t dmask) {
+    const size_t gid = blockIdx.x * (size_t)blockDim.x + threadIdx.x, stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = gid; i < n; i += stride) F::store(lhs + i, F::mul_boundary(F::load(lhs + i), F::load(r + (i & dmask))));
+}
+
 // lhs[i] = lhs[i] +- rhs[i] coefficient-wise: RqNTT / RqPoly Add and Sub (ntt_form.rs:227-285, 588-638; coeff_form.rs
 // operator impls) -- the same in either form and for every ring, the slots being Fp-vector spaces
 template <class F, bool SUB>

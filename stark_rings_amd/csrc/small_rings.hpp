@@ -19,7 +19,7 @@ enum {
     SMALL_G24_CRT, SMALL_G24_ICRT, SMALL_G24_MUL, SMALL_G24_RINGMUL, SMALL_G24_REDUCE,
     SMALL_B72_CRT, SMALL_B72_ICRT, SMALL_B72_MUL, SMALL_B72_RINGMUL, SMALL_B72_REDUCE
 };
-enum { SOP_CRT = 0, SOP_ICRT = 1, SOP_MUL = 2, SOP_RINGMUL = 3 };
+enum { SOP_CRT = 0, SOP_ICRT = 1, SOP_MUL = 2, SOP_RINGMUL = 3, SOP_MULB = 5 };  // MULB: slot product with ONE element b for the whole batch
 
 // ROOTS_OF_UNITY_24[k] = omega^k, omega = g^((p-1)/24) (goldilocks/ntt.rs:15-40, babybear/ntt.rs:16-41),
 // KAPPA = (2 zeta - 1)^-1, 1/8, 1/4 (goldilocks/ntt.rs:42-47, babybear/ntt.rs:136-141); table form, 64-bit slots.
@@ -314,7 +314,12 @@ __global__ __launch_bounds__(64, (small_staged<F, D, W, OP>() && D == 24 ? 4 : 3
         small_inv3<F, D>(x, k);
     } else {
         E y[D];
-        small_get<F, D, STAGED>(lds, b, first, batch, y);
+        if (OP == SOP_MULB) {
+#pragma unroll
+            for (int i = 0; i < D; i++) y[i] = F::load(b + i);
+        } else {
+            small_get<F, D, STAGED>(lds, b, first, batch, y);
+        }
         if (OP == SOP_RINGMUL) {
             small_fwd3<F, D>(x, k);
             small_homogenize<F, W>(x, k);
@@ -402,6 +407,7 @@ inline int small_dispatch(const SmallRingConsts &c, int op, const uint64_t *a, c
         case SOP_ICRT: hipLaunchKernelGGL((small_ring_kernel<F, D, W, SOP_ICRT>), g, t, 0, st, c, a, b, out, batch); break;
         case SOP_MUL: hipLaunchKernelGGL((small_ring_kernel<F, D, W, SOP_MUL>), g, t, 0, st, c, a, b, out, batch); break;
         case SOP_RINGMUL: hipLaunchKernelGGL((small_ring_kernel<F, D, W, SOP_RINGMUL>), g, t, 0, st, c, a, b, out, batch); break;
+        case SOP_MULB: hipLaunchKernelGGL((small_ring_kernel<F, D, W, SOP_MULB>), g, t, 0, st, c, a, b, out, batch); break;
         default: return 1;
     }
     return hipGetLastError() != hipSuccess;
@@ -411,6 +417,10 @@ inline int small_launch(const SmallRingConsts &c, int op, const uint64_t *a, con
                         uint64_t *out, size_t batch, hipStream_t st) {
     if (op <= SMALL_G24_REDUCE) return small_dispatch<Goldilocks, 24, 3>(c, op - SMALL_G24_CRT, a, b, in_len, out, batch, st);
     return small_dispatch<BabyBear, 72, 9>(c, op - SMALL_B72_CRT, a, b, in_len, out, batch, st);
+}
+// a[e] *= b[0] slot-wise for every element e of the batch (Matrix<R> *= &R, matrix.rs:207-211)
+inline int small_launch_mul_bcast(const SmallRingConsts &c, bool b72, uint64_t *a, const uint64_t *b, size_t batch, hipStream_t st) {
+    return b72 ? small_dispatch<BabyBear, 72, 9>(c, SOP_MULB, a, b, 0, a, batch, st) : small_dispatch<Goldilocks, 24, 3>(c, SOP_MULB, a, b, 0, a, batch, st);
 }
 
 }  // namespace sr

@@ -181,6 +181,15 @@ class CyclotomicRing:
         self._check(self._lib.sr_scale_batch(self._ctx, _np_ptr(data), _np_ptr(s), self._batch_of(data.size)))
         return data
 
+    def mul_elem(self, data, elem):
+        """`Matrix<R> *= &R` / `SparseMatrix<R> *= &R` (linear_algebra/src/matrix.rs:207-211, sparse_matrix.rs:303-307) on the
+        matrix's flat storage: every element of the batch (CRT/NTT form) times ONE ring element, slot-wise, in place."""
+        if elem.size != self.words_per_elem:
+            raise RingError("mul_elem: the multiplier is not one ring element")
+        if data.size:
+            self._check(self._lib.sr_mul_elem_batch(self._ctx, _np_ptr(data), _np_ptr(elem), self._batch_of(data.size)))
+        return data
+
     def add_scalar(self, data, scalar, ntt_form):
         """Add<primitive> (coeff_form.rs:652-700: coefficient 0 of every element; ntt_form.rs:427-505: component 0 of every slot);
         Sub: pass the negated scalar.  In place."""
@@ -509,6 +518,14 @@ class CyclotomicRing:
         p, n = self._dev(t)
         s = self._scalar(scalar)
         self._check(self._lib.sr_scale_batch_dev(self._ctx, p, _np_ptr(s), self._batch_of(n), self._stream(stream)))
+        return t
+
+    def mul_elem_dev(self, t, elem, stream=None):
+        p, n = self._dev(t)
+        pe, ne = self._dev(elem)
+        if ne != self.words_per_elem:
+            raise RingError("mul_elem: the multiplier is not one ring element")
+        self._check(self._lib.sr_mul_elem_batch_dev(self._ctx, p, pe, self._batch_of(n), self._stream(stream)))
         return t
 
     def add_scalar_dev(self, t, scalar, ntt_form, stream=None):

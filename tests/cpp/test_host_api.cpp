@@ -221,6 +221,35 @@ static void linalg_suite(sr_ring ring, int field, int log2d) {
         EXPECT(elem(sy->words(), 2) == dot({{elem(A, 5), elem(v, 0)}}));
     }
     EXPECT(!S.checked_mul_vec(RqNTTVec(cfg, uniform(field, 25, (m + 2) * d))).has_value());
+    // MulAssign<&R> for Matrix<R> / SparseMatrix<R> (matrix.rs:207-211, sparse_matrix.rs:303-307): every entry times one ring element;
+    // (r M) v == r (M v) entry by entry
+    {
+        RqNTTVec R(cfg, elem(B, 1));
+        MatrixNTT MR(cfg, n, m, A);
+        MR *= R;
+        for (size_t i = 0; i < n * m; i++) {
+            RqNTTVec x(cfg, elem(A, i));
+            x *= R;
+            EXPECT(elem(MR.words(), i) == x.words());
+        }
+        auto ry = MR.checked_mul_vec(V);
+        RqNTTVec scaled(cfg, y ? y->words() : std::vector<uint64_t>(n * w, 0));
+        scaled.mul_assign_elem(R);
+        EXPECT(ry.has_value() && ry->words() == scaled.words());
+        SparseMatrixNTT SR(cfg, 3, m, rows);
+        SR *= R;
+        auto sry = SR.checked_mul_vec(V);
+        RqNTTVec sscaled(cfg, sy ? sy->words() : std::vector<uint64_t>(3 * w, 0));
+        sscaled.mul_assign_elem(R);
+        EXPECT(sry.has_value() && sry->words() == sscaled.words());
+        threw = false;
+        try {
+            MR *= RqNTTVec(cfg, uniform(field, 26, 2 * d));
+        } catch (const std::length_error &) {
+            threw = true;
+        }
+        EXPECT(threw);
+    }
     rows[1] = {{elem(A, 3), m}};  // column out of range: the reference panics on v[col]
     threw = false;
     try {

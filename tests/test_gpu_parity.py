@@ -1798,10 +1798,11 @@ def test_library_settles_the_lanes_plan_itself(torch_cuda):
 @pytest.mark.gpu
 @pytest.mark.parametrize("name,k,batch", [("goldilocks", 16, 16384), ("babybear", 16, 16384), ("goldilocks", 20, 1024)])
 def test_probe_measures_the_plan_it_picks(torch_cuda, name, k, batch):
-    """the probe times the STEADY STATE of both plans (two lanes: t(16 chunks) - t(4 chunks); one stream: one set of
-    launches), so its one-stream / two-lane ratio must be the ratio the full batch shows when each plan is forced -- BASELINE configs
-    2 and 3 at full size, config 4's degree on 1024 elements.  A context that never reserves scratch never probes: two lanes,
-    unmeasured, and its first product does not block on a measurement."""
+    """the probe runs each plan the way it runs a batch (up to 32 chunks, warmed up, on the context's own streams), so
+    its one-stream / two-lane ratio must be the ratio the full batch shows when each plan is forced -- BASELINE configs 2 and 3 at
+    full size, config 4's degree on 1024 elements.  A context that never reserves scratch never probes: two lanes, unmeasured, and
+    its first product does not block on a measurement.  A context created while six foreign streams exist (and have run work: their
+    hardware queues are mapped) still picks the faster plan."""
     torch = torch_cuda
     import time
     from stark_rings_amd import CyclotomicRing
@@ -1850,6 +1851,19 @@ def test_probe_measures_the_plan_it_picks(torch_cuda, name, k, batch):
     assert (plan.lanes == 2) == (ratio_probe > 1.0)
     if abs(ratio_full - 1.0) > 0.04:
         assert (plan.lanes == 2) == (ratio_full > 1.0), "the probe picked the slower plan"
+    foreign = [torch.cuda.Stream() for _ in range(6)]
+    for st in foreign:
+        with torch.cuda.stream(st):
+            torch.zeros(1 << 20, device="cuda").add_(1)
+    torch.cuda.synchronize()
+    crowded = CyclotomicRing(name, k, plan=Plan())
+    crowded.reserve_scratch(batch)
+    plan_c, probe_c = crowded.plan_in_use()
+    crowded.close()
+    print("  beside six foreign streams: one/two = %.4f, picked %d lanes" % (probe_c["one_stream_ms"] / probe_c["two_lanes_ms"], plan_c.lanes))
+    if abs(ratio_full - 1.0) > 0.04:
+        assert (plan_c.lanes == 2) == (ratio_full > 1.0), "beside six foreign streams the probe picked the slower plan"
+    del foreign
 
 
 @pytest.mark.parametrize("k,batch", [(0, 7), (4, 5), (10, 37), (12, 5), (13, 3), (14, 2), (16, 5), (17, 1)])
@@ -2159,9 +2173,49 @@ def test_neg_scale_and_add_scalar_match_integer_arithmetic(torch_cuda, name, k):
             ring.scale(a.copy(), np.array([(1 << 32) + 5], dtype=np.uint64))
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,k,batch", [("goldilocks", 6, 5), ("goldilocks", 16, 3), ("babybear", 5, 9), ("stark", 4, 7), ("stark", 12, 2),
+                                          ("goldilocks24", 0, 131), ("babybear72", 0, 67), ("frog16", 0, 200)])
+def test_matrix_times_one_ring_element(torch_cuda, name, k, batch):
+    """`MulAssign<&R> for Matrix<R>` (linear_algebra/src/matrix.rs:207-211) and `for SparseMatrix<R>` (sparse_matrix.rs:303-307):
+    every entry of the matrix's flat storage times ONE ring element, slot-wise (Fq3 / Fq9 / Fq4 slot products on the reference's own
+    rings; batches that leave ragged last workgroups).  Against the slot product with the element repeated (itself pinned to the
+    oracle by the tests above), against the oracle directly on the power-of-two rings, host and device entry points; edge
+    multipliers 0 and 1; a multiplier that is not one element or lies inside the batch is refused."""
+    torch = torch_cuda
+    from stark_rings_amd import RingError
+
+    base = {"goldilocks24": "goldilocks", "babybear72": "babybear", "frog16": "frog"}.get(name, name)
+    F = O.FIELD_ID[base]
+    ring = ring_for(name, k)
+    w = ring.words_per_elem
+    a = O.fill_uniform(F, 0x7A0 + k, 0, batch * ring.degree)
+    r = O.fill_uniform(F, 0x7B0 + k, 0, ring.degree)
+    want = ring.ntt_mul(a.copy(), np.tile(r, batch))
+    assert np.array_equal(ring.mul_elem(a.copy(), r), want)
+    ta = torch.from_numpy(a.copy().view(np.int64)).cuda()
+    tr = torch.from_numpy(r.view(np.int64)).cuda()
+    ring.mul_elem_dev(ta, tr)
+    torch.cuda.synchronize()
+    assert np.array_equal(ta.cpu().numpy().view(np.uint64), want)
+    if name in ("goldilocks", "babybear", "stark"):
+        for e in (0, batch - 1):
+            assert np.array_equal(want[e * w:(e + 1) * w], O.pow2_pointwise(F, a[e * w:(e + 1) * w], r)), e
+    one = O.to_mont(F, [1] * ring.degree) if name in ("goldilocks", "babybear", "stark") else None
+    if one is not None:     # the multiplicative identity of the fully split rings: 1 in every slot
+        assert np.array_equal(ring.mul_elem(a.copy(), one), a)
+    assert not ring.mul_elem(a.copy(), np.zeros(w, dtype=np.uint64)).any()
+    assert ring.mul_elem(np.zeros(0, dtype=np.uint64), r).size == 0
+    with pytest.raises(RingError, match="one ring element"):
+        ring.mul_elem(a.copy(), np.tile(r, 2))
+    with pytest.raises(RingError, match="inside the batch"):
+        ring.mul_elem_dev(ta, ta[w:2 * w] if batch > 1 else ta)
+
+
 # ----------------------------------------------------------------------------- round 4: the column pass that keeps its twist factors
 @pytest.mark.gpu
-@pytest.mark.parametrize("k,batch,chunk", [(16, 272, 0), (16, 264, 64), (16, 40, 8), (17, 136, 0), (18, 72, 0), (20, 24, 0), (20, 17, 8)])
+@pytest.mark.parametrize("k,batch,chunk", [(16, 272, 0), (16, 264, 64), (16, 40, 8), (16, 48, 24), (16, 32, 16), (16, 200, 40),
+                                           (17, 136, 0), (18, 72, 0), (20, 24, 0), (20, 17, 8)])
 def test_keep_and_plain_column_passes_agree(torch_cuda, k, batch, chunk):
     """Round 4: on the two-lane plans a column-pass workgroup owns one column chunk and walks over the ring elements of the launch
     with its 16 twist factors in registers (cols256_keep_kernel; launches whose element count is a multiple of 8 -- the rest, here
