@@ -46,7 +46,7 @@ while time.time() < t_end:
         vals = [special[int(rng.integers(0, len(special)))] for _ in range(d)]
         a[:d * O.LIMBS[F]] = O.to_mont(F, vals)
     op = ["crt", "icrt", "mul", "ntt_mul", "add", "sub", "reduce", "decompose", "rot", "matvec", "wire", "neg", "scale", "add_scalar",
-          "mul_ntt_rhs"][int(rng.integers(0, 15))]
+          "mul_ntt_rhs", "mul_elem"][int(rng.integers(0, 16))]
     ok = True
     if op == "crt":
         ok = np.array_equal(r.elementwise_crt(a.copy()), O.pow2_fwd(F, a, k, batch, 4)) if batch else True
@@ -112,6 +112,11 @@ while time.time() < t_end:
             ok = O.from_mont(F, r.add_scalar(a.copy(), img, ntt)) == want
     elif op == "mul_ntt_rhs" and batch:
         ok = np.array_equal(r.mul_ntt_rhs(a, O.pow2_fwd(F, b, k, batch, 4)), O.pow2_ring_mul(F, a, b, k, batch, 4))
+    elif op == "mul_elem" and batch:   # Matrix<R> *= &R: every element times the first element of b
+        L = O.LIMBS[F]
+        one = b[:d * L].copy()
+        got = r.mul_elem(a.copy(), one)
+        ok = all(np.array_equal(got[e * d * L:(e + 1) * d * L], O.pow2_pointwise(F, a[e * d * L:(e + 1) * d * L], one)) for e in range(batch))
     elif op == "wire" and batch:
         wire = r.serialize(a)
         ok = np.array_equal(wire, O.serialize(F, a)) and np.array_equal(r.deserialize(wire), a)
@@ -119,5 +124,15 @@ while time.time() < t_end:
     by_op[op] = by_op.get(op, 0) + 1
     if not ok:
         print("MISMATCH: %s k=%d batch=%d op=%s seed=%d" % (name, k, batch, op, seed))
+        sys.exit(1)
+if os.environ.get("SR_LIB_PATH", "").endswith("_check.so"):   # the invariant-checking build: its counters must have stayed at zero
+    import ctypes
+
+    from stark_rings_amd import _lib
+    buf = (ctypes.c_uint64 * 8)()
+    assert _lib.load().sr_selftest_rep_counters(buf, 0) == 0
+    c = [int(v) for v in buf]
+    print("checking build: invariant counters %s, largest Stark limb %d" % (c[:7], c[7]))
+    if any(c[:7]):
         sys.exit(1)
 print("random differential soak: %d checks in %.0f s, 0 mismatches; per op %s" % (n_checks, budget, by_op))
