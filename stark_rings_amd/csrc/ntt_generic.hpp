@@ -244,7 +244,27 @@ __global__ __launch_bounds__(256) void pointwise_kernel(typename F::storage *lhs
 template <class F>
 __global__ __launch_bounds__(256) void pointwise_bcast_kernel(typename F::storage *lhs, const typename F::storage *r, size_t n, size_t dmask) {
     const size_t gid = blockIdx.x * (size_t)blockDim.x + threadIdx.x, stride = (size_t)gridDim.x * blockDim.x;
-    for (size_t i = gid; i < n; i += stride) F::store(lhs + i, F::mul_boundary(F::load(lhs + i), F::load(r + (i & dmask))));
+    size_t done = 0;
+    if constexpr (sizeof(typename F::storage) == 8) {
+        if (dmask != 0 && (((uintptr_t)lhs | (uintptr_t)r) & 15u) == 0) {   // D >= 2: a pair of coefficients never straddles two elements
+            typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+            const size_t pairs = n >> 1, pmask = dmask >> 1;
+            u64x2 *l2 = reinterpret_cast<u64x2 *>(lhs);
+            const u64x2 *r2 = reinterpret_cast<const u64x2 *>(r);
+            for (size_t i = gid; i < pairs; i += stride) {
+                u64x2 x = __builtin_nontemporal_load(l2 + i);
+                const u64x2 y = r2[i & pmask];
+                typename F::storage xs[2] = {x.x, x.y}, ys[2] = {y.x, y.y};
+                F::store(&xs[0], F::mul_boundary(F::load(&xs[0]), F::load(&ys[0])));
+                F::store(&xs[1], F::mul_boundary(F::load(&xs[1]), F::load(&ys[1])));
+                x.x = xs[0];
+                x.y = xs[1];
+                __builtin_nontemporal_store(x, l2 + i);
+            }
+            done = pairs << 1;
+        }
+    }
+    for (size_t i = done + gid; i < n; i += stride) F::store(lhs + i, F::mul_boundary(F::load(lhs + i), F::load(r + (i & dmask))));
 }
 
 // lhs[i] = lhs[i] +- rhs[i] coefficient-wise: RqNTT / RqPoly Add and Sub (ntt_form.rs:227-285, 588-638; coeff_form.rs

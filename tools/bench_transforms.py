@@ -17,8 +17,10 @@ for name, k, batch in (("goldilocks", 16, 1 << 14), ("babybear", 16, 1 << 14), (
     b = torch.empty(n, dtype=torch.int64, device="cuda")
     ring.fill_uniform_dev(a, 1)
     ring.fill_uniform_dev(b, 2)
+    one = b[:ring.words_per_elem].clone()
     for op, fn, streams in (("crt", lambda: ring.elementwise_crt_dev(a), 2), ("icrt", lambda: ring.elementwise_icrt_dev(a), 2),
-                            ("slot product", lambda: ring.ntt_mul_dev(a, b), 3)):
+                            ("slot product", lambda: ring.ntt_mul_dev(a, b), 3),
+                            ("x one element", lambda: ring.mul_elem_dev(a, one), 2)):   # Matrix<R> *= &R: read + write the batch
         fn()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
