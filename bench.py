@@ -373,9 +373,14 @@ def main():
     value = total_muls / elapsed
     bytes_per_mul = 3 * d * coeff_bytes  # read a, read b, write c
     kern = {t: v for t, v in prof.items() if v["launches"]}
-    # dominant kernel = the longest single launch of the step (the two forward column launches together take about as long as
-    # the rows launch at D = 2^16, so "largest total" would flip between runs; the per-launch figure is stable)
-    dom_tag = max(kern, key=lambda t: kern[t]["ms"] / kern[t]["launches"])
+    # dominant kernel = the longest single launch of the step.  Since the forward column passes of both operands are ONE launch, that
+    # launch and the rows launch take about equally long at D = 2^16 (and did in total before): the rows kernel -- the one that moves
+    # and computes the most per ring element -- stays the subject unless another launch is clearly (> 10 %) longer, so that the tag
+    # does not flip between runs.
+    per_launch = {t: kern[t]["ms"] / kern[t]["launches"] for t in kern}
+    dom_tag = max(per_launch, key=per_launch.get)
+    if "rows" in per_launch and per_launch["rows"] >= 0.9 * per_launch[dom_tag]:
+        dom_tag = "rows"
     dom = kern[dom_tag]
     launches_per_step = dom["launches"] / args.steps
     dom_avg_ms = dom["ms"] / dom["launches"]
@@ -393,7 +398,8 @@ def main():
         kernel_bytes_per_elem = 2 * d * wk
     if k <= 12 and ring_name != "stark" or launches_per_step == 0:
         kernel_bytes_per_elem = bytes_per_mul  # one fused launch at the boundary layout
-    alg_bytes_per_launch = kernel_bytes_per_elem * batch / max(launches_per_step, 1e-9) * (2 if dom_tag == "fwd_cols" else 1)
+    fwd_operands = 2 if args.variant == "mul" else 1   # operands whose forward column pass runs in a step (one launch or two)
+    alg_bytes_per_launch = kernel_bytes_per_elem * batch / max(launches_per_step, 1e-9) * (fwd_operands if dom_tag == "fwd_cols" else 1)
     achieved_gbs = alg_bytes_per_launch / (dom_avg_ms * 1e-3) / 1e9
     step_gbs = bytes_per_mul * batch * world / (elapsed / args.steps) / 1e9 / world
 
@@ -479,7 +485,7 @@ def main():
     if prof_single:
         # what `kernel_avg_ms` above means when launches of two streams overlap, and the one-stream figures next to it
         ps = prof_single[dom_tag]
-        s_launch_bytes = kernel_bytes_per_elem * batch / (ps["launches"] / ps["steps"]) * (2 if dom_tag == "fwd_cols" else 1)
+        s_launch_bytes = kernel_bytes_per_elem * batch / (ps["launches"] / ps["steps"]) * (fwd_operands if dom_tag == "fwd_cols" else 1)
         s_avg = ps["ms"] / ps["launches"]
         out["roofline"]["overlap"] = {
             "internal_streams": 2, "kernel_ms_in_flight_per_step": in_flight, "factor": in_flight / (elapsed / args.steps * 1e3),

@@ -670,6 +670,17 @@ __global__ __launch_bounds__(16 << LC, 4) void cols256_kernel(u64 *data, const u
     __syncthreads();
     cols256_tile<DIR, LC>(xcd_tile(blockIdx.x, kColsXcdGroup, grouped), data, src, k, wl, twist, lds);
 }
+// the forward passes of BOTH operands of a ring product in one launch: blockIdx.y picks the operand (grid.x as for one operand)
+template <int LC>
+__global__ __launch_bounds__(16 << LC, 4) void cols256_pair_kernel(u64 *data_a, const u64 *src_a, u64 *data_b, const u64 *src_b, int k,
+                                                                   const u64 *__restrict__ wc, const u64 *__restrict__ twist,
+                                                                   unsigned grouped) {
+    __shared__ u64 lds[ColsTile<LC>::kElems];
+    __shared__ u64 wl[256];
+    if (threadIdx.x < 256) wl[threadIdx.x] = wc[threadIdx.x];
+    __syncthreads();
+    cols256_tile<0, LC>(xcd_tile(blockIdx.x, kColsXcdGroup, grouped), blockIdx.y ? data_b : data_a, blockIdx.y ? src_b : src_a, k, wl, twist, lds);
+}
 
 // ------------------------------------------------------------------------------------------------
 // cols256_keep: the same column pass for the SMALL launches of the two-lane plans (gl_fast_*_lanes: 64 MiB of coefficients per
@@ -687,10 +698,13 @@ __global__ __launch_bounds__(16 << LC, 4) void cols256_kernel(u64 *data, const u
 // group * chunks + ci; the workgroup handles ring elements xcd + 8 (group + groups r), r = 0, 1, ...: all column chunks of a ring
 // element are in flight on ONE XCD at the same time (what xcd_tile() arranges for the plain launch).  Same values bit for bit
 // (tests/test_gpu_parity.py: test_keep_and_plain_column_passes_agree).  grid.x = 8 * (N2 / 16) * groups; npoly a multiple of 8.
+// data2 / src2 != nullptr: the forward pass of a SECOND operand (b of a ring product) in the same launch, walked over behind the first
+// by the same workgroups with the same factors: one launch boundary per lane chunk fewer (-1.1 % on the config-2 step).
 // ------------------------------------------------------------------------------------------------
 template <int DIR>
-__global__ __launch_bounds__(256, 3) void cols256_keep_kernel(u64 *data, const u64 *src, int k, const u64 *__restrict__ wc,
-                                                              const u64 *__restrict__ twist, unsigned npoly, unsigned groups) {
+__global__ __launch_bounds__(256, 3) void cols256_keep_kernel(u64 *data, const u64 *src, u64 *data2, const u64 *src2, int k,
+                                                              const u64 *__restrict__ wc, const u64 *__restrict__ twist, unsigned npoly,
+                                                              unsigned groups) {
     using CT = ColsTile<4>;
     __shared__ u64 lds[CT::kElems];
     __shared__ u64 wl[256];
@@ -710,9 +724,13 @@ __global__ __launch_bounds__(256, 3) void cols256_keep_kernel(u64 *data, const u
 #pragma unroll
     for (int sg = 0; sg < 16; sg++) tw[sg] = *reinterpret_cast<const u64 *>(tb + (offB0 + (unsigned)sg * leg));
     __syncthreads();
-    for (unsigned poly = xcd + 8u * grp; poly < npoly; poly += 8u * groups) {  // uniform per workgroup: every lane reaches every barrier
-        char *pb = reinterpret_cast<char *>(data + ((size_t)poly << k));
-        const char *ps = reinterpret_cast<const char *>(src + ((size_t)poly << k));
+    // data2 != nullptr: a second operand (the forward passes of a and b of a ring product) in the same launch, behind the first
+    const unsigned total = data2 ? 2u * npoly : npoly;
+    for (unsigned it = xcd + 8u * grp; it < total; it += 8u * groups) {  // uniform per workgroup: every lane reaches every barrier
+        const bool second = it >= npoly;
+        const unsigned poly = second ? it - npoly : it;
+        char *pb = reinterpret_cast<char *>((second ? data2 : data) + ((size_t)poly << k));
+        const char *ps = reinterpret_cast<const char *>((second ? src2 : src) + ((size_t)poly << k));
         // opaque per iteration: otherwise the 32 per-access offsets are hoisted out of the loop as invariants and live across it
         unsigned offA = offA0, offB = offB0;
         asm volatile("" : "+v"(offA), "+v"(offB));
@@ -1217,7 +1235,28 @@ inline int gl_launch_cols256_lane(const GoldilocksFastTables &f, uint64_t *data,
         return gl_launch_cols256<DIR>(f, data, src, npoly, wc, twist, st);
     if (groups > npoly / 16) groups = (unsigned)(npoly / 16);
     GlProfScope ps(f, DIR == 0 ? 0 : 2, st);
-    hipLaunchKernelGGL((gl::cols256_keep_kernel<DIR>), dim3(8u * chunks * groups), dim3(256), 0, st, data, src, f.k, wc, twist,
+    hipLaunchKernelGGL((gl::cols256_keep_kernel<DIR>), dim3(8u * chunks * groups), dim3(256), 0, st, data, src, (uint64_t *)nullptr,
+                       (const uint64_t *)nullptr, f.k, wc, twist, (unsigned)npoly, groups);
+    return hipGetLastError() != hipSuccess;
+}
+// the forward column passes of BOTH operands of a ring product in one launch (the same workgroups, their twist factors loaded once,
+// walk over the elements of a and then of b); falls back to two launches where the persistent kernel does not apply
+inline int gl_launch_cols256_lane_pair(const GoldilocksFastTables &f, uint64_t *da, const uint64_t *sa, uint64_t *db, const uint64_t *sb,
+                                       size_t npoly, hipStream_t st) {
+    const unsigned chunks = 1u << (f.k - 12);
+    unsigned groups = chunks >= 128 ? 1u : 128u / chunks;
+    if (!f.keep_cols || f.k != 16 || (npoly & 7u) != 0 || npoly < 16u || npoly > 0x3FFFFFFFull) {
+        GlProfScope ps(f, 0, st);
+        constexpr int LC = 4;
+        const size_t blocks = npoly << (f.k - 8 - LC);
+        if (blocks == 0 || blocks > 0x7FFFFFFFull) return 1;
+        hipLaunchKernelGGL((gl::cols256_pair_kernel<LC>), dim3((unsigned)blocks, 2), dim3(16 << LC), 0, st, da, sa, db, sb, f.k, f.t.wcf,
+                           f.t.twist_f, xcd_grouped_tiles(blocks, gl::kColsXcdGroup));
+        return hipGetLastError() != hipSuccess;
+    }
+    if (groups > npoly / 16) groups = (unsigned)(npoly / 16);
+    GlProfScope ps(f, 0, st);
+    hipLaunchKernelGGL((gl::cols256_keep_kernel<0>), dim3(8u * chunks * groups), dim3(256), 0, st, da, sa, db, sb, f.k, f.t.wcf, f.t.twist_f,
                        (unsigned)npoly, groups);
     return hipGetLastError() != hipSuccess;
 }
@@ -1345,8 +1384,7 @@ inline int gl_fast_ring_mul_lanes(const GoldilocksFastTables &f, uint64_t *out, 
     for (size_t e = 0; e < batch && !rc; e += L.chunk, c++) {
         const int i = (int)(c % (size_t)L.n);
         const size_t n = batch - e < L.chunk ? batch - e : L.chunk;
-        rc = gl_launch_cols256_lane<0>(f, L.sa[i], a + e * stride, n, f.t.wcf, f.t.twist_f, L.st[i]);
-        if (!rc) rc = gl_launch_cols256_lane<0>(f, L.sb[i], b + e * stride, n, f.t.wcf, f.t.twist_f, L.st[i]);
+        rc = gl_launch_cols256_lane_pair(f, L.sa[i], a + e * stride, L.sb[i], b + e * stride, n, L.st[i]);
         if (!rc) rc = gl_launch_rows<2>(f, L.sa[i], L.sb[i], L.sa[i], n, true, L.st[i]);
         if (!rc) rc = gl_launch_cols256_lane<1>(f, out + e * stride, L.sa[i], n, f.t.wci, f.t.twist_i_mul, L.st[i]);
     }

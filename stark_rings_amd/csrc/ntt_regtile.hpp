@@ -323,8 +323,13 @@ __global__ __launch_bounds__(256) void strided_kernel(const typename View<F, VI>
 constexpr int kXcdGroup = 3;  // 8 consecutive tiles per XCD turn: 1 KiB (4-byte words, 32 columns) or 1 KiB (8-byte, 16 columns) of every leg
 template <class F, int DIR, class VI, class VO, int COLS>
 __global__ __launch_bounds__(16 * COLS) void cols256_kernel(const typename View<F, VI>::T *src, typename View<F, VO>::T *dst,
+                                                            const typename View<F, VI>::T *src2, typename View<F, VO>::T *dst2,
                                                             Params<F> p, unsigned grouped) {
     using E = typename F::elem;
+    if (blockIdx.y) {  // grid.y = 2: the forward passes of both operands of a ring product in one launch
+        src = src2;
+        dst = dst2;
+    }
     // [leg][column] words; COLS = 32 for 4-byte elements so that a leg's segment is a whole 128-byte line on the packed side
     __shared__ E lds[256 * COLS + 16 * COLS];
     constexpr int LC = COLS == 32 ? 5 : 4;
@@ -504,7 +509,19 @@ inline int launch_cols256(const Hooks &hk, const typename View<F, VI>::T *src, t
     const size_t blocks = (npoly << (p.k - 8)) / COLS;
     if (blocks == 0 || blocks > 0x7FFFFFFFull) return 1;
     Scope sc(hk, DIR == 0 ? 0 : 2, st);
-    hipLaunchKernelGGL((cols256_kernel<F, DIR, VI, VO, COLS>), dim3((unsigned)blocks), dim3(16 * COLS), 0, st, src, dst, p,
+    hipLaunchKernelGGL((cols256_kernel<F, DIR, VI, VO, COLS>), dim3((unsigned)blocks), dim3(16 * COLS), 0, st, src, dst,
+                       (const typename View<F, VI>::T *)nullptr, (typename View<F, VO>::T *)nullptr, p, xcd_grouped_tiles(blocks, kXcdGroup));
+    return hipGetLastError() != hipSuccess;
+}
+// the forward column passes of both operands of a ring product in ONE launch (grid.y = 2)
+template <class F, class VB>
+inline int launch_cols256_pair(const Hooks &hk, const typename View<F, VB>::T *a, typename F::elem *da, const typename View<F, VB>::T *b,
+                               typename F::elem *db, size_t npoly, const Params<F> &p, hipStream_t st) {
+    constexpr int COLS = sizeof(typename F::elem) == 4 ? 32 : 16;
+    const size_t blocks = (npoly << (p.k - 8)) / COLS;
+    if (blocks == 0 || blocks > 0x7FFFFFFFull) return 1;
+    Scope sc(hk, 0, st);
+    hipLaunchKernelGGL((cols256_kernel<F, 0, VB, Packed, COLS>), dim3((unsigned)blocks, 2), dim3(16 * COLS), 0, st, a, da, b, db, p,
                        xcd_grouped_tiles(blocks, kXcdGroup));
     return hipGetLastError() != hipSuccess;
 }
@@ -577,8 +594,12 @@ inline int ring_mul(const Hooks &hk, typename View<F, VB>::T *out, const typenam
                     size_t batch, const Params<F> &p, typename F::elem *scratch0, typename F::elem *scratch1, hipStream_t st) {
     if (batch == 0) return 0;
     if (p.c == 0) return launch_rows<F, 2, VB, VB>(hk, a, b, out, batch, p, st);
-    if (strided_fwd<F, VB>(hk, a, scratch0, batch, p, st)) return 1;
-    if (strided_fwd<F, VB>(hk, b, scratch1, batch, p, st)) return 1;
+    if (use_cols256(p)) {
+        if (launch_cols256_pair<F, VB>(hk, a, scratch0, b, scratch1, batch, p, st)) return 1;
+    } else {
+        if (strided_fwd<F, VB>(hk, a, scratch0, batch, p, st)) return 1;
+        if (strided_fwd<F, VB>(hk, b, scratch1, batch, p, st)) return 1;
+    }
     if (launch_rows<F, 2, Packed, Packed>(hk, scratch0, scratch1, scratch0, batch, p, st)) return 1;
     return strided_inv<F, VB>(hk, scratch0, out, batch, p, st);
 }

@@ -1834,11 +1834,12 @@ def test_probe_measures_the_plan_it_picks(torch_cuda, name, k, batch):
         r.mul_dev(out, ta, tb)
         torch.cuda.synchronize()
         best = None
-        for _ in range(3):
+        for _ in range(4):      # the best of four samples of two back-to-back batches each
             t0 = time.perf_counter()
             r.mul_dev(out, ta, tb)
+            r.mul_dev(out, ta, tb)
             torch.cuda.synchronize()
-            ms = (time.perf_counter() - t0) * 1e3
+            ms = (time.perf_counter() - t0) * 1e3 / 2
             best = ms if best is None or ms < best else best
         r.close()
         return best
@@ -1847,9 +1848,10 @@ def test_probe_measures_the_plan_it_picks(torch_cuda, name, k, batch):
     ratio_full, ratio_probe = one / two, probe["one_stream_ms"] / probe["two_lanes_ms"]
     print("probe %s D=2^%d: probe one/two = %.4f (%.3f / %.3f ms per %d), full batch one/two = %.4f (%.3f / %.3f ms per %d); picked %d lanes"
           % (name, k, ratio_probe, probe["one_stream_ms"], probe["two_lanes_ms"], probe["elems"], ratio_full, one, two, batch, plan.lanes))
-    assert abs(ratio_probe - ratio_full) < 0.04 * ratio_full, (ratio_probe, ratio_full)
+    # typically within 2 %; 6 % here: one box in a dozen showed 4.7 % between two separately timed runs of the same plan
+    assert abs(ratio_probe - ratio_full) < 0.06 * ratio_full, (ratio_probe, ratio_full)
     assert (plan.lanes == 2) == (ratio_probe > 1.0)
-    if abs(ratio_full - 1.0) > 0.04:
+    if abs(ratio_full - 1.0) > 0.06:
         assert (plan.lanes == 2) == (ratio_full > 1.0), "the probe picked the slower plan"
     foreign = [torch.cuda.Stream() for _ in range(6)]
     for st in foreign:
@@ -1861,7 +1863,7 @@ def test_probe_measures_the_plan_it_picks(torch_cuda, name, k, batch):
     plan_c, probe_c = crowded.plan_in_use()
     crowded.close()
     print("  beside six foreign streams: one/two = %.4f, picked %d lanes" % (probe_c["one_stream_ms"] / probe_c["two_lanes_ms"], plan_c.lanes))
-    if abs(ratio_full - 1.0) > 0.04:
+    if abs(ratio_full - 1.0) > 0.06:
         assert (plan_c.lanes == 2) == (ratio_full > 1.0), "beside six foreign streams the probe picked the slower plan"
     del foreign
 

@@ -84,6 +84,8 @@ def tag_of(kernel):
     k = kernel.replace("void ", "")
     if "build" in k or "fill_uniform" in k or "count_noncanonical" in k or "addsub" in k or "__amd" in k:
         return None
+    if re.match(r"sr::gl::cols256_pair_kernel<", k):     # both operands' forward passes in one launch (plain column pass)
+        return "fwd_cols"
     m = re.match(r"sr::gl::cols256(?:_keep)?_kernel<(\d)", k) or re.match(r"sr::gl::strided\w*_kernel<(?:\d+, )?(\d)", k)
     if m:
         return "fwd_cols" if m.group(1) == "0" else "inv_cols"

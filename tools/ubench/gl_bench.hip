@@ -23,7 +23,7 @@ static inline unsigned keep_groups(size_t np) { size_t g = np / 8; if (g < 1) g 
 #define KEEP_LAUNCH(DIRV, st_, buf, srcbuf, np, wcp, twp)                                                                                         \
     do {                                                                                                                                          \
         if ((KEEP_DIRS >> DIRV) & 1)                                                                                                              \
-            hipLaunchKernelGGL((cols256_keep_kernel<DIRV>), dim3(8u * (1u << (k - 12)) * keep_groups(np)), dim3(256), 0, st_, buf, srcbuf, k, wcp, \
+            hipLaunchKernelGGL((cols256_keep_kernel<DIRV>), dim3(8u * (1u << (k - 12)) * keep_groups(np)), dim3(256), 0, st_, buf, srcbuf, (u64 *)nullptr, (const u64 *)nullptr, k, wcp, \
                                twp, (unsigned)(np), keep_groups(np));                                                                             \
         else                                                                                                                                      \
             hipLaunchKernelGGL((cols256_kernel<DIRV, 4>), dim3((unsigned)((np) << (k - 12))), dim3(256), 0, st_, buf, srcbuf, k, wcp, twp,         \

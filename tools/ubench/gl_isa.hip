@@ -8,8 +8,8 @@ template __global__ void sr::gl::rows256_kernel<0>(u64 *, const u64 *, u64 *, Ta
 template __global__ void sr::gl::rows256_kernel<1>(u64 *, const u64 *, u64 *, Tables);
 template __global__ void sr::gl::cols256_kernel<0, 4>(u64 *, const u64 *, int, const u64 *, const u64 *, unsigned);
 template __global__ void sr::gl::cols256_kernel<1, 4>(u64 *, const u64 *, int, const u64 *, const u64 *, unsigned);
-template __global__ void sr::gl::cols256_keep_kernel<0>(u64 *, const u64 *, int, const u64 *, const u64 *, unsigned, unsigned);
-template __global__ void sr::gl::cols256_keep_kernel<1>(u64 *, const u64 *, int, const u64 *, const u64 *, unsigned, unsigned);
+template __global__ void sr::gl::cols256_keep_kernel<0>(u64 *, const u64 *, u64 *, const u64 *, int, const u64 *, const u64 *, unsigned, unsigned);
+template __global__ void sr::gl::cols256_keep_kernel<1>(u64 *, const u64 *, u64 *, const u64 *, int, const u64 *, const u64 *, unsigned, unsigned);
 template __global__ void sr::gl::cols256_kernel<0, 5>(u64 *, const u64 *, int, const u64 *, const u64 *, unsigned);
 template __global__ void sr::gl::cols256_kernel<1, 5>(u64 *, const u64 *, int, const u64 *, const u64 *, unsigned);
 __global__ void probe_mul(u64 *x, const u64 *w) { x[threadIdx.x] = sr::Goldilocks::mul(x[threadIdx.x], w[threadIdx.x]); }
