@@ -41,9 +41,10 @@ SELF_EXE = os.path.join(ROOT, "tools", "ubench", "repcheck_selftest")
 def test_invariant_counters_fire_when_their_precondition_is_violated():
     """Test of the test behind tests/test_rep_invariants.py: compiled with -DSR_GL_CHECK_REPS, each counter of csrc/fields.hpp: repcheck
     fires for the violation it guards -- a canonical add handed p, a lazy sum that would wrap twice, a lazy difference that would
-    borrow twice, a word >= p through st_result, a twiddle-1 butterfly of a phased stage fed p + 1 -- and all stay at zero on legal
-    operands (tools/ubench/repcheck_selftest.hip)."""
-    if not os.path.exists(SELF_EXE) or any(os.path.getmtime(d) > os.path.getmtime(SELF_EXE) for d in [SELF_SRC] + DEPS[1:]):
+    borrow twice, a word >= p through st_result, a twiddle-1 butterfly of a phased stage fed p + 1, a nine-limb Stark sum that leaves
+    int32, a Stark product whose operands could overflow its column accumulator -- and all stay at zero on legal operands
+    (tools/ubench/repcheck_selftest.hip)."""
+    if not os.path.exists(SELF_EXE) or any(os.path.getmtime(d) > os.path.getmtime(SELF_EXE) for d in [SELF_SRC, os.path.join(ROOT, "stark_rings_amd", "csrc", "stark_lazy.hpp")] + DEPS[1:]):
         hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
         if not os.path.exists(hipcc):
             hipcc = shutil.which("hipcc")
