@@ -1633,8 +1633,8 @@ int sr_pointwise_mul_batch_dev(sr_ctx *c, uint64_t *l, const uint64_t *r, size_t
 int sr_mul_elem_batch_dev(sr_ctx *c, uint64_t *d, const uint64_t *elem, size_t batch, void *stream) {
     if (int rc = check(c, d, elem)) return rc;
     if (int rc = check_count(c, batch)) return rc;
-    const size_t w = (size_t)c->degree * c->limbs;
-    if (elem + w > d && d + batch * w > elem) return fail(SR_E_INVALID, "mul_elem: the element must not lie inside the batch it multiplies");
+    const uintptr_t w = (uintptr_t)c->degree * c->limbs * 8, pe = (uintptr_t)elem, pd = (uintptr_t)d;
+    if (pe + w > pd && pd + batch * w > pe) return fail(SR_E_INVALID, "mul_elem: the element must not lie inside the batch it multiplies");
     std::lock_guard<std::mutex> lk(c->mu);
     DeviceGuard g(c->device);
     return dev_mul_elem(c, d, elem, batch, (hipStream_t)stream);

@@ -1239,21 +1239,25 @@ inline int gl_launch_cols256_lane(const GoldilocksFastTables &f, uint64_t *data,
                        (const uint64_t *)nullptr, f.k, wc, twist, (unsigned)npoly, groups);
     return hipGetLastError() != hipSuccess;
 }
+// the plain forward column pass over both operands of a ring product in one launch (grid.y picks the operand)
+inline int gl_launch_cols256_pair_plain(const GoldilocksFastTables &f, uint64_t *da, const uint64_t *sa, uint64_t *db, const uint64_t *sb,
+                                        size_t npoly, hipStream_t st) {
+    GlProfScope ps(f, 0, st);
+    constexpr int LC = 4;
+    const size_t blocks = npoly << (f.k - 8 - LC);
+    if (blocks == 0 || blocks > 0x7FFFFFFFull) return 1;
+    hipLaunchKernelGGL((gl::cols256_pair_kernel<LC>), dim3((unsigned)blocks, 2), dim3(16 << LC), 0, st, da, sa, db, sb, f.k, f.t.wcf,
+                       f.t.twist_f, xcd_grouped_tiles(blocks, gl::kColsXcdGroup));
+    return hipGetLastError() != hipSuccess;
+}
 // the forward column passes of BOTH operands of a ring product in one launch (the same workgroups, their twist factors loaded once,
 // walk over the elements of a and then of b); falls back to two launches where the persistent kernel does not apply
 inline int gl_launch_cols256_lane_pair(const GoldilocksFastTables &f, uint64_t *da, const uint64_t *sa, uint64_t *db, const uint64_t *sb,
                                        size_t npoly, hipStream_t st) {
     const unsigned chunks = 1u << (f.k - 12);
     unsigned groups = chunks >= 128 ? 1u : 128u / chunks;
-    if (!f.keep_cols || f.k != 16 || (npoly & 7u) != 0 || npoly < 16u || npoly > 0x3FFFFFFFull) {
-        GlProfScope ps(f, 0, st);
-        constexpr int LC = 4;
-        const size_t blocks = npoly << (f.k - 8 - LC);
-        if (blocks == 0 || blocks > 0x7FFFFFFFull) return 1;
-        hipLaunchKernelGGL((gl::cols256_pair_kernel<LC>), dim3((unsigned)blocks, 2), dim3(16 << LC), 0, st, da, sa, db, sb, f.k, f.t.wcf,
-                           f.t.twist_f, xcd_grouped_tiles(blocks, gl::kColsXcdGroup));
-        return hipGetLastError() != hipSuccess;
-    }
+    if (!f.keep_cols || f.k != 16 || (npoly & 7u) != 0 || npoly < 16u || npoly > 0x3FFFFFFFull)
+        return gl_launch_cols256_pair_plain(f, da, sa, db, sb, npoly, st);
     if (groups > npoly / 16) groups = (unsigned)(npoly / 16);
     GlProfScope ps(f, 0, st);
     hipLaunchKernelGGL((gl::cols256_keep_kernel<0>), dim3(8u * chunks * groups), dim3(256), 0, st, da, sa, db, sb, f.k, f.t.wcf, f.t.twist_f,
@@ -1350,8 +1354,12 @@ inline int gl_fast_ring_mul(const GoldilocksFastTables &f, uint64_t *out, const 
     for (size_t e = 0; e < batch; e += chunk) {
         const size_t n = batch - e < chunk ? batch - e : chunk;
         uint64_t *o = out + e * stride;
-        if (gl_strided_fwd(f, o, a + e * stride, n, st)) return 1;
-        if (gl_strided_fwd(f, scratch, b + e * stride, n, st)) return 1;
+        if (f.cols256) {  // both operands' column passes in one launch (a's output goes straight to out, b's into the scratch)
+            if (gl_launch_cols256_pair_plain(f, o, a + e * stride, scratch, b + e * stride, n, st)) return 1;
+        } else {
+            if (gl_strided_fwd(f, o, a + e * stride, n, st)) return 1;
+            if (gl_strided_fwd(f, scratch, b + e * stride, n, st)) return 1;
+        }
         if (gl_launch_rows<2>(f, o, scratch, o, n, true, st)) return 1;
         if (gl_strided_inv(f, o, n, true, st)) return 1;
     }
