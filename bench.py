@@ -374,12 +374,12 @@ def main():
     bytes_per_mul = 3 * d * coeff_bytes  # read a, read b, write c
     kern = {t: v for t, v in prof.items() if v["launches"]}
     # dominant kernel = the longest single launch of the step.  Since the forward column passes of both operands are ONE launch, that
-    # launch and the rows launch take about equally long at D = 2^16 (and did in total before): the rows kernel -- the one that moves
-    # and computes the most per ring element -- stays the subject unless another launch is clearly (> 10 %) longer, so that the tag
-    # does not flip between runs.
+    # launch and the rows launch take about equally long at D = 2^16 (85 against 78 us; they did in total before): the rows kernel --
+    # the one that computes the most per ring element, and the lower of the two fractions -- stays the subject unless another launch is
+    # clearly (> 25 %) longer, so that the tag does not flip between runs; `by_kernel` carries every tag's own figure.
     per_launch = {t: kern[t]["ms"] / kern[t]["launches"] for t in kern}
     dom_tag = max(per_launch, key=per_launch.get)
-    if "rows" in per_launch and per_launch["rows"] >= 0.9 * per_launch[dom_tag]:
+    if "rows" in per_launch and per_launch["rows"] >= 0.8 * per_launch[dom_tag]:
         dom_tag = "rows"
     dom = kern[dom_tag]
     launches_per_step = dom["launches"] / args.steps
@@ -400,6 +400,14 @@ def main():
         kernel_bytes_per_elem = bytes_per_mul  # one fused launch at the boundary layout
     fwd_operands = 2 if args.variant == "mul" else 1   # operands whose forward column pass runs in a step (one launch or two)
     alg_bytes_per_launch = kernel_bytes_per_elem * batch / max(launches_per_step, 1e-9) * (fwd_operands if dom_tag == "fwd_cols" else 1)
+    # the same figure for every tag of the step (multi-launch degrees excepted: one fused launch has no separate column tags)
+    by_kernel = {}
+    if not (k <= 12 and ring_name != "stark"):
+        for t in kern:
+            per_elem = 3 * d * wk if t == "rows" else (d * (coeff_bytes + wk) if ring_name == "babybear" else 2 * d * wk)
+            bpl = per_elem * batch / (kern[t]["launches"] / args.steps) * (fwd_operands if t == "fwd_cols" else 1)
+            by_kernel[t] = {"avg_ms": per_launch[t], "algorithmic_bytes_per_launch": bpl,
+                            "frac": bpl / (per_launch[t] * 1e-3) / 1e9 / HBM_PEAK_GBS}
     achieved_gbs = alg_bytes_per_launch / (dom_avg_ms * 1e-3) / 1e9
     step_gbs = bytes_per_mul * batch * world / (elapsed / args.steps) / 1e9 / world
 
@@ -470,7 +478,7 @@ def main():
                      "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                      "copy_measured": copy_gbs, "copy_measured_kind": copy_kind,
                      "frac_of_copy_measured": achieved_gbs / copy_gbs if copy_gbs else None,
-                     "kernel": dom_tag, "kernel_avg_ms": dom_avg_ms, "launches_per_step": launches_per_step,
+                     "kernel": dom_tag, "kernel_avg_ms": dom_avg_ms, "launches_per_step": launches_per_step, "by_kernel": by_kernel,
                      "launches_per_step_by_kernel": {t: v["launches"] / args.steps for t, v in kern.items()},
                      "algorithmic_bytes_per_ring_mul": bytes_per_mul,
                      "dominant_kernel_bytes_per_ring_mul": kernel_bytes_per_elem,
