@@ -147,6 +147,10 @@ def test_bench_single_rank_reports_the_plan_the_library_chose():
     assert plan.startswith("library default (sr_plan.lanes = 0, auto): ") and "its probe took" in plan
     roof = d["roofline"]
     assert 0 < roof["frac"] < 1 and 0 < roof["whole_step_frac"] < 1
+    # every kernel tag of the step carries its own per-launch fraction; the reported one is the subject kernel's
+    assert set(roof["by_kernel"]) == {"fwd_cols", "rows", "inv_cols"}
+    assert abs(roof["by_kernel"][roof["kernel"]]["frac"] - roof["frac"]) < 1e-9
+    assert roof["launches_per_step_by_kernel"]["fwd_cols"] == roof["launches_per_step_by_kernel"]["rows"]  # both operands: one launch
     assert "multi_gpu" not in d
     if "two lanes --" in plan and "overlap" in roof:
         assert roof["overlap"]["internal_streams"] == 2 and roof["overlap"]["factor"] > 1.2
