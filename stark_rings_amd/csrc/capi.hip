@@ -541,6 +541,15 @@ bool lanes_pay(const sr_ctx *c, size_t batch, size_t lane_chunk) {
 bool gl_use_lanes(const sr_ctx *c, size_t batch) {
     return effective_lanes(c) != 1 && c->k > 12 && c->gl_fast.cols256 && lanes_pay(c, batch, gl_lane_chunk(c));
 }
+// The stand-alone transforms (two launches per chunk, in place) need more chunks before the lanes pay: at four chunks one set of
+// launches on the caller's stream is a quarter faster (512 Goldilocks elements of degree 2^16: 0.169 against 0.222 ms; 32 of degree
+// 2^20: 0.210 against 0.268; 1 024 BabyBear: 0.251 against 0.294), at eight the two are level (tools/bench_small_transforms.py).
+bool lanes_pay_transform(const sr_ctx *c, size_t batch, size_t lane_chunk) {
+    return c->plan.chunk_polys ? batch > lane_chunk : batch >= 8 * lane_chunk;
+}
+bool gl_use_lanes_transform(const sr_ctx *c, size_t batch) {
+    return effective_lanes(c) != 1 && c->k > 12 && c->gl_fast.cols256 && lanes_pay_transform(c, batch, gl_lane_chunk(c));
+}
 int gl_lanes_init(sr_ctx *c) {
     sr::GlLanes &L = c->gl_lanes;
     if (L.n) return SR_OK;
@@ -680,6 +689,7 @@ int rt_scratch_release(sr_ctx *c, hipStream_t st) {
 }
 template <class F> size_t rt_lane_chunk(const sr_ctx *c);
 template <class F> bool rt_use_lanes(const sr_ctx *c, size_t batch, hipStream_t st);
+template <class F> bool rt_use_lanes_transform(const sr_ctx *c, size_t batch, hipStream_t st);
 int gl_lanes_init(sr_ctx *c);
 // stand-alone transform in chunks on the context's two streams, each lane with its own packed scratch (the two-lane plan of
 // rt_ring_mul below; the scratch has the product's size, so one allocation serves both)
@@ -716,7 +726,7 @@ int rt_transform_lanes(sr_ctx *c, void *d, size_t batch, hipStream_t st) {
 template <class F, class VB = sr::rt::Boundary>
 int rt_fwd(sr_ctx *c, void *d, size_t batch, hipStream_t st) {
     using E = typename F::elem;
-    if (rt_use_lanes<F>(c, batch, st)) return rt_transform_lanes<F, 0, VB>(c, d, batch, st);
+    if (rt_use_lanes_transform<F>(c, batch, st)) return rt_transform_lanes<F, 0, VB>(c, d, batch, st);
     if (int rc = rt_ensure_scratch(c, 1, (batch << c->k) * sizeof(E))) return rc;
     ScratchUse su(c, st);
     if (int rc = su.acquire()) return rc;
@@ -728,7 +738,7 @@ int rt_fwd(sr_ctx *c, void *d, size_t batch, hipStream_t st) {
 template <class F, class VB = sr::rt::Boundary>
 int rt_inv(sr_ctx *c, void *d, size_t batch, hipStream_t st) {
     using E = typename F::elem;
-    if (rt_use_lanes<F>(c, batch, st)) return rt_transform_lanes<F, 1, VB>(c, d, batch, st);
+    if (rt_use_lanes_transform<F>(c, batch, st)) return rt_transform_lanes<F, 1, VB>(c, d, batch, st);
     if (int rc = rt_ensure_scratch(c, 1, (batch << c->k) * sizeof(E))) return rc;
     ScratchUse su(c, st);
     if (int rc = su.acquire()) return rc;
@@ -759,6 +769,10 @@ size_t rt_lane_chunk(const sr_ctx *c) {
 template <class F>
 bool rt_use_lanes(const sr_ctx *c, size_t batch, hipStream_t st) {
     return effective_lanes(c) != 1 && c->k > 12 && lanes_pay(c, batch, rt_lane_chunk<F>(c)) && st != c->stream && st != c->out_stream;
+}
+template <class F>
+bool rt_use_lanes_transform(const sr_ctx *c, size_t batch, hipStream_t st) {
+    return effective_lanes(c) != 1 && c->k > 12 && lanes_pay_transform(c, batch, rt_lane_chunk<F>(c)) && st != c->stream && st != c->out_stream;
 }
 template <class F, class VB = sr::rt::Boundary>
 int rt_ring_mul(sr_ctx *c, void *out, const void *a, const void *b, size_t batch, hipStream_t st) {
@@ -1061,7 +1075,7 @@ int dev_fwd(sr_ctx *c, uint64_t *d, size_t batch, hipStream_t st) {
         return rt_fwd<sr::Goldilocks>(c, d, batch, st);
     }
     if (c->ring == SR_RING_GOLDILOCKS_POW2 && c->fast_goldilocks && sr::gl_fast_supported(c->gl_fast)) {
-        if (gl_use_lanes(c, batch) && st != c->stream && st != c->out_stream) {  // chunks on the two lanes, in place (no scratch)
+        if (gl_use_lanes_transform(c, batch) && st != c->stream && st != c->out_stream) {  // chunks on the two lanes, in place (no scratch)
             if (int rc = gl_lanes_init(c)) return rc;
             c->gl_lanes.chunk = gl_lane_chunk(c);
             return sr::gl_fast_transform_lanes<0>(c->gl_fast, d, c->gl_lanes, batch, st) ? fail(SR_E_HIP, "goldilocks fast-path launch failed") : SR_OK;
@@ -1081,7 +1095,7 @@ int dev_inv(sr_ctx *c, uint64_t *d, size_t batch, hipStream_t st) {
         return rt_inv<sr::Goldilocks>(c, d, batch, st);
     }
     if (c->ring == SR_RING_GOLDILOCKS_POW2 && c->fast_goldilocks && sr::gl_fast_supported(c->gl_fast)) {
-        if (gl_use_lanes(c, batch) && st != c->stream && st != c->out_stream) {
+        if (gl_use_lanes_transform(c, batch) && st != c->stream && st != c->out_stream) {
             if (int rc = gl_lanes_init(c)) return rc;
             c->gl_lanes.chunk = gl_lane_chunk(c);
             return sr::gl_fast_transform_lanes<1>(c->gl_fast, d, c->gl_lanes, batch, st) ? fail(SR_E_HIP, "goldilocks fast-path launch failed") : SR_OK;
