@@ -111,8 +111,8 @@ int sr_ctx_create_ex(int ring, int log2_degree, int device, const sr_plan *plan,
  * that batch size can also be CAPTURED into a HIP graph by the caller (hipStreamBeginCapture on `stream`): they neither allocate
  * nor synchronise nor probe, and the internal lanes fork from and join to `stream` by events
  * (tests/test_gpu_parity.py: test_device_calls_can_be_captured_into_a_hip_graph).
- * Chunking of a batch (sr_plan.chunk_polys = 0): never below 64 MiB of coefficients per set of launches; two lanes from a little
- * over two such chunks on, one set of launches on the caller's stream below. */
+ * Chunking of a batch (sr_plan.chunk_polys = 0): never below 64 MiB of coefficients per set of launches; products take the two
+ * lanes from three and a half such chunks on, stand-alone transforms from eight, one set of launches on the caller's stream below. */
 int sr_ctx_reserve_scratch(sr_ctx *ctx, size_t batch);
 /* The plan the context runs: *plan = the sr_plan it was created with, with lanes resolved to 1 or 2 once the library has settled it
  * (lanes stays 0 while sr_plan.lanes = 0 and sr_ctx_reserve_scratch has not run: such a context runs two lanes).  probe_ms

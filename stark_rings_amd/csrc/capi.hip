@@ -532,11 +532,13 @@ size_t gl_lane_chunk(const sr_ctx *c) {
     if (chunk > cap / (4 * elem)) chunk = cap / (4 * elem);
     return chunk ? chunk : 1;
 }
-// Two lanes pay from a little over two chunks on: up to two default chunks one set of launches on the caller's stream is faster (256
-// elements of degree 2^16: 0.256 against 0.273 ms; 16 of degree 2^20: 0.332 against 0.366; 512 and 64: the lanes win).  A plan that
-// fixes chunk_polys gets its chunks on the lanes as soon as there are two.
+// Two lanes pay from three and a half chunks on: below, one set of launches on the caller's stream is faster -- Goldilocks degree 2^16:
+// 256 elements 0.256 against 0.273 ms, 288 0.287 against 0.338, 384 0.385 against 0.413, 448 level, 512 0.522 against 0.498, 640 0.655
+// against 0.633; degree 2^20: 24 elements 0.491 against 0.533, 40 level; BabyBear 2^16: 768 0.513 against 0.532, 1 280 0.887 against
+// 0.858 (tools/bench_small_batches.py).  (Three chunks on two lanes are two on one and one on the other.)  A plan that fixes
+// chunk_polys gets its chunks on the lanes as soon as there are two.
 bool lanes_pay(const sr_ctx *c, size_t batch, size_t lane_chunk) {
-    return batch > (c->plan.chunk_polys ? lane_chunk : 2 * lane_chunk);
+    return c->plan.chunk_polys ? batch > lane_chunk : 2 * batch >= 7 * lane_chunk;
 }
 bool gl_use_lanes(const sr_ctx *c, size_t batch) {
     return effective_lanes(c) != 1 && c->k > 12 && c->gl_fast.cols256 && lanes_pay(c, batch, gl_lane_chunk(c));

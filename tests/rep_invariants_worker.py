@@ -280,8 +280,8 @@ def main():
             run_plan(k)
         for k in (16, 20):
             run_plan(k, {"SR_GL_COLS256": "0"})     # the older plan: strided passes + lazy 4096-point tiles
-        run_lanes(16, 264)     # two chunks of 128 and one of 8: cols256_keep_kernel on both lanes
-        run_lanes(20, 17)      # chunks of 8, 8 and 1 at D = 2^20
+        run_lanes(16, 520)     # four chunks of 128 and one of 8: cols256_keep_kernel on both lanes, the plain pass on the ragged one
+        run_lanes(20, 33)      # four chunks of 8 and one of 1 at D = 2^20
     if "stark" in which:
         highs = [run_stark(k) for k in (4, 8, 10, 11, 12, 13, 14, 15, 16)]   # one tile per element, then 1, 2 or 3 strided stages in front
         highs += [run_stark(k, {"SR_STARK_TUNED": "0"}) for k in (6, 10, 12)]   # the generic LDS kernels on the same lazy arithmetic

@@ -1525,7 +1525,7 @@ def test_column_pass_tile_order_covers_every_tile(torch_cuda, name, k, batch):
     ring.close()
 
 
-@pytest.mark.parametrize("k,batch,plan_kw", [(16, 300, {}), (16, 300, {"chunk_polys": 64}), (16, 131, {"chunk_polys": 1}), (17, 7, {"chunk_polys": 2}),
+@pytest.mark.parametrize("k,batch,plan_kw", [(16, 460, {}), (16, 300, {"chunk_polys": 64}), (16, 131, {"chunk_polys": 1}), (17, 7, {"chunk_polys": 2}),
                                              (20, 3, {"chunk_polys": 1}), (16, 300, {"lanes": 1}), (16, 129, {"scratch_limit_bytes": 16 << 20})])
 def test_goldilocks_product_on_two_lanes(torch_cuda, k, batch, plan_kw):
     """Tuned Goldilocks product above one chunk: chunks dealt to two internal streams, each with its own scratch pair (gl_fast_ring_mul_lanes);
@@ -2215,7 +2215,7 @@ def test_matrix_times_one_ring_element(torch_cuda, name, k, batch):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name,k,batch", [("goldilocks", 16, 300), ("goldilocks", 20, 19), ("goldilocks", 10, 64), ("babybear", 16, 600),
+@pytest.mark.parametrize("name,k,batch", [("goldilocks", 16, 460), ("goldilocks", 16, 100), ("goldilocks", 20, 30), ("goldilocks", 10, 64), ("babybear", 16, 1000),
                                           ("stark", 12, 8), ("stark", 14, 3)])
 def test_device_calls_can_be_captured_into_a_hip_graph(torch_cuda, name, k, batch):
     """A caller that replays the same batch shape many times can capture the `_dev` calls into a HIP graph: after
@@ -2270,8 +2270,8 @@ def test_device_calls_can_be_captured_into_a_hip_graph(torch_cuda, name, k, batc
 
 # ----------------------------------------------------------------------------- round 4: the column pass that keeps its twist factors
 @pytest.mark.gpu
-@pytest.mark.parametrize("k,batch,chunk", [(16, 272, 0), (16, 264, 64), (16, 40, 8), (16, 48, 24), (16, 32, 16), (16, 200, 40),
-                                           (17, 136, 0), (18, 72, 0), (20, 24, 0), (20, 17, 8)])
+@pytest.mark.parametrize("k,batch,chunk", [(16, 456, 0), (16, 264, 64), (16, 40, 8), (16, 48, 24), (16, 32, 16), (16, 200, 40),
+                                           (17, 232, 0), (18, 120, 0), (20, 33, 0), (20, 17, 8)])
 def test_keep_and_plain_column_passes_agree(torch_cuda, k, batch, chunk):
     """Round 4: on the two-lane plans a column-pass workgroup owns one column chunk and walks over the ring elements of the launch
     with its 16 twist factors in registers (cols256_keep_kernel; launches whose element count is a multiple of 8 -- the rest, here
