@@ -263,8 +263,8 @@ int sr_deserialize_batch(sr_ctx *ctx, uint64_t *out, const uint8_t *wire, size_t
 /* RqPoly * &RqPoly (coeff_form.rs:250-258): d_a and d_b are only read -- the reference never mutates an operand, so one b can
  * be multiplied into many a.  d_out may alias d_a; d_b must not alias d_out.  Above one LDS tile the intermediates go
  * through the context's operand scratch (sr_ctx_reserve_scratch).  Stream semantics: one stream-ordered operation on `stream`;
- * a batch of more than one chunk (sr_plan.chunk_polys, 64 MiB of coefficients by default) is forked onto the context's two
- * internal streams and joined back onto `stream` before the call returns (sr_plan.lanes = 1, or the library's own choice when
+ * a batch of three and a half chunks or more (64 MiB of coefficients each by default; with sr_plan.chunk_polys set: more than one
+ * chunk) is forked onto the context's two internal streams and joined back onto `stream` before the call returns (sr_plan.lanes = 1, or the library's own choice when
  * lanes = 0 and its probe found one stream faster: everything on `stream` itself). */
 int sr_ring_mul_batch_dev(sr_ctx *ctx, uint64_t *d_out, const uint64_t *d_a, const uint64_t *d_b, size_t batch, void *stream);
 /* The constant-operand case: d_b_ntt already holds crt(b) (sr_ntt_fwd_batch_dev), e.g. the rows of a commitment matrix that

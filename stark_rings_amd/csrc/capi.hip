@@ -524,7 +524,7 @@ size_t gl_chunk_polys(const sr_ctx *c, size_t batch) {
 // Two-lane plan of the tuned Goldilocks product (sr::gl_fast_ring_mul_lanes): chunk of a lane in ring elements -- 64 MiB of
 // coefficients per scratch buffer by default, so that the four buffers of the two lanes are the 256 MiB of the Infinity Cache --
 // capped by the plan's scratch limit (four buffers) and by sr_plan.chunk_polys when set.  Taken when the plan allows lanes
-// (sr_plan.lanes != 1), the column passes are cols256 launches and the batch is more than one such chunk.
+// (sr_plan.lanes != 1), the column passes are cols256 launches and the batch has enough such chunks for the lanes to pay (lanes_pay).
 size_t gl_lane_chunk(const sr_ctx *c) {
     const size_t elem = (size_t)8 << c->k;
     size_t chunk = c->plan.chunk_polys ? (size_t)c->plan.chunk_polys : (((size_t)64 << 20) / elem);
