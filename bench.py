@@ -88,6 +88,97 @@ def source_hash():
     return h.hexdigest()[:16]
 
 
+class ClockPowerSampler:
+    """Shader clock and socket power of ONE GPU while the timed steps run: a thread of THIS process that reads the amdgpu hwmon files
+    (freq1_input = sclk in Hz, power1_input / power1_average = socket power in microwatts) every ~2 ms.  sysfs only: no HIP call, no
+    second process, nothing that touches the GPU.  The card is found by the PCI address torch reports for the HIP device."""
+
+    def __init__(self, pci_bus_id):
+        import glob
+        import threading
+
+        self.files = None
+        self.samples = []   # (perf_counter, sclk_hz, power_uw)
+        self.card = None
+        want = (pci_bus_id or "").lower()
+        for card in sorted(glob.glob("/sys/class/drm/card[0-9]*")):
+            dev = os.path.join(card, "device")
+            try:
+                addr = os.path.basename(os.path.realpath(dev)).lower()
+            except OSError:
+                continue
+            if want and addr != want:
+                continue
+            for hw in glob.glob(os.path.join(dev, "hwmon", "hwmon*")):
+                f = os.path.join(hw, "freq1_input")
+                pw = [q for q in (os.path.join(hw, "power1_input"), os.path.join(hw, "power1_average")) if os.path.exists(q)]
+                if os.path.exists(f) and pw:
+                    self.files = (f, pw[0])
+                    self.card = "%s (%s)" % (os.path.basename(card), addr)
+                    break
+            if self.files:
+                break
+        self._stop = threading.Event()
+        self._thread = threading.Thread(target=self._run, daemon=True) if self.files else None
+
+    def start(self):
+        if self._thread:
+            self._thread.start()
+        return self
+
+    def _run(self):
+        f_clk, f_pw = self.files
+        while not self._stop.is_set():
+            try:
+                with open(f_clk) as a, open(f_pw) as b:
+                    self.samples.append((time.perf_counter(), int(a.read()), int(b.read())))
+            except (OSError, ValueError):
+                pass
+            self._stop.wait(0.002)
+
+    def stop(self):
+        self._stop.set()
+        if self._thread:
+            self._thread.join(timeout=1.0)
+
+    def window(self, t0, t1):
+        """mean sclk (MHz) and socket power (W) over the samples taken in [t0, t1]; None when the box exposes no such files"""
+        rows = [(c, w) for (t, c, w) in self.samples if t0 <= t <= t1]
+        if not rows:
+            return None
+        return {"sclk_mhz": sum(c for c, _ in rows) / len(rows) / 1e6, "socket_w": sum(w for _, w in rows) / len(rows) / 1e6,
+                "sclk_mhz_min": min(c for c, _ in rows) / 1e6, "sclk_mhz_max": max(c for c, _ in rows) / 1e6,
+                "samples": len(rows), "source": "amdgpu hwmon freq1_input / power1_input of %s, read by a thread of this process "
+                                                "every ~2 ms during the timed steps" % self.card}
+
+
+def replayed_kernel_stats(workload, dom_kernel_names, here_hash):
+    """Average duration (ms) of the dominant kernel in profiles/<latest round>/kernel_stats_<workload>.csv (rocprofv3 --kernel-trace
+    --stats of `bench.py --workload ...`), replayed only while the build's source hash equals the one the profile was collected at
+    (pmc_<workload>.json of the same collection carries it).  -> (avg_ms, kernel name, source string) or (None, None, reason)."""
+    import csv
+
+    try:
+        rounds = sorted(r for r in os.listdir(os.path.join(ROOT, "profiles")) if r.startswith("r"))
+        for rnd in reversed(rounds):
+            stats = os.path.join(ROOT, "profiles", rnd, "kernel_stats_%s.csv" % workload)
+            pj = os.path.join(ROOT, "profiles", rnd, "pmc_%s.json" % workload)
+            if os.path.exists(stats) and os.path.exists(pj):
+                break
+        else:
+            return None, None, "none: no profiles/*/kernel_stats_%s.csv" % workload
+        if json.load(open(pj)).get("source_sha256") != here_hash:
+            return None, None, "dropped (stale): %s was collected at another source hash" % os.path.relpath(stats, ROOT)
+        rows = [r for r in csv.DictReader(open(stats)) if any(k in r["Name"] for k in dom_kernel_names)]
+        if not rows:
+            return None, None, "no dominant-kernel row in %s" % os.path.relpath(stats, ROOT)
+        big = max(rows, key=lambda r: float(r["TotalDurationNs"]))
+        return float(big["AverageNs"]) / 1e6, big["Name"].split("(")[0].replace("void ", ""), \
+            "replayed from %s (rocprofv3 --kernel-trace --stats of the same command, source hash %s)" % (os.path.relpath(stats, ROOT), here_hash)
+    except (OSError, ValueError, KeyError):
+        return None, None, "unreadable"
+
+
 def self_launch(args):
     """--gpus N > 1 outside torchrun: start the ranks as a child process tree.  Nothing in this process has initialised HIP
     (no torch.cuda call, no library load), so no exec-after-GPU-init can happen; the child is a plain subprocess."""
@@ -148,6 +239,14 @@ def main():
     dev_index = local_rank % ndev  # one rank per GPU on a full node; a 1-GPU rehearsal folds ranks onto device 0
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
+    sampler = None
+    if rank == 0:
+        try:
+            pr = torch.cuda.get_device_properties(dev_index)
+            bus = "%04x:%02x:%02x.0" % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
+        except (AttributeError, RuntimeError):
+            bus = None
+        sampler = ClockPowerSampler(bus).start()
     dist_on = world > 1 or args.force_dist
     if dist_on:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -264,7 +363,9 @@ def main():
     for _ in range(args.steps):
         step()
     barrier()
-    elapsed = time.perf_counter() - t0
+    t_end = time.perf_counter()
+    elapsed = t_end - t0
+    clock_power = sampler.window(t0, t_end) if sampler else None
     rank_ms = None
     if dist_on:  # max over ranks is the job's time; min next to it makes a straggler visible
         cdev = dev if args.backend == "nccl" else "cpu"
@@ -275,13 +376,35 @@ def main():
         rank_ms = {"min": float(tmin.item()) / args.steps * 1e3, "max": float(t.item()) / args.steps * 1e3}
         elapsed = float(t.item())
 
-    # ---- per-kernel durations over the same K steps, HIP events on the launch stream ----
-    ring.profile_enable(True)
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize()
-    prof = ring.profile_read()
-    ring.profile_enable(False)
+    # ---- per-kernel durations over the same K steps, HIP events on the launch stream.  Every PROF_STRIDE-th launch is bracketed
+    #      (7: coprime to the 3, 4 or 6 launches of a chunk, so every tag is sampled evenly): bracketing EVERY launch of a two-lane
+    #      plan opens gaps in which the other lane's kernel runs alone and reads 10-20 % short (81.7 us printed against
+    #      96.9 us inside the timed steps); the sparse sample leaves the step as it runs, which `profile_step_ms` below checks ----
+    def profiled_steps(r, fn, stride, steps):
+        r.profile_read()                    # drop whatever earlier steps left
+        r.profile_enable(stride)
+        torch.cuda.synchronize()
+        tp0 = time.perf_counter()
+        for _ in range(steps):
+            fn()
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - tp0) / steps * 1e3
+        pr = r.profile_read()
+        r.profile_enable(False)
+        return pr, ms
+
+    PROF_STRIDE = 7
+    prof, profile_step_ms = profiled_steps(ring, step, PROF_STRIDE, args.steps)
+    if any(v["seen"] and not v["launches"] for v in prof.values()):   # too few launches for a sparse sample: bracket every one
+        PROF_STRIDE = 1
+        prof, profile_step_ms = profiled_steps(ring, step, 1, args.steps)
+    for v in prof.values():   # from here on: ms = mean bracketed duration x every launch of the tag, launches = every launch
+        v["sampled"] = v["launches"]
+        if v["launches"]:
+            v["ms"] = v["ms"] / v["launches"] * v["seen"]
+        v["launches"] = v["seen"]
+    if sampler:
+        sampler.stop()
     # The tuned Goldilocks product runs its chunks on two internal streams (DESIGN_APPENDIX.md A.2): the event-timed duration of a launch is
     # then time IN FLIGHT next to the other lane's kernels, not exclusive GPU time.  For a kernel-quality figure that can be compared
     # with earlier rounds the same steps are also profiled on a second context whose plan pins ONE stream (sr_plan.lanes = 1) --
@@ -301,12 +424,8 @@ def main():
             ring1.mul_dev(a, a, b)
         torch.cuda.synchronize()
         single_ms = (time.perf_counter() - t1) / ks * 1e3
-        ring1.profile_enable(True)
-        for _ in range(ks):
-            ring1.mul_dev(a, a, b)
-        torch.cuda.synchronize()
-        prof_single = {t: dict(v, steps=ks) for t, v in ring1.profile_read().items() if v["launches"]}
-        ring1.profile_enable(False)
+        pr1, _ = profiled_steps(ring1, lambda: ring1.mul_dev(a, a, b), 1, ks)
+        prof_single = {t: dict(v, steps=ks) for t, v in pr1.items() if v["launches"]}
         ring1.close()
     # the timed steps kept multiplying a by the (unchanged) b: the final state must still be a batch of canonical ring elements
     # whose transform round-trips -- outputs after the warm-up are checked, not only the first step
@@ -415,7 +534,7 @@ def main():
     # dynamic VALU instructions per wave (SQ counter pass) are NOT measured in this run: they are replayed from
     # profiles/<round>/pmc_<workload>.json, which records the source hash of the build it was collected on.  A different
     # hash (any kernel edit since) drops them instead of presenting stale numbers as current.
-    traffic = step_traffic = valu = None
+    traffic = step_traffic = valu = valu_step = valu_scaled = None
     traffic_source = "none: no profiles/*/pmc_%s.json" % args.workload
     try:
         rounds = sorted(r for r in os.listdir(os.path.join(ROOT, "profiles")) if r.startswith("r"))
@@ -427,6 +546,12 @@ def main():
         here = source_hash()
         lps_now = {t: kern[t]["launches"] / args.steps for t in kern}
         lps_then = pj.get("launches_per_step")
+        if pj.get("source_sha256") == here and lps_then and pj.get("batch") and all(t in pj.get("valu", {}) for t in lps_then):
+            # VALU wave-instructions per RING ELEMENT are a property of the kernels, not of the batch: a run at another batch (or another
+            # cut into launches) scales them by its own element count; the exact per-launch form below overrides when everything matches
+            per_elem = sum(pj["valu"][t]["waves_per_launch"] * pj["valu"][t]["valu_per_wave"] * lps_then[t] for t in lps_then) / pj["batch"]
+            valu_step = per_elem * batch
+            valu_scaled = "per ring element from the profile's batch of %d" % pj["batch"]
         if pj.get("batch") != batch:
             traffic_source = "dropped: %s was collected at batch %s" % (os.path.relpath(pj_path, ROOT), pj.get("batch"))
         elif lps_then is None or any(abs(lps_then.get(t, -1) - v) > 1e-6 for t, v in lps_now.items()):
@@ -443,16 +568,59 @@ def main():
             traffic = pj["bytes_per_launch"].get(dom_tag)
             if all(t in pj["bytes_per_launch"] for t in kern):
                 step_traffic = sum(pj["bytes_per_launch"][t] * kern[t]["launches"] / args.steps for t in kern)
+            if all(t in pj.get("valu", {}) for t in kern):
+                # VALU wave-instructions of ONE STEP: every tag's waves per launch x VALU per wave x launches per step
+                valu_step = sum(pj["valu"][t]["waves_per_launch"] * pj["valu"][t]["valu_per_wave"] * kern[t]["launches"] / args.steps for t in kern)
+                valu_scaled = None
             if dom_tag in pj.get("valu", {}):
                 kv = pj["valu"][dom_tag]
                 rate = kv["waves_per_launch"] * kv["valu_per_wave"] / (dom_avg_ms * 1e-3)
                 peak = 256 * 4 * 2.4e9 / 4
                 valu = {"bound": "valu-issue", "achieved": rate, "peak": peak, "unit": "wave-instructions/s", "frac": rate / peak,
                         "valu_instructions_per_wave": kv["valu_per_wave"], "waves_per_launch": kv["waves_per_launch"],
-                        "note": "supplementary, replayed like roofline.traffic: one wave-instruction per 4 cycles per SIMD at the nominal 2.4 GHz as the "
-                                "peak; under this integer-dense kernel the chip holds about 2.0 GHz (profiles/r02/clock_*.txt, DESIGN_APPENDIX.md A.2)"}
+                        "note": "the DOMINANT kernel's in-flight issue rate beside the other lane's kernels, nominal 2.4 GHz peak -- supplementary; "
+                                "whole_step below is the figure that says how close the step is to its issue floor"}
     except (OSError, ValueError, KeyError, IndexError, NameError):
         pass
+
+    # ---- the figures a reader of this ONE line needs to see why the whole step is where it is ----
+    # (a) the dominant kernel's duration a second way: rocprofv3's own average for it over the same command, replayed from profiles/
+    #     while the source hash matches; roofline.frac is the LOWER of the two fractions
+    dom_names = {"rows": ("rows256_kernel<2>", "rows_kernel<2", "rows256_kernel<sr::BabyBear, 2", "rows_kernel<sr::BabyBear, 2", "tile_kernel<", "rows_kernel<sr::")
+                 if args.variant == "mul" else ("rows256_kernel<3>", "rows_kernel<3"),
+                 "fwd_cols": ("cols256_keep_kernel<0>", "cols256_pair_kernel", "cols256_kernel<0", "cols256_kernel<sr::BabyBear, 0", "cols_kernel<3, 0", "cols_kernel<2, 0", "cols_kernel<1, 0", "strided"),
+                 "inv_cols": ("cols256_keep_kernel<1>", "cols256_kernel<1", "cols256_kernel<sr::BabyBear, 1", "cols_kernel<3, 1", "cols_kernel<2, 1", "cols_kernel<1, 1", "strided")}.get(dom_tag, ())
+    rocprof_ms, rocprof_kernel, rocprof_source = replayed_kernel_stats(args.workload, dom_names, source_hash()) if dom_names else (None, None, "n/a")
+    if rocprof_ms and "dropped (other plan)" in traffic_source:
+        rocprof_ms, rocprof_source = None, "dropped (other plan): the profile was collected with other launches per step"
+    frac_events = achieved_gbs / HBM_PEAK_GBS
+    frac_rocprof = (alg_bytes_per_launch / (rocprof_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if rocprof_ms else None
+    frac_reported = min(frac_events, frac_rocprof) if frac_rocprof else frac_events
+    # (b) whole-step VALU issue: wave-instructions of the step / step time, against one wave-instruction per 4 cycles per SIMD (256 CUs x
+    #     4 SIMDs) at the clock the chip HELD during the timed steps (sampled) and at the nominal 2.4 GHz
+    step_s = elapsed / args.steps
+    whole_valu = None
+    if valu_step:
+        rate = valu_step / step_s
+        sclk = clock_power["sclk_mhz"] * 1e6 if clock_power else None
+        whole_valu = {"valu_wave_instructions_per_step": valu_step, "achieved": rate, "unit": "wave-instructions/s",
+                      "peak_at_sampled_clock": (1024 * sclk / 4) if sclk else None, "frac": (rate / (1024 * sclk / 4)) if sclk else None,
+                      "peak_at_nominal_2400_mhz": 1024 * 2.4e9 / 4, "frac_at_nominal_2400_mhz": rate / (1024 * 2.4e9 / 4),
+                      "issue_floor_ms_at_sampled_clock": (valu_step / (1024 * sclk / 4) * 1e3) if sclk else None,
+                      "sclk_mhz": clock_power["sclk_mhz"] if clock_power else None, "socket_w": clock_power["socket_w"] if clock_power else None,
+                      "scaled": valu_scaled,
+                      "note": "VALU per wave and waves per launch replayed from the PMC pass under profiles/ (hash-guarded like roofline.traffic); "
+                              "launches per step, step time, clock and power measured in this run"}
+    hbm_traffic_frac = (step_traffic / step_s / 1e9 / HBM_PEAK_GBS) if step_traffic else None
+    vfrac = whole_valu and (whole_valu["frac"] or whole_valu["frac_at_nominal_2400_mhz"])
+    if vfrac and vfrac > 0.75 and hbm_traffic_frac is not None and hbm_traffic_frac < 0.8:
+        limiter = "valu-issue @ power cap"
+    elif hbm_traffic_frac is not None and hbm_traffic_frac >= 0.8:
+        limiter = "hbm"
+    elif vfrac:
+        limiter = "valu-issue (%.2f of the issue rate at the %s clock) + latency / launch tails" % (vfrac, "sampled" if whole_valu["frac"] else "nominal")
+    else:
+        limiter = "undetermined: no PMC replay for this build (profiles/ carries another source hash)"
 
     out = {
         "metric": ("ring-muls/sec (Goldilocks, deg 2^16, batch 2^14)" if args.workload == "goldilocks_d65536_b16384"
@@ -474,11 +642,20 @@ def main():
                               if packed else "ark-ff Montgomery u64 limbs, in place (a *= b), b read-only"),
                    "variant": args.variant, "plan": plan_used,
                    "parallelism": "batch-sharded x%d, twiddle broadcast only" % world},
-        "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
+        "roofline": {"bound": "hbm", "achieved": frac_reported * HBM_PEAK_GBS, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": frac_reported, "traffic": traffic, "traffic_source": traffic_source,
+                     "limiter": limiter,
+                     "frac_is": "the lower of frac_events and frac_rocprof (the same algorithmic bytes per launch over two measurements of the launch's duration)",
+                     "frac_events": frac_events, "frac_rocprof": frac_rocprof,
+                     "kernel_avg_ms_events": dom_avg_ms, "kernel_avg_ms_rocprof": rocprof_ms, "rocprof_kernel": rocprof_kernel, "rocprof_source": rocprof_source,
+                     "events": {"bracketed": "every %d%s launch" % (PROF_STRIDE, "th" if PROF_STRIDE > 1 else "st"), "sampled_launches": dom.get("sampled"),
+                                "profiled_step_ms": profile_step_ms, "timed_step_ms": elapsed / args.steps * 1e3,
+                                "lane_time_ms_per_step": in_flight,
+                                "note": "HIP events on the launch stream around a sparse sample of the launches over K more steps; profiled_step_ms ~ "
+                                        "timed_step_ms says the sampling left the step as it runs"},
                      "copy_measured": copy_gbs, "copy_measured_kind": copy_kind,
-                     "frac_of_copy_measured": achieved_gbs / copy_gbs if copy_gbs else None,
-                     "kernel": dom_tag, "kernel_avg_ms": dom_avg_ms, "launches_per_step": launches_per_step, "by_kernel": by_kernel,
+                     "frac_of_copy_measured": frac_reported * HBM_PEAK_GBS / copy_gbs if copy_gbs else None,
+                     "kernel": dom_tag, "kernel_avg_ms": (alg_bytes_per_launch / (frac_reported * HBM_PEAK_GBS * 1e9) * 1e3), "launches_per_step": launches_per_step, "by_kernel": by_kernel,
                      "launches_per_step_by_kernel": {t: v["launches"] / args.steps for t, v in kern.items()},
                      "algorithmic_bytes_per_ring_mul": bytes_per_mul,
                      "dominant_kernel_bytes_per_ring_mul": kernel_bytes_per_elem,
@@ -507,8 +684,10 @@ def main():
             "achieved": s_launch_bytes / (s_avg * 1e-3) / 1e9, "frac": s_launch_bytes / (s_avg * 1e-3) / 1e9 / HBM_PEAK_GBS,
             "per_kernel_ms_per_step": {t: v["ms"] / v["steps"] for t, v in prof_single.items()}}
 
-    if valu is not None:
-        out["integer_valu"] = valu
+    if valu is not None or whole_valu is not None:
+        out["integer_valu"] = dict(valu or {}, bound=limiter if "valu" in limiter else (valu or {}).get("bound", "valu-issue"), whole_step=whole_valu)
+    if clock_power:
+        out["clock_power"] = clock_power
     if parity:
         out["parity"] = parity
     if dist_on:

@@ -141,6 +141,9 @@ public:
     // Montgomery image of the base-field element
     void neg_dev(uint64_t *d, size_t batch, void *stream) const { check(sr_neg_batch_dev(raw(), d, batch, stream), "neg_dev"); }
     void mul_elem_dev(uint64_t *d, const uint64_t *d_elem, size_t batch, void *stream) const { check(sr_mul_elem_batch_dev(raw(), d, d_elem, batch, stream), "mul_elem_dev"); }
+    // Sum / Product over a device-resident slice (coeff_form.rs:507-537, ntt_form.rs:640-670); out = one ring element outside the slice
+    void sum_dev(uint64_t *out, const uint64_t *in, size_t n, void *stream) const { check(sr_sum_batch_dev(raw(), out, in, n, stream), "sum_dev"); }
+    void product_dev(uint64_t *out, const uint64_t *in_ntt, size_t n, void *stream) const { check(sr_product_batch_dev(raw(), out, in_ntt, n, stream), "product_dev"); }
     void scale_dev(uint64_t *d, const uint64_t *scalar, size_t batch, void *stream) const { check(sr_scale_batch_dev(raw(), d, scalar, batch, stream), "scale_dev"); }
     void add_scalar_dev(uint64_t *d, const uint64_t *scalar, bool ntt_form, size_t batch, void *stream) const {
         check(sr_add_scalar_batch_dev(raw(), d, scalar, ntt_form ? 1 : 0, batch, stream), "add_scalar_dev");
@@ -237,6 +240,14 @@ public:
         CyclotomicConfig::check(sr_add_scalar_batch(cfg_.raw(), w_.data(), scalar.data(), 0, len()), "RqPoly += scalar");
         return *this;
     }
+    // impl Sum<&Self> (coeff_form.rs:507-521): `iter.fold(Self::zero(), |acc, x| acc + x)` -> a vector of ONE element (zero() when empty)
+    RqPolyVec sum() const {
+        std::vector<uint64_t> out(cfg_.words_per_elem());
+        const uint64_t dummy = 0;
+        CyclotomicConfig::check(sr_sum_batch(cfg_.raw(), out.data(), w_.empty() ? &dummy : w_.data(), len()), "RqPoly sum");
+        return RqPolyVec(cfg_, std::move(out));
+    }
+    RqPolyVec product() const;  // impl Product<&Self> (coeff_form.rs:523-537); defined below RqNTTVec
     std::vector<uint64_t> into_words() && { return std::move(w_); }
 
 private:
@@ -298,6 +309,17 @@ public:
         CyclotomicConfig::check(sr_add_scalar_batch(cfg_.raw(), w_.data(), scalar.data(), 1, len()), "RqNTT += scalar");
         return *this;
     }
+    // impl Sum<&Self> / Product<&Self> (ntt_form.rs:640-670): folds over the slice -> a vector of ONE element (zero() / one() when empty)
+    RqNTTVec sum() const {
+        std::vector<uint64_t> out(cfg_.words_per_elem());
+        CyclotomicConfig::check(sr_sum_batch(cfg_.raw(), out.data(), w_.empty() ? dummy_word() : w_.data(), len()), "RqNTT sum");
+        return RqNTTVec(cfg_, std::move(out));
+    }
+    RqNTTVec product() const {
+        std::vector<uint64_t> out(cfg_.words_per_elem());
+        CyclotomicConfig::check(sr_product_batch(cfg_.raw(), out.data(), w_.empty() ? dummy_word() : w_.data(), len()), "RqNTT product");
+        return RqNTTVec(cfg_, std::move(out));
+    }
     std::vector<uint64_t> into_words() && { return std::move(w_); }
 
 private:
@@ -309,6 +331,10 @@ private:
     std::vector<uint64_t> w_;
 };
 
+// `iter.fold(Self::one(), |acc, x| acc * x)` with the ring product = icrt(product(crt(x_i))): the CRT is a ring isomorphism
+inline RqPolyVec RqPolyVec::product() const {
+    return RqPolyVec(*this).elementwise_crt().product().elementwise_icrt();
+}
 inline RqNTTVec RqPolyVec::elementwise_crt() && {
     CyclotomicConfig::check(sr_ntt_fwd_batch(cfg_.raw(), w_.data(), len()), "elementwise_crt");
     return RqNTTVec(cfg_, std::move(w_));

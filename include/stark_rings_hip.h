@@ -83,8 +83,10 @@ enum sr_plan_flags {
     SR_PLAN_STARK_NO_LAZY = 1u << 4,    /* Stark transforms and sums on 8 x 32-bit limbs instead of nine 28-bit lazy limbs       */
     SR_PLAN_STARK_GENERIC_ON_LAZY = 1u << 5, /* Stark: generic LDS kernels on the lazy limbs instead of ntt_stark.hpp            */
     SR_PLAN_NO_HOST_PIN = 1u << 6,      /* accepted, no effect: host buffers are never registered (round 4 removed the pinning)  */
-    SR_PLAN_GL_PLAIN_COLS = 1u << 7     /* Goldilocks lane plans: the plain column pass instead of the workgroup-owns-its-columns
+    SR_PLAN_GL_PLAIN_COLS = 1u << 7,    /* Goldilocks lane plans: the plain column pass instead of the workgroup-owns-its-columns
                                            one (cols256_keep_kernel, ntt_goldilocks.hpp)                                          */
+    SR_PLAN_GL_SPLIT_ROWS = 1u << 8     /* Goldilocks D > 4096 ring products: the fused rows kernel as two launches (crt of b's tiles in
+                                           the scratch, then the constant-operand product) -- A/B plan, measured slower */
 };
 typedef struct sr_plan {
     uint32_t flags;               /* OR of sr_plan_flags                                                                       */
@@ -107,10 +109,20 @@ int sr_ctx_create_ex(int ring, int log2_degree, int device, const sr_plan *plan,
 /* Pre-sizes the context's operand scratch for fused ring products of up to `batch` elements (capped by the plan's
  * scratch_limit_bytes).  Device entry points are asynchronous, with ONE exception: a ring product above one LDS tile whose
  * scratch has to grow first blocks (hipDeviceSynchronize + hipFree + hipMalloc) -- call this once after creating the context
- * (or accept that the first product of a new size blocks) and no _dev call blocks afterwards.  From then on the _dev calls of
+ * (or accept that the first product of a new size blocks) and no _dev call blocks afterwards: the reservation covers ring
+ * products AND stand-alone transforms of up to `batch` elements.  From then on the _dev calls of
  * that batch size can also be CAPTURED into a HIP graph by the caller (hipStreamBeginCapture on `stream`): they neither allocate
  * nor synchronise nor probe, and the internal lanes fork from and join to `stream` by events
  * (tests/test_gpu_parity.py: test_device_calls_can_be_captured_into_a_hip_graph).
+ * LIMITS of capture -- a captured graph bakes in this context's scratch addresses and lane streams:
+ *   (1) the scratch must not move while the graph is alive.  The library enforces its half: once a _dev call has arrived on a
+ *       capturing stream, no _dev call grows a context buffer any more -- one that would have to returns SR_E_INVALID (also during the
+ *       capture itself: reserve first).  Only sr_ctx_reserve_scratch still grows; calling it with a larger batch INVALIDATES graphs
+ *       captured earlier on this context (destroy them first).
+ *   (2) ordering between a replay and other work on the same context is the HOST's job: the event that orders users of the shared
+ *       scratch is recorded at capture time, not at replay, so a replay is unordered against eager _dev calls of this context on
+ *       other streams and against replays of a second graph -- do not overlap them (same stream, or an event / synchronisation of
+ *       your own).  One graph per context at a time; use one context per concurrent graph.
  * Chunking of a batch (sr_plan.chunk_polys = 0): never below 64 MiB of coefficients per set of launches; products take the two
  * lanes from three and a half such chunks on, stand-alone transforms from eight, one set of launches on the caller's stream below. */
 int sr_ctx_reserve_scratch(sr_ctx *ctx, size_t batch);
@@ -166,6 +178,21 @@ int sr_add_scalar_batch(sr_ctx *ctx, uint64_t *data, const uint64_t *scalar, int
  * `row.iter_mut().for_each(|r_m| *r_m *= r)`.  Every ring id (Fq3 / Fq9 / Fq4 slot products for the reference's own rings).
  * elem: D coefficients; it must not lie inside the batch it multiplies (the _dev form: a DEVICE pointer). */
 int sr_mul_elem_batch(sr_ctx *ctx, uint64_t *data_inout, const uint64_t *elem, size_t batch);
+/* Batch reductions of the same element types (round 5): `Sum` and `Product` over a slice of ring elements --
+ *   sr_sum_batch       impl Sum<Self> / Sum<&Self>: `iter.fold(Self::zero(), |acc, x| acc + x)` for RqPoly (coeff_form.rs:507-521)
+ *                      and RqNTT (ntt_form.rs:640-654): n elements -> 1, word-wise, the same in either form, every ring id;
+ *                      n = 0 gives zero().
+ *   sr_product_batch   impl Product<Self> / Product<&Self> for RqNTT: `iter.fold(Self::one(), |acc, x| acc * x)`, slot-wise
+ *                      (ntt_form.rs:656-670), every ring id (Fq3 / Fq9 / Fq4 slot products for the reference's own rings); n = 0
+ *                      gives one() = every slot (1, 0, ..).  Product for RqPoly (coeff_form.rs:523-537, `acc * x` = the ring product)
+ *                      is icrt(product(crt(x_i))): the mirrors compose it from sr_ntt_fwd_batch, this call and sr_ntt_inv_batch on
+ *                      ONE element (include/stark_rings.hpp: product_poly; stark_rings_amd/rings.py: product_poly[_dev]).
+ * out: one ring element; it must not overlap the n input elements.  The folds are associative and commutative and every partial
+ * result is canonical, so the tree order the device uses gives the reference's left fold bit for bit.  Partial elements live in
+ * context-owned temporaries (ordered between caller streams like the operand scratch; sized on first use or by
+ * sr_ctx_reserve_scratch). */
+int sr_sum_batch(sr_ctx *ctx, uint64_t *out, const uint64_t *in, size_t n);
+int sr_product_batch(sr_ctx *ctx, uint64_t *out, const uint64_t *in_ntt, size_t n);
 /* RqPoly * RqPoly == icrt(crt(a) * crt(b)) (coeff_form.rs:250-258; identity tested at
  * stark_prime/mod.rs:161-177).  out may alias a.                                          */
 int sr_ring_mul_batch(sr_ctx *ctx, uint64_t *out, const uint64_t *a, const uint64_t *b, size_t batch);
@@ -184,6 +211,8 @@ int sr_neg_batch_dev(sr_ctx *ctx, uint64_t *d_data, size_t batch, void *stream);
 int sr_scale_batch_dev(sr_ctx *ctx, uint64_t *d_data, const uint64_t *host_scalar, size_t batch, void *stream);
 int sr_add_scalar_batch_dev(sr_ctx *ctx, uint64_t *d_data, const uint64_t *host_scalar, int ntt_form, size_t batch, void *stream);
 int sr_mul_elem_batch_dev(sr_ctx *ctx, uint64_t *d_data_inout, const uint64_t *d_elem, size_t batch, void *stream);
+int sr_sum_batch_dev(sr_ctx *ctx, uint64_t *d_out, const uint64_t *d_in, size_t n, void *stream);
+int sr_product_batch_dev(sr_ctx *ctx, uint64_t *d_out, const uint64_t *d_in_ntt, size_t n, void *stream);
 /* First "next" row: y = M * v for a dense nrows x ncols matrix of ring elements in CRT/NTT form
  * (row-major, each entry one ring element) and a vector of ncols elements -- Matrix<RqNTT>::checked_mul_vec,
  * crates/linear_algebra/src/matrix.rs:168-178 -- as one fused multiply-accumulate pass over M.  Every ring id: the fully
@@ -312,8 +341,13 @@ enum sr_prof_tag {
     SR_PROF_OTHER = 4,
     SR_PROF_NTAGS = 5
 };
+/* on = 0: off; 1: every launch bracketed; N >= 2: every N-th launch only -- two event records around EVERY launch of a two-lane plan open
+ * gaps in which the other lane's kernel runs alone, so fully bracketed steps read shorter in-flight durations than undisturbed ones; a
+ * sparse sample (bench.py uses 7, coprime to the 3, 4 or 6 launches of a chunk) leaves the step as it runs.
+ * sr_ctx_profile_read_sampled: ms_total / launches over the bracketed launches, seen = every launch that went by, per tag. */
 int sr_ctx_profile_enable(sr_ctx *ctx, int on);
 int sr_ctx_profile_read(sr_ctx *ctx, double ms_total[SR_PROF_NTAGS], uint64_t launches[SR_PROF_NTAGS]);
+int sr_ctx_profile_read_sampled(sr_ctx *ctx, double ms_total[SR_PROF_NTAGS], uint64_t launches[SR_PROF_NTAGS], uint64_t seen[SR_PROF_NTAGS]);
 
 /* Host-side self-test hook for the CPU test-suite: one scalar field operation computed by the same
  * source the kernels compile (fields.hpp).  field: 0 Goldilocks, 1 BabyBear, 2 Stark.
@@ -326,7 +360,9 @@ int sr_selftest_field_op(int field, int op, const uint64_t *a, const uint64_t *b
  * kernels of the tuned Goldilocks path run, every canonical butterfly counts a non-canonical input, every lazy butterfly a second
  * wrap or borrow, every result store a word >= p; the lazy nine-limb Stark arithmetic counts limb sums that leave int32 and
  * products that could overflow a column accumulator (csrc/fields.hpp: repcheck).  counters[0..6] as documented there, counters[7]
- * = the largest |limb| any Stark add / sub produced; reset != 0 clears them.  Synchronises the device.  The product library returns SR_E_UNSUPPORTED: it carries no checks.
+ * = the largest |limb| any Stark add / sub produced; reset != 0 clears them.  The counters are per-device symbols: the call visits EVERY
+ * visible HIP device (synchronising each), sums [0..6] and takes the maximum of [7], so work done by contexts on any device is seen.
+ * The product library returns SR_E_UNSUPPORTED: it carries no checks.
  * Not a compute path. */
 int sr_selftest_rep_counters(uint64_t counters[8], int reset);
 

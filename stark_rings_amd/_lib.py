@@ -38,6 +38,10 @@ SYMBOLS = {
     "sr_scale_batch_dev": (_c.c_int, [_c.c_void_p, _c.c_void_p, u64p, _c.c_size_t, _c.c_void_p]),
     "sr_mul_elem_batch": (_c.c_int, [_c.c_void_p, u64p, u64p, _c.c_size_t]),
     "sr_mul_elem_batch_dev": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_size_t, _c.c_void_p]),
+    "sr_sum_batch": (_c.c_int, [_c.c_void_p, u64p, u64p, _c.c_size_t]),
+    "sr_product_batch": (_c.c_int, [_c.c_void_p, u64p, u64p, _c.c_size_t]),
+    "sr_sum_batch_dev": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_size_t, _c.c_void_p]),
+    "sr_product_batch_dev": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_size_t, _c.c_void_p]),
     "sr_add_scalar_batch_dev": (_c.c_int, [_c.c_void_p, _c.c_void_p, u64p, _c.c_int, _c.c_size_t, _c.c_void_p]),
     "sr_reduce_batch": (_c.c_int, [_c.c_void_p, u64p, _c.c_size_t, u64p, _c.c_size_t]),
     "sr_ntt_fwd_batch_dev": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_size_t, _c.c_void_p]),
@@ -85,6 +89,7 @@ SYMBOLS = {
     "sr_count_noncanonical_dev": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_size_t, _c.POINTER(_c.c_uint64), _c.c_void_p]),
     "sr_ctx_profile_enable": (_c.c_int, [_c.c_void_p, _c.c_int]),
     "sr_ctx_profile_read": (_c.c_int, [_c.c_void_p, _c.POINTER(_c.c_double), _c.POINTER(_c.c_uint64)]),
+    "sr_ctx_profile_read_sampled": (_c.c_int, [_c.c_void_p, _c.POINTER(_c.c_double), _c.POINTER(_c.c_uint64), _c.POINTER(_c.c_uint64)]),
     "sr_selftest_field_op": (_c.c_int, [_c.c_int, _c.c_int, u64p, u64p, u64p]),
     "sr_selftest_rep_counters": (_c.c_int, [u64p, _c.c_int]),
     "sr_last_error_string": (_c.c_char_p, []),
@@ -103,6 +108,7 @@ PLAN_GENERIC_KERNELS, PLAN_GL_NO_COLS256, PLAN_RT_NO_COLS256 = 1, 2, 4
 PLAN_GL_REGTILE, PLAN_STARK_NO_LAZY, PLAN_STARK_GENERIC_ON_LAZY = 8, 16, 32
 PLAN_NO_HOST_PIN = 64
 PLAN_GL_PLAIN_COLS = 128
+PLAN_GL_SPLIT_ROWS = 256
 
 
 def plan_from_env(ring=None):
@@ -126,6 +132,8 @@ def plan_from_env(ring=None):
         f |= PLAN_NO_HOST_PIN
     if e.get("SR_GL_KEEP_COLS") == "0":
         f |= PLAN_GL_PLAIN_COLS
+    if e.get("SR_GL_SPLIT_ROWS") == "1":
+        f |= PLAN_GL_SPLIT_ROWS
     p = Plan()
     p.flags = f
     p.log_tile = int(e.get("SR_LOG_TILE", "0") or 0)

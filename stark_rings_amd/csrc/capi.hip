@@ -47,6 +47,13 @@ enum KernelTag { K_FWD_COLS = 0, K_ROWS = 1, K_INV_COLS = 2, K_POINTWISE = 3, K_
 
 struct Prof {
     bool on = false;
+    // stride > 1: only every stride-th launch is bracketed by events (sr_ctx_profile_enable(ctx, stride)).  Two event records around
+    // EVERY launch of a two-lane plan open a gap on that lane in which the other lane's kernel runs alone, so fully bracketed steps
+    // report shorter in-flight durations than the timed steps have (70-82 against 90-97 us for the config-2 rows kernel, round 4);
+    // a sparse sample leaves the step as it runs.  `seen` counts every launch, `launches` the bracketed ones.
+    unsigned stride = 1;
+    uint64_t tick = 0;
+    bool open = false;  // the launch between gl_prof_begin and gl_prof_end is a bracketed one
     struct Pair {
         hipEvent_t a, b;
         int tag;
@@ -54,6 +61,11 @@ struct Prof {
     std::vector<Pair> pending;
     double ms[K_NTAGS] = {0, 0, 0, 0, 0};
     uint64_t launches[K_NTAGS] = {0, 0, 0, 0, 0};
+    uint64_t seen[K_NTAGS] = {0, 0, 0, 0, 0};
+    bool sample(int tag) {
+        seen[tag]++;
+        return tick++ % stride == 0;
+    }
 };
 
 }  // namespace
@@ -93,10 +105,15 @@ struct sr_ctx {
     size_t lanes_probe_elems = 0;
     size_t probe_chunk = 0;
     bool probing = false;
-    void *host_tmp[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // device temporaries of the host-pointer
-    size_t host_tmp_bytes[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // linear-algebra / decomposition calls (grow-only, see DevBuf); [5], [6]: the
-                                                          // widened operands of packed-u32 calls below D = 4096, [7]: the row parts of
-                                                          // a short-and-wide small-ring mat-vec (DevBufLite)
+    static constexpr int kTmpSlots = 10;
+    void *host_tmp[kTmpSlots] = {};         // device temporaries of the host-pointer linear-algebra / decomposition calls (grow-only,
+    size_t host_tmp_bytes[kTmpSlots] = {};  // see DevBuf); [5], [6]: the widened operands of packed-u32 calls below D = 4096, [7]: the
+                                            // row parts of a short-and-wide small-ring mat-vec, [8], [9]: the partial elements of
+                                            // sr_sum_batch_dev / sr_product_batch_dev (DevBufLite)
+    // A _dev call has been seen on a stream under capture: a captured graph holds the scratch pointers of this context, so they may
+    // no longer move -- from then on only sr_ctx_reserve_scratch (explicit, blocking, documented to invalidate earlier graphs) grows
+    // a buffer; an asynchronous call that would have to fails with SR_E_INVALID instead of freeing memory a graph still writes to.
+    bool scratch_frozen = false;
     void *stage[4] = {nullptr, nullptr, nullptr, nullptr};  // [2], [3]: second lane of the chunked host pipeline
     size_t stage_bytes[4] = {0, 0, 0, 0};
     hipStream_t stream = nullptr;
@@ -129,15 +146,17 @@ struct ProfScope {
     hipStream_t s;
     int tag;
     hipEvent_t a = nullptr, b = nullptr;
+    bool sampled = false;
     ProfScope(sr_ctx *ctx, hipStream_t st, int t) : c(ctx), s(st), tag(t) {
-        if (c->prof.on) {
+        sampled = c->prof.on && c->prof.sample(tag);
+        if (sampled) {
             (void)hipEventCreate(&a);
             (void)hipEventCreate(&b);
             (void)hipEventRecord(a, s);
         }
     }
     ~ProfScope() {
-        if (c->prof.on) {
+        if (sampled) {
             (void)hipEventRecord(b, s);
             c->prof.pending.push_back({a, b, tag});
         }
@@ -147,18 +166,22 @@ struct ProfScope {
 // timing hooks handed to the tuned Goldilocks launcher (tags: 0 strided fwd, 1 rows, 2 strided inv)
 void gl_prof_begin(void *user, int tag, hipStream_t st) {
     sr_ctx *c = (sr_ctx *)user;
+    c->prof.open = false;
     if (!c->prof.on) return;
     Prof::Pair p;
+    p.tag = tag == 0 ? K_FWD_COLS : (tag == 1 ? K_ROWS : K_INV_COLS);
+    if (!c->prof.sample(p.tag)) return;
     (void)hipEventCreate(&p.a);
     (void)hipEventCreate(&p.b);
-    p.tag = tag == 0 ? K_FWD_COLS : (tag == 1 ? K_ROWS : K_INV_COLS);
     (void)hipEventRecord(p.a, st);
     c->prof.pending.push_back(p);
+    c->prof.open = true;
 }
 void gl_prof_end(void *user, hipStream_t st) {
     sr_ctx *c = (sr_ctx *)user;
-    if (!c->prof.on || c->prof.pending.empty()) return;
+    if (!c->prof.open || c->prof.pending.empty()) return;
     (void)hipEventRecord(c->prof.pending.back().b, st);
+    c->prof.open = false;
 }
 
 template <class F>
@@ -291,6 +314,7 @@ int init_pow2(sr_ctx *c) {
                              (uint64_t)fused, !(c->plan.flags & SR_PLAN_GL_NO_COLS256), c->plan.chunk_polys, c->stream))
             return fail(SR_E_HIP, "goldilocks fast-path table build failed");
         c->gl_fast.keep_cols = !(c->plan.flags & SR_PLAN_GL_PLAIN_COLS);
+        c->gl_fast.split_rows = (c->plan.flags & SR_PLAN_GL_SPLIT_ROWS) != 0 && k > 12;
     }
     return SR_OK;
 }
@@ -445,8 +469,23 @@ int matmul_dev(sr_ctx *c, uint64_t *y, const uint64_t *a, const uint64_t *b, siz
     HIP_TRY(hipGetLastError());
     return SR_OK;
 }
-// operand scratch (defined below): grow-only device buffers owned by the context, ordered between streams by an event
-int ensure_scratch(sr_ctx *c, int n_buffers, size_t bytes);
+// operand scratch (defined below): grow-only device buffers owned by the context, ordered between streams by an event.  st = the
+// stream of the call that needs it (nullptr: sr_ctx_reserve_scratch, which may always grow).
+int ensure_scratch(sr_ctx *c, int n_buffers, size_t bytes, hipStream_t st);
+// remembers that a call arrived on a capturing stream (sr_ctx::scratch_frozen); true while `st` is being captured
+bool note_capture(sr_ctx *c, hipStream_t st) {
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (st && hipStreamIsCapturing(st, &cs) == hipSuccess && cs == hipStreamCaptureStatusActive) {
+        c->scratch_frozen = true;
+        return true;
+    }
+    (void)hipGetLastError();
+    return false;
+}
+int frozen_fail() {
+    return fail(SR_E_INVALID, "context scratch would have to grow, but a stream capture has used it (a captured graph holds its address): "
+                              "call sr_ctx_reserve_scratch for the largest batch BEFORE capturing (include/stark_rings_hip.h)");
+}
 int rt_scratch_acquire(sr_ctx *c, hipStream_t st);
 int rt_scratch_release(sr_ctx *c, hipStream_t st);
 // One use of the shared operand scratch by a call on stream st.  The release (an event recorded on st, which the next user on another
@@ -458,6 +497,7 @@ struct ScratchUse {
     bool held = false;
     ScratchUse(sr_ctx *ctx, hipStream_t s) : c(ctx), st(s) {}
     int acquire() {
+        note_capture(c, st);
         const int rc = rt_scratch_acquire(c, st);
         held = rc == SR_OK;
         return rc;
@@ -476,9 +516,11 @@ struct DevBufLite {
     int slot;
     void *p = nullptr;
     DevBufLite(sr_ctx *c_, int slot_) : c(c_), slot(slot_) {}
-    int alloc(size_t bytes) {
+    int alloc(size_t bytes, hipStream_t st = nullptr) {
         if (bytes == 0) bytes = 8;
+        const bool capturing = note_capture(c, st);
         if (c->host_tmp_bytes[slot] < bytes) {
+            if (capturing || (st && c->scratch_frozen)) return frozen_fail();
             if (c->host_tmp[slot]) {
                 HIP_TRY(hipDeviceSynchronize());  // a _dev call on another stream may still be using the smaller buffer
                 (void)hipFree(c->host_tmp[slot]);
@@ -583,7 +625,7 @@ int ring_mul_dev(sr_ctx *c, uint64_t *out, const uint64_t *a, const uint64_t *b,
         // neither operand is written (coeff_form.rs:250-258); batches beyond the scratch cap run in chunks
         const size_t elem = sizeof(S) << c->k;
         const size_t chunk = scratch_polys(c, batch, elem);
-        if (int rc = ensure_scratch(c, 1, chunk * elem)) return rc;
+        if (int rc = ensure_scratch(c, 1, chunk * elem, st)) return rc;
         ScratchUse su(c, st);
         if (int rc = su.acquire()) return rc;
         S *sb = reinterpret_cast<S *>(c->rt_scratch[0]);
@@ -659,9 +701,11 @@ sr::rt::Params<F> make_rt_params(const sr_ctx *c, bool fused) {
 }
 // grow-only scratch for packed intermediates (allocated on first use; a hipMalloc here is why the very first
 // call of a given size is not graph-capturable)
-int ensure_scratch(sr_ctx *c, int n_buffers, size_t bytes) {
+int ensure_scratch(sr_ctx *c, int n_buffers, size_t bytes, hipStream_t st) {
+    const bool capturing = note_capture(c, st);
     for (int i = 0; i < n_buffers; i++) {
         if (c->rt_scratch_bytes[i] >= bytes) continue;
+        if (capturing || (st && c->scratch_frozen)) return frozen_fail();
         HIP_TRY(hipDeviceSynchronize());
         if (c->rt_scratch[i]) HIP_TRY(hipFree(c->rt_scratch[i]));
         c->rt_scratch[i] = nullptr;
@@ -673,9 +717,9 @@ int ensure_scratch(sr_ctx *c, int n_buffers, size_t bytes) {
     return SR_OK;
 }
 // stream ordering of the shared scratch (callers hold the context's mutex, so the bookkeeping itself is serialised)
-int rt_ensure_scratch(sr_ctx *c, int n_buffers, size_t bytes) {
+int rt_ensure_scratch(sr_ctx *c, int n_buffers, size_t bytes, hipStream_t st) {
     if (c->k <= 12) return SR_OK;
-    return ensure_scratch(c, n_buffers, bytes);
+    return ensure_scratch(c, n_buffers, bytes, st);
 }
 int rt_scratch_acquire(sr_ctx *c, hipStream_t st) {
     if (!c->rt_scratch_free) HIP_TRY(hipEventCreateWithFlags(&c->rt_scratch_free, hipEventDisableTiming));
@@ -700,7 +744,7 @@ int rt_transform_lanes(sr_ctx *c, void *d, size_t batch, hipStream_t st) {
     using E = typename F::elem;
     using S = typename sr::rt::View<F, VB>::T;
     const size_t chunk = rt_lane_chunk<F>(c), words = chunk << c->k;
-    if (int rc = ensure_scratch(c, 1, 4 * words * sizeof(E))) return rc;
+    if (int rc = ensure_scratch(c, 1, 4 * words * sizeof(E), st)) return rc;
     if (int rc = gl_lanes_init(c)) return rc;
     ScratchUse su(c, st);
     if (int rc = su.acquire()) return rc;
@@ -729,7 +773,7 @@ template <class F, class VB = sr::rt::Boundary>
 int rt_fwd(sr_ctx *c, void *d, size_t batch, hipStream_t st) {
     using E = typename F::elem;
     if (rt_use_lanes_transform<F>(c, batch, st)) return rt_transform_lanes<F, 0, VB>(c, d, batch, st);
-    if (int rc = rt_ensure_scratch(c, 1, (batch << c->k) * sizeof(E))) return rc;
+    if (int rc = rt_ensure_scratch(c, 1, (batch << c->k) * sizeof(E), st)) return rc;
     ScratchUse su(c, st);
     if (int rc = su.acquire()) return rc;
     if (sr::rt::fwd<F, VB>(c->rt_hooks, reinterpret_cast<typename sr::rt::View<F, VB>::T *>(d), batch, make_rt_params<F>(c, false),
@@ -741,7 +785,7 @@ template <class F, class VB = sr::rt::Boundary>
 int rt_inv(sr_ctx *c, void *d, size_t batch, hipStream_t st) {
     using E = typename F::elem;
     if (rt_use_lanes_transform<F>(c, batch, st)) return rt_transform_lanes<F, 1, VB>(c, d, batch, st);
-    if (int rc = rt_ensure_scratch(c, 1, (batch << c->k) * sizeof(E))) return rc;
+    if (int rc = rt_ensure_scratch(c, 1, (batch << c->k) * sizeof(E), st)) return rc;
     ScratchUse su(c, st);
     if (int rc = su.acquire()) return rc;
     if (sr::rt::inv<F, VB>(c->rt_hooks, reinterpret_cast<typename sr::rt::View<F, VB>::T *>(d), batch, make_rt_params<F>(c, false),
@@ -783,7 +827,7 @@ int rt_ring_mul(sr_ctx *c, void *out, const void *a, const void *b, size_t batch
     if (batch == 0) return SR_OK;
     if (rt_use_lanes<F>(c, batch, st)) {
         const size_t chunk = rt_lane_chunk<F>(c), words = chunk << c->k;
-        if (int rc = ensure_scratch(c, 1, 4 * words * sizeof(E))) return rc;
+        if (int rc = ensure_scratch(c, 1, 4 * words * sizeof(E), st)) return rc;
         if (int rc = gl_lanes_init(c)) return rc;
         ScratchUse su(c, st);
         if (int rc = su.acquire()) return rc;
@@ -809,7 +853,7 @@ int rt_ring_mul(sr_ctx *c, void *out, const void *a, const void *b, size_t batch
         return rc ? fail(SR_E_HIP, "register-tiled launch failed") : SR_OK;
     }
     const size_t chunk = c->k > 12 ? rt_chunk_polys(c, batch) : batch;
-    if (int rc = rt_ensure_scratch(c, 2, (chunk << c->k) * sizeof(E))) return rc;
+    if (int rc = rt_ensure_scratch(c, 2, (chunk << c->k) * sizeof(E), st)) return rc;
     ScratchUse su(c, st);
     if (int rc = su.acquire()) return rc;
     for (size_t e = 0; e < batch; e += chunk) {
@@ -860,7 +904,7 @@ int st_ring_mul(sr_ctx *c, uint64_t *out, const uint64_t *a, const uint64_t *b, 
     // strided stages of both operands first: a's go straight to out, b's into the operand scratch (neither is written)
     const size_t elem = sizeof(S) << c->k;
     const size_t chunk = scratch_polys(c, batch, elem);
-    if (int rc = ensure_scratch(c, 1, chunk * elem)) return rc;
+    if (int rc = ensure_scratch(c, 1, chunk * elem, st)) return rc;
     ScratchUse su(c, st);
     if (int rc = su.acquire()) return rc;
     S *sb = reinterpret_cast<S *>(c->rt_scratch[0]);
@@ -1201,6 +1245,118 @@ int dev_add_scalar(sr_ctx *c, uint64_t *d, const uint64_t *scalar, bool ntt_form
     const size_t stride = ntt_form ? slot_words(c) : c->degree, count = batch * c->degree / stride;
     DISPATCH_BASE_FIELD(c, (add_scalar_dev<F>(c, d, scalar, count, stride, st)));
 }
+// ---- Sum / Product over a slice of ring elements (coeff_form.rs:507-537, ntt_form.rs:640-670) --------------------------------------
+// partial elements one stage of the word-wise fold leaves: about 2^20 lanes in flight, at least 32 elements per lane, one element
+// once 32 or fewer remain
+size_t fold_parts(size_t n, size_t w) {
+    if (n <= 32) return 1;
+    size_t r = (n + 31) / 32, cap = ((size_t)1 << 20) / w;
+    if (cap < 1) cap = 1;
+    return r < cap ? r : cap;
+}
+size_t fold_tmp_words(size_t w) { return w > ((size_t)1 << 20) ? w : ((size_t)1 << 20); }  // r * w <= max(w, 2^20)
+extern "C++" {
+template <class F, bool MUL>
+int fold_dev(sr_ctx *c, uint64_t *out, const uint64_t *in, size_t n, hipStream_t st) {
+    using S = typename F::storage;
+    const size_t w = c->degree;  // storage words (coefficients) per ring element
+    DevBufLite t0(c, 8), t1(c, 9);
+    ScratchUse su(c, st);
+    const S *src = reinterpret_cast<const S *>(in);
+    bool tmp_used = false;
+    int flip = 0;
+    while (true) {
+        const size_t r = fold_parts(n, w);
+        S *dst = reinterpret_cast<S *>(out);
+        if (r > 1) {
+            DevBufLite &t = flip ? t1 : t0;
+            if (int rc = t.alloc(fold_tmp_words(w) * sizeof(S), st)) return rc;
+            if (!tmp_used) {
+                if (int rc = su.acquire()) return rc;
+                tmp_used = true;
+            }
+            dst = reinterpret_cast<S *>(t.p);
+            flip ^= 1;
+        }
+        const size_t lanes = r * w;
+        {
+            ProfScope ps(c, st, K_OTHER);
+            hipLaunchKernelGGL((sr::fold_stage_kernel<F, MUL>), dim3((unsigned)((lanes + 255) / 256)), dim3(256), 0, st, dst, src, w, n, r);
+            HIP_TRY(hipGetLastError());
+        }
+        if (r == 1) break;
+        src = dst;
+        n = r;
+    }
+    return tmp_used ? su.release() : SR_OK;
+}
+// the Montgomery memory image of the base field's 1 (R mod p = mul_boundary(1, R^2))
+template <class F>
+void mont_one_image(uint64_t out[4]) {
+    typename F::storage s;
+    F::store(&s, F::mul_boundary(sr::dec::Consts<F>::one(), sr::dec::Consts<F>::r2()));
+    memset(out, 0, 32);
+    memcpy(out, &s, sizeof(s));
+}
+}  // extern "C++"
+// out = l (.) r slot-wise, out of place, for the three reference-native rings (their slot-product kernels take an output pointer)
+int small_slot_mul_to(sr_ctx *c, uint64_t *out, const uint64_t *l, const uint64_t *r, size_t batch, hipStream_t st) {
+    if (c->ring == SR_RING_FROG_16) return sr::frog_launch(c->frog, sr::FROG_MUL, l, r, 0, out, batch, st) ? fail(SR_E_HIP, "frog-ring launch failed") : SR_OK;
+    const int op = c->ring == SR_RING_GOLDILOCKS_24 ? sr::SMALL_G24_MUL : sr::SMALL_B72_MUL;
+    return sr::small_launch(c->small, op, l, r, 0, out, batch, st) ? fail(SR_E_HIP, "small-ring launch failed") : SR_OK;
+}
+// n == 0: zero() / one() (one(): component 0 of every slot is the base field's 1)
+int fold_empty(sr_ctx *c, uint64_t *out, bool mul, hipStream_t st) {
+    const size_t bytes = c->degree * c->limbs * 8;
+    HIP_TRY(hipMemsetAsync(out, 0, bytes, st));
+    if (!mul) return SR_OK;
+    uint64_t one[4];
+    switch (c->ring) {
+        case SR_RING_GOLDILOCKS_POW2: case SR_RING_GOLDILOCKS_24: mont_one_image<sr::Goldilocks>(one); break;
+        case SR_RING_BABYBEAR_POW2: case SR_RING_BABYBEAR_72: mont_one_image<sr::BabyBear>(one); break;
+        case SR_RING_FROG_16: mont_one_image<sr::Frog>(one); break;
+        default: mont_one_image<sr::Stark>(one); break;
+    }
+    return dev_add_scalar(c, out, one, true, 1, st);
+}
+int dev_sum(sr_ctx *c, uint64_t *out, const uint64_t *in, size_t n, hipStream_t st) {
+    if (n == 0) return fold_empty(c, out, false, st);
+    DISPATCH_BASE_FIELD(c, (fold_dev<F, false>(c, out, in, n, st)));
+}
+int dev_product(sr_ctx *c, uint64_t *out, const uint64_t *in, size_t n, hipStream_t st) {
+    if (n == 0) return fold_empty(c, out, true, st);
+    if (is_pow2_ring(c->ring)) {  // fully split: the slot product is the base field's product on the memory images
+        DISPATCH_POW2(c, (fold_dev<F, true>(c, out, in, n, st)));
+    }
+    // Fq3 / Fq9 / Fq4 slots: a halving tree of the rings' own slot-product kernels.  First level out of place (the input is only
+    // read): tmp[i] = in[i] * in[m + i] for i < h = n / 2, m = n - h, the middle element of an odd n copied; then in place.
+    const size_t w = c->degree, bytes = w * 8;
+    if (n == 1) {
+        HIP_TRY(hipMemcpyAsync(out, in, bytes, hipMemcpyDeviceToDevice, st));
+        return SR_OK;
+    }
+    size_t h = n / 2, m = n - h;
+    DevBufLite t(c, 8);
+    if (int rc = t.alloc(m * bytes, st)) return rc;
+    ScratchUse su(c, st);
+    if (int rc = su.acquire()) return rc;
+    uint64_t *tmp = (uint64_t *)t.p;
+    {
+        ProfScope ps(c, st, K_POINTWISE);
+        if (int rc = small_slot_mul_to(c, tmp, in, in + m * w, h, st)) return rc;
+    }
+    if (m > h) HIP_TRY(hipMemcpyAsync(tmp + h * w, in + h * w, bytes, hipMemcpyDeviceToDevice, st));
+    n = m;
+    while (n > 1) {
+        h = n / 2;
+        m = n - h;
+        ProfScope ps(c, st, K_POINTWISE);
+        if (int rc = small_slot_mul_to(c, tmp, tmp, tmp + m * w, h, st)) return rc;
+        n = m;
+    }
+    HIP_TRY(hipMemcpyAsync(out, tmp, bytes, hipMemcpyDeviceToDevice, st));
+    return su.release();
+}
 // the three reference-native rings: one slot (Fq3 / Fq9 / Fq4) per lane, small_linalg.hpp
 #define DISPATCH_SLOT(c, CALL)                                                                                   \
     switch ((c)->ring) {                                                                                         \
@@ -1237,7 +1393,7 @@ int dev_matvec(sr_ctx *c, uint64_t *y, const uint64_t *m, const uint64_t *v, siz
         ScratchUse su(c, st);
         if (nsplit > 1) {
             DevBufLite pb(c, 7);
-            if (int rc = pb.alloc(nrows * nsplit * c->degree * 8)) return rc;
+            if (int rc = pb.alloc(nrows * nsplit * c->degree * 8, st)) return rc;
             part = (uint64_t *)pb.p;
             if (int rc = su.acquire()) return rc;
         }
@@ -1369,7 +1525,7 @@ int dev_ring_mul(sr_ctx *c, uint64_t *out, const uint64_t *a, const uint64_t *b,
         // drives this function on the very streams the lanes are and is bound by PCIe anyway)
         if (gl_use_lanes(c, batch) && st != c->stream && st != c->out_stream) {
             const size_t chunk = gl_lane_chunk(c), words = chunk << c->k;
-            if (int rc = ensure_scratch(c, 1, 4 * words * 8)) return rc;
+            if (int rc = ensure_scratch(c, 1, 4 * words * 8, st)) return rc;
             if (int rc = gl_lanes_init(c)) return rc;
             ScratchUse su(c, st);
             if (int rc = su.acquire()) return rc;
@@ -1389,7 +1545,7 @@ int dev_ring_mul(sr_ctx *c, uint64_t *out, const uint64_t *a, const uint64_t *b,
         ScratchUse su(c, st);
         if (c->k > 12 && batch) {  // b's column stages go through the operand scratch
             chunk = gl_chunk_polys(c, batch);
-            if (int rc = ensure_scratch(c, 1, chunk * ((size_t)8 << c->k))) return rc;
+            if (int rc = ensure_scratch(c, 1, chunk * ((size_t)8 << c->k), st)) return rc;
             if (int rc = su.acquire()) return rc;
             scratch = reinterpret_cast<uint64_t *>(c->rt_scratch[0]);
         }
@@ -1407,7 +1563,7 @@ int dev_ring_mul_ntt_rhs(sr_ctx *c, uint64_t *out, const uint64_t *a, const uint
     if (c->ring == SR_RING_GOLDILOCKS_POW2 && !c->regtile && c->fast_goldilocks && sr::gl_fast_supported(c->gl_fast) && c->k >= 8) {
         if (gl_use_lanes(c, batch) && st != c->stream && st != c->out_stream) {  // as dev_ring_mul: chunks on the two lanes
             const size_t chunk = gl_lane_chunk(c), words = chunk << c->k;
-            if (int rc = ensure_scratch(c, 1, 4 * words * 8)) return rc;
+            if (int rc = ensure_scratch(c, 1, 4 * words * 8, st)) return rc;
             if (int rc = gl_lanes_init(c)) return rc;
             ScratchUse su(c, st);
             if (int rc = su.acquire()) return rc;
@@ -1550,7 +1706,7 @@ int sr_ctx_destroy(sr_ctx *c) {
         if (c->rt_scratch[i]) (void)hipFree(c->rt_scratch[i]);
     if (c->out_stream) (void)hipStreamDestroy(c->out_stream);
     if (c->rt_scratch_free) (void)hipEventDestroy(c->rt_scratch_free);
-    for (int i = 0; i < 8; i++)
+    for (int i = 0; i < sr_ctx::kTmpSlots; i++)
         if (c->host_tmp[i]) (void)hipFree(c->host_tmp[i]);
     if (c->gl_lanes.n) {
         for (int i = 0; i < 2; i++)
@@ -1654,6 +1810,25 @@ int sr_mul_elem_batch_dev(sr_ctx *c, uint64_t *d, const uint64_t *elem, size_t b
     std::lock_guard<std::mutex> lk(c->mu);
     DeviceGuard g(c->device);
     return dev_mul_elem(c, d, elem, batch, (hipStream_t)stream);
+}
+static int check_fold(sr_ctx *c, const uint64_t *out, const uint64_t *in, size_t n) {
+    if (int rc = check(c, out, n ? (const void *)in : (const void *)1)) return rc;
+    if (int rc = check_count(c, n)) return rc;
+    const uintptr_t w = (uintptr_t)c->degree * c->limbs * 8, po = (uintptr_t)out, pi = (uintptr_t)in;
+    if (n && po + w > pi && pi + n * w > po) return fail(SR_E_INVALID, "sum / product: out must not overlap the input elements");
+    return SR_OK;
+}
+int sr_sum_batch_dev(sr_ctx *c, uint64_t *out, const uint64_t *in, size_t n, void *stream) {
+    if (int rc = check_fold(c, out, in, n)) return rc;
+    std::lock_guard<std::mutex> lk(c->mu);
+    DeviceGuard g(c->device);
+    return dev_sum(c, out, in, n, (hipStream_t)stream);
+}
+int sr_product_batch_dev(sr_ctx *c, uint64_t *out, const uint64_t *in, size_t n, void *stream) {
+    if (int rc = check_fold(c, out, in, n)) return rc;
+    std::lock_guard<std::mutex> lk(c->mu);
+    DeviceGuard g(c->device);
+    return dev_product(c, out, in, n, (hipStream_t)stream);
 }
 int sr_add_batch_dev(sr_ctx *c, uint64_t *l, const uint64_t *r, size_t batch, void *stream) {
     if (int rc = check(c, l, r)) return rc;
@@ -1907,6 +2082,26 @@ int sr_spmv_ntt(sr_ctx *c, uint64_t *y, const uint64_t *vals, const uint32_t *co
     HIP_TRY(hipStreamSynchronize(c->stream));
     return SR_OK;
 }
+// Sum / Product on host buffers: the n elements go to a device temporary as a whole (like the linear-algebra calls above)
+static int host_fold(sr_ctx *c, uint64_t *out, const uint64_t *in, size_t n, bool mul) {
+    if (int rc = check_fold(c, out, in, n)) return rc;
+    std::lock_guard<std::mutex> lk(c->mu);
+    DeviceGuard g(c->device);
+    const size_t w = (size_t)c->degree * c->limbs * 8;
+    DevBuf di(c, 0), dout(c, 1);
+    if (int rc = di.alloc(n * w)) return rc;
+    if (int rc = dout.alloc(w)) return rc;
+    if (n) HIP_TRY(hipMemcpyAsync(di.p, in, n * w, hipMemcpyHostToDevice, c->stream));
+    if (int rc = mul ? dev_product(c, (uint64_t *)dout.p, (const uint64_t *)di.p, n, c->stream) : dev_sum(c, (uint64_t *)dout.p, (const uint64_t *)di.p, n, c->stream)) {
+        (void)hipStreamSynchronize(c->stream);
+        return rc;
+    }
+    HIP_TRY(hipMemcpyAsync(out, dout.p, w, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return SR_OK;
+}
+int sr_sum_batch(sr_ctx *c, uint64_t *out, const uint64_t *in, size_t n) { return host_fold(c, out, in, n, false); }
+int sr_product_batch(sr_ctx *c, uint64_t *out, const uint64_t *in, size_t n) { return host_fold(c, out, in, n, true); }
 int sr_decompose_balanced_batch(sr_ctx *c, uint64_t *out, const uint64_t *in, uint64_t basis, size_t padding_size, size_t batch) {
     return sr_decompose_balanced_batch_wide(c, out, in, basis, 0, padding_size, batch);
 }
@@ -2014,18 +2209,37 @@ int sr_ctx_reserve_scratch(sr_ctx *c, size_t batch) {
     if (int rc = check_count(c, batch)) return rc;
     std::lock_guard<std::mutex> lk(c->mu);
     DeviceGuard g(c->device);
-    if (!is_pow2_ring(c->ring) || batch == 0) return SR_OK;  // the small rings need no scratch
+    if (batch == 0) return SR_OK;
+    {   // the two partial-element buffers of sr_sum_batch_dev / sr_product_batch_dev (a few MiB; the small rings' product tree sizes its
+        // own by the slice length on first use)
+        const size_t sw = (size_t)c->limbs * 8;  // bytes per coefficient
+        for (int slot = 8; slot <= 9; slot++) {
+            DevBufLite t(c, slot);
+            if (int rc = t.alloc(fold_tmp_words(c->degree) * sw)) return rc;
+        }
+    }
+    if (!is_pow2_ring(c->ring)) return SR_OK;  // the small rings need no operand scratch
     if (int rc = lanes_autoselect(c, batch)) return rc;      // sr_plan.lanes = 0: settle the plan now, then size the scratch for it
     const size_t elem = c->degree * c->limbs * 8;
     if (c->regtile) {
-        const size_t w = c->ring == SR_RING_BABYBEAR_POW2 ? 4 : 8;
-        const bool lanes = c->ring == SR_RING_BABYBEAR_POW2 ? rt_use_lanes<sr::BabyBear>(c, batch, nullptr) : rt_use_lanes<sr::Goldilocks>(c, batch, nullptr);
-        if (lanes) {
-            const size_t chunk = c->ring == SR_RING_BABYBEAR_POW2 ? rt_lane_chunk<sr::BabyBear>(c) : rt_lane_chunk<sr::Goldilocks>(c);
+        // BOTH users of the packed scratch: the ring product (four lane chunks on two lanes, else two buffers of one chunk) and the
+        // stand-alone transforms, whose lanes only start at eight chunks (lanes_pay_transform): below that they run on the caller's
+        // stream through ONE buffer of the whole batch (a batch of 4 .. 8 lane chunks used to be reserved for the product
+        // only, and the first transform afterwards synchronised the device and reallocated)
+        const bool bb = c->ring == SR_RING_BABYBEAR_POW2;
+        const size_t w = bb ? 4 : 8;
+        const bool lanes = bb ? rt_use_lanes<sr::BabyBear>(c, batch, nullptr) : rt_use_lanes<sr::Goldilocks>(c, batch, nullptr);
+        const bool lanes_t = bb ? rt_use_lanes_transform<sr::BabyBear>(c, batch, nullptr) : rt_use_lanes_transform<sr::Goldilocks>(c, batch, nullptr);
+        const size_t chunk = bb ? rt_lane_chunk<sr::BabyBear>(c) : rt_lane_chunk<sr::Goldilocks>(c);
+        const size_t whole = (batch << c->k) * w, four = 4 * (chunk << c->k) * w;
+        if (lanes || lanes_t)
             if (int rc = gl_lanes_init(c)) return rc;
-            return ensure_scratch(c, 1, 4 * (chunk << c->k) * w);
-        }
-        return rt_ensure_scratch(c, 2, ((c->k > 12 ? rt_chunk_polys(c, batch) : batch) << c->k) * w);
+        if (c->k <= 12) return SR_OK;
+        size_t need0 = lanes ? four : ((c->k > 12 ? rt_chunk_polys(c, batch) : batch) << c->k) * w, need1 = lanes ? 0 : need0;
+        const size_t transform = lanes_t ? four : whole;
+        if (transform > need0) need0 = transform;
+        if (int rc = ensure_scratch(c, 1, need0, nullptr)) return rc;
+        return need1 ? ensure_scratch(c, 2, need1, nullptr) : SR_OK;
     }
     const bool one_launch = c->ring == SR_RING_GOLDILOCKS_POW2 && c->fast_goldilocks && sr::gl_fast_supported(c->gl_fast)
                                 ? c->k <= 12
@@ -2034,9 +2248,9 @@ int sr_ctx_reserve_scratch(sr_ctx *c, size_t batch) {
     const bool gl = c->ring == SR_RING_GOLDILOCKS_POW2 && c->fast_goldilocks && sr::gl_fast_supported(c->gl_fast);
     if (gl && gl_use_lanes(c, batch)) {
         if (int rc = gl_lanes_init(c)) return rc;
-        return ensure_scratch(c, 1, 4 * gl_lane_chunk(c) * elem);
+        return ensure_scratch(c, 1, 4 * gl_lane_chunk(c) * elem, nullptr);
     }
-    return ensure_scratch(c, 1, (gl ? gl_chunk_polys(c, batch) : scratch_polys(c, batch, elem)) * elem);
+    return ensure_scratch(c, 1, (gl ? gl_chunk_polys(c, batch) : scratch_polys(c, batch, elem)) * elem, nullptr);
 }
 // ---- packed-u32 boundary (BabyBear power-of-two rings; csrc/packed32.hpp) ----------------------------------------------------
 extern "C++" {
@@ -2065,9 +2279,9 @@ template <class Fn>
 int packed_via_wide(sr_ctx *c, uint32_t *out, const uint32_t *a, const uint32_t *b, size_t batch, hipStream_t st, Fn run) {
     const size_t n = batch << c->k;
     DevBufLite wa(c, 5), wb(c, 6);
-    if (int rc = wa.alloc(n * 8)) return rc;
+    if (int rc = wa.alloc(n * 8, st)) return rc;
     if (b)
-        if (int rc = wb.alloc(n * 8)) return rc;
+        if (int rc = wb.alloc(n * 8, st)) return rc;
     ScratchUse su(c, st);  // the staging buffers belong to the context, the call may arrive on any stream: ordered like the operand scratch
     if (int rc = su.acquire()) return rc;
     if (int rc = launch_unpack32(c, (uint64_t *)wa.p, a, n, st)) return rc;
@@ -2503,13 +2717,23 @@ int sr_selftest_field_op(int field, int op, const uint64_t *a, const uint64_t *b
 int sr_selftest_rep_counters(uint64_t counters[8], int reset) {
     if (!counters) return fail(SR_E_INVALID, "null argument");
 #if defined(SR_GL_CHECK_REPS)
-    unsigned long long h[8];
-    HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipMemcpyFromSymbol(h, HIP_SYMBOL(sr::repcheck::g_counters), sizeof(h)));
-    for (int i = 0; i < 8; i++) counters[i] = h[i];
-    if (reset) {
-        memset(h, 0, sizeof(h));
-        HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(sr::repcheck::g_counters), h, sizeof(h)));
+    // g_counters is a __device__ symbol, i.e. one copy per device: visit every visible device (contexts of the sharded tests live on
+    // devices other than the current one), sum the violation counts and take the high-water mark's maximum
+    int ndev = 0;
+    HIP_TRY(hipGetDeviceCount(&ndev));
+    for (int i = 0; i < 8; i++) counters[i] = 0;
+    for (int dev = 0; dev < ndev; dev++) {
+        DeviceGuard g(dev);
+        if (!g.ok) return fail(SR_E_HIP, "hipSetDevice failed");
+        unsigned long long h[8];
+        HIP_TRY(hipDeviceSynchronize());
+        HIP_TRY(hipMemcpyFromSymbol(h, HIP_SYMBOL(sr::repcheck::g_counters), sizeof(h)));
+        for (int i = 0; i < 7; i++) counters[i] += h[i];
+        if (h[7] > counters[7]) counters[7] = h[7];
+        if (reset) {
+            memset(h, 0, sizeof(h));
+            HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(sr::repcheck::g_counters), h, sizeof(h)));
+        }
     }
     return SR_OK;
 #else
@@ -2524,9 +2748,12 @@ int sr_ctx_profile_enable(sr_ctx *c, int on) {
     if (!c) return fail(SR_E_INVALID, "null context");
     std::lock_guard<std::mutex> lk(c->mu);
     c->prof.on = on != 0;
+    c->prof.stride = on > 1 ? (unsigned)on : 1u;
+    c->prof.tick = 0;
     return SR_OK;
 }
-int sr_ctx_profile_read(sr_ctx *c, double *ms_total, uint64_t *launches) {
+int sr_ctx_profile_read(sr_ctx *c, double *ms_total, uint64_t *launches) { return sr_ctx_profile_read_sampled(c, ms_total, launches, nullptr); }
+int sr_ctx_profile_read_sampled(sr_ctx *c, double *ms_total, uint64_t *launches, uint64_t *seen) {
     if (!c || !ms_total || !launches) return fail(SR_E_INVALID, "null argument");
     std::lock_guard<std::mutex> lk(c->mu);
     DeviceGuard g(c->device);
@@ -2543,8 +2770,10 @@ int sr_ctx_profile_read(sr_ctx *c, double *ms_total, uint64_t *launches) {
     for (int t = 0; t < K_NTAGS; t++) {
         ms_total[t] = c->prof.ms[t];
         launches[t] = c->prof.launches[t];
+        if (seen) seen[t] = c->prof.seen[t];
         c->prof.ms[t] = 0;
         c->prof.launches[t] = 0;
+        c->prof.seen[t] = 0;
     }
     return SR_OK;
 }

@@ -323,6 +323,40 @@ __global__ __launch_bounds__(256) void add_scalar_kernel(typename F::storage *da
         F::store(p, F::add(F::load(p), s));
     }
 }
+// One stage of `Sum` / `Product` over a slice of ring elements (coeff_form.rs:507-537, ntt_form.rs:640-670: `iter.fold(zero(), acc + x)`,
+// `iter.fold(one(), acc * x)`): n elements of w words each are folded word-wise into r partial elements.  Lane g < r * w folds the
+// words g, g + r w, g + 2 r w, ... of the flat input (all of them word g mod w of some element), so a wave reads consecutive words;
+// four independent accumulators keep four loads in flight.  The fold is associative and commutative, and field results are
+// canonical, so the order changes nothing.  MUL: the fully split rings' slot product on the memory images (mul_boundary).
+template <class F, bool MUL>
+__global__ __launch_bounds__(256) void fold_stage_kernel(typename F::storage *out, const typename F::storage *in, size_t w, size_t n, size_t r) {
+    using E = typename F::elem;
+    const size_t g = blockIdx.x * (size_t)blockDim.x + threadIdx.x, t = r * w, total = n * w;
+    if (g >= t) return;
+    auto op = [](const E &a, const E &b) { return MUL ? F::mul_boundary(a, b) : F::add(a, b); };
+    E acc[4];
+    bool have[4] = {false, false, false, false};
+    size_t i = g;
+    for (; i + 3 * t < total; i += 4 * t) {
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const E x = F::load(in + i + u * t);
+            acc[u] = have[u] ? op(acc[u], x) : x;
+            have[u] = true;
+        }
+    }
+    for (int u = 0; i < total; i += t, u++) {
+        const E x = F::load(in + i);
+        acc[u] = have[u] ? op(acc[u], x) : x;
+        have[u] = true;
+    }
+    // lane g < t <= n w always owns word g itself, so acc[0] is set
+    E s = acc[0];
+#pragma unroll
+    for (int u = 1; u < 4; u++)
+        if (have[u]) s = op(s, acc[u]);
+    F::store(out + g, s);
+}
 // workgroups for a streaming kernel over n coefficients: one 16-byte access per lane where the field allows it (no grid-stride
 // loop below 2^24 workgroups (HIP limits a launch to 2^32 lanes): a lane that loops streams measurably worse, see elementwise2)
 template <class F>

@@ -670,16 +670,22 @@ __global__ __launch_bounds__(16 << LC, 4) void cols256_kernel(u64 *data, const u
     __syncthreads();
     cols256_tile<DIR, LC>(xcd_tile(blockIdx.x, kColsXcdGroup, grouped), data, src, k, wl, twist, lds);
 }
-// the forward passes of BOTH operands of a ring product in one launch: blockIdx.y picks the operand (grid.x as for one operand)
+// the forward passes of BOTH operands of a ring product in one launch: a one-dimensional grid of 2 * tiles workgroups, the XCD order
+// taken over the whole range (the hardware deals workgroups to the XCDs by their LINEAR id, so a second grid dimension would put
+// operand b's tiles on other XCDs than xcd_tile assumes whenever `tiles` is not a multiple of 8); virtual tile v < tiles is a's,
+// the rest are b's.  `tiles` is a multiple of 2^kColsXcdGroup (N2 / 16 >= 16 column chunks per ring element), so no run of
+// consecutive tiles straddles the two operands.
 template <int LC>
 __global__ __launch_bounds__(16 << LC, 4) void cols256_pair_kernel(u64 *data_a, const u64 *src_a, u64 *data_b, const u64 *src_b, int k,
                                                                    const u64 *__restrict__ wc, const u64 *__restrict__ twist,
-                                                                   unsigned grouped) {
+                                                                   unsigned grouped, unsigned tiles) {
     __shared__ u64 lds[ColsTile<LC>::kElems];
     __shared__ u64 wl[256];
     if (threadIdx.x < 256) wl[threadIdx.x] = wc[threadIdx.x];
     __syncthreads();
-    cols256_tile<0, LC>(xcd_tile(blockIdx.x, kColsXcdGroup, grouped), blockIdx.y ? data_b : data_a, blockIdx.y ? src_b : src_a, k, wl, twist, lds);
+    const unsigned v = xcd_tile(blockIdx.x, kColsXcdGroup, grouped);
+    const bool second = v >= tiles;
+    cols256_tile<0, LC>(second ? v - tiles : v, second ? data_b : data_a, second ? src_b : src_a, k, wl, twist, lds);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -871,7 +877,7 @@ __device__ __forceinline__ void tile_inv(u64 *x, u64 *lds, const int t, const Ta
 // 3: out = icrt(crt(a) (.) b) with b already in CRT/NTT form (the constant-operand product: one transform fewer).
 // n_total = flat coefficient count of the batch (only consulted when TW: ragged last tile).
 // waves per SIMD: 4; whole-ring-element tiles 3 (2 / 3 / 4: 16.0 / 13.9 / 14.1 ms for the fused D = 4096 product, round 1)
-template <int MODE, int Q, bool TW>
+template <int MODE, int Q, bool TW, int PH = (MODE >= 2 ? (TW ? -1 : 0) : kPhased)>
 __global__ __launch_bounds__(256, TW ? 3 : 4) void rows_kernel(u64 *a, const u64 *b, u64 *out, Tables T, const u64 *w1i,
                                                                    size_t n_total) {
     __shared__ u64 lds[kLdsElems];
@@ -886,8 +892,8 @@ __global__ __launch_bounds__(256, TW ? 3 : 4) void rows_kernel(u64 *a, const u64
     int nvalid = kTile;
     if (TW) nvalid = n_total - base < (size_t)kTile ? (int)(n_total - base) : kTile;
     // the fused products hold a's transformed tile in registers while b's runs: butterfly by butterfly there (no spills); the
-    // stand-alone transforms take the phased stages
-    constexpr int P = MODE >= 2 ? (TW ? -1 : 0) : kPhased;
+    // stand-alone transforms take the phased stages (PH's default)
+    constexpr int P = PH;
     u64 A[16];
     if (MODE == 1) {
         // lane-contiguous global load, then an exchange into the 16-contiguous-per-lane layout of the first pass
@@ -1095,6 +1101,8 @@ struct GoldilocksFastTables {
     int c = 0;               // merged stages run by the column passes; the rows kernels see blocks of D >> c coefficients
     bool cols256 = false;    // c == 8 in one cols256 launch (2^16 <= D <= 2^20)
     bool keep_cols = true;   // lane plans: cols256_keep_kernel (sr_plan flag SR_PLAN_GL_PLAIN_COLS clears it)
+    bool split_rows = false; // A/B plan (sr_plan flag SR_PLAN_GL_SPLIT_ROWS): the fused rows kernel of a ring product as two launches --
+                             // crt of b's tiles in place in the scratch (rows<0>), then the constant-operand product (rows<3>)
     bool ready = false;
     gl::Tables t{};
     size_t chunk_polys = 0;  // ring products: elements per chunk of launches (0 = as many as the scratch holds)
@@ -1147,15 +1155,18 @@ inline int gl_fast_init(GoldilocksFastTables &f, int k, const uint64_t *tw, cons
     f.c = f.cols256 ? 8 : (k > 12 ? k - 12 : 0);
     uint64_t *d_pows = nullptr;
     if (hipMalloc(&d_pows, 2 * (k + 1) * sizeof(uint64_t)) != hipSuccess) return 1;
-    if (hipMemcpy(d_pows, host_pows, (k + 1) * 8, hipMemcpyHostToDevice) != hipSuccess) return 1;
-    if (hipMemcpy(d_pows + k + 1, host_ipows, (k + 1) * 8, hipMemcpyHostToDevice) != hipSuccess) return 1;
-    unsigned blocks = (unsigned)(((d > 4096 ? d : 4096) + 255) / 256);
-    if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(gl::build_tables_kernel, dim3(blocks), dim3(256), 0, st, k, f.c, d_pows, d_pows + k + 1, dinv, dinv_mul,
-                       twist_f, twist_ip, twist_im, w1f, w1i, w1im, w2f, w2i, wcf, wci);
-    if (hipGetLastError() != hipSuccess) return 1;
-    if (hipStreamSynchronize(st) != hipSuccess) return 1;
-    (void)hipFree(d_pows);
+    bool ok = hipMemcpy(d_pows, host_pows, (k + 1) * 8, hipMemcpyHostToDevice) == hipSuccess &&
+              hipMemcpy(d_pows + k + 1, host_ipows, (k + 1) * 8, hipMemcpyHostToDevice) == hipSuccess;
+    if (ok) {
+        unsigned blocks = (unsigned)(((d > 4096 ? d : 4096) + 255) / 256);
+        if (blocks > 4096) blocks = 4096;
+        hipLaunchKernelGGL(gl::build_tables_kernel, dim3(blocks), dim3(256), 0, st, k, f.c, d_pows, d_pows + k + 1, dinv, dinv_mul,
+                           twist_f, twist_ip, twist_im, w1f, w1i, w1im, w2f, w2i, wcf, wci);
+        ok = hipGetLastError() == hipSuccess;
+        ok = hipStreamSynchronize(st) == hipSuccess && ok;  // (also after a failed launch: nothing may still read d_pows)
+    }
+    (void)hipFree(d_pows);  // on every path
+    if (!ok) return 1;
     f.t = gl::Tables{tw, itw, twist_f, twist_ip, twist_im, w1f, w1i, w1im, w2f, w2i, wcf, wci};
     f.ready = true;
     return 0;
@@ -1245,9 +1256,9 @@ inline int gl_launch_cols256_pair_plain(const GoldilocksFastTables &f, uint64_t 
     GlProfScope ps(f, 0, st);
     constexpr int LC = 4;
     const size_t blocks = npoly << (f.k - 8 - LC);
-    if (blocks == 0 || blocks > 0x7FFFFFFFull) return 1;
-    hipLaunchKernelGGL((gl::cols256_pair_kernel<LC>), dim3((unsigned)blocks, 2), dim3(16 << LC), 0, st, da, sa, db, sb, f.k, f.t.wcf,
-                       f.t.twist_f, xcd_grouped_tiles(blocks, gl::kColsXcdGroup));
+    if (blocks == 0 || blocks > 0x3FFFFFFFull) return 1;
+    hipLaunchKernelGGL((gl::cols256_pair_kernel<LC>), dim3((unsigned)(2 * blocks)), dim3(16 << LC), 0, st, da, sa, db, sb, f.k, f.t.wcf,
+                       f.t.twist_f, xcd_grouped_tiles(2 * blocks, gl::kColsXcdGroup), (unsigned)blocks);
     return hipGetLastError() != hipSuccess;
 }
 // the forward column passes of BOTH operands of a ring product in one launch (the same workgroups, their twist factors loaded once,
@@ -1360,7 +1371,12 @@ inline int gl_fast_ring_mul(const GoldilocksFastTables &f, uint64_t *out, const 
             if (gl_strided_fwd(f, o, a + e * stride, n, st)) return 1;
             if (gl_strided_fwd(f, scratch, b + e * stride, n, st)) return 1;
         }
-        if (gl_launch_rows<2>(f, o, scratch, o, n, true, st)) return 1;
+        if (f.split_rows) {
+            if (gl_launch_rows<0>(f, scratch, nullptr, scratch, n, false, st)) return 1;
+            if (gl_launch_rows<3>(f, o, scratch, o, n, true, st)) return 1;
+        } else if (gl_launch_rows<2>(f, o, scratch, o, n, true, st)) {
+            return 1;
+        }
         if (gl_strided_inv(f, o, n, true, st)) return 1;
     }
     return 0;
@@ -1393,7 +1409,12 @@ inline int gl_fast_ring_mul_lanes(const GoldilocksFastTables &f, uint64_t *out, 
         const int i = (int)(c % (size_t)L.n);
         const size_t n = batch - e < L.chunk ? batch - e : L.chunk;
         rc = gl_launch_cols256_lane_pair(f, L.sa[i], a + e * stride, L.sb[i], b + e * stride, n, L.st[i]);
-        if (!rc) rc = gl_launch_rows<2>(f, L.sa[i], L.sb[i], L.sa[i], n, true, L.st[i]);
+        if (f.split_rows) {
+            if (!rc) rc = gl_launch_rows<0>(f, L.sb[i], nullptr, L.sb[i], n, false, L.st[i]);
+            if (!rc) rc = gl_launch_rows<3>(f, L.sa[i], L.sb[i], L.sa[i], n, true, L.st[i]);
+        } else if (!rc) {
+            rc = gl_launch_rows<2>(f, L.sa[i], L.sb[i], L.sa[i], n, true, L.st[i]);
+        }
         if (!rc) rc = gl_launch_cols256_lane<1>(f, out + e * stride, L.sa[i], n, f.t.wci, f.t.twist_i_mul, L.st[i]);
     }
     for (int i = 0; i < L.n; i++) {  // join even after a failed launch: the caller's stream must not run ahead of the lanes

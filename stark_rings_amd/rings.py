@@ -197,6 +197,28 @@ class CyclotomicRing:
         self._check(self._lib.sr_add_scalar_batch(self._ctx, _np_ptr(data), _np_ptr(s), 1 if ntt_form else 0, self._batch_of(data.size)))
         return data
 
+    def sum(self, elems):
+        """impl Sum for RqPoly / RqNTT (coeff_form.rs:507-521, ntt_form.rs:640-654): `iter.fold(zero(), |acc, x| acc + x)` over a slice
+        of ring elements, word-wise, either form; an empty slice gives zero().  Returns one ring element."""
+        out = np.empty(self.words_per_elem, dtype=np.uint64)
+        src = elems if elems.size else np.zeros(1, dtype=np.uint64)
+        self._check(self._lib.sr_sum_batch(self._ctx, _np_ptr(out), _np_ptr(src), self._batch_of(elems.size)))
+        return out
+
+    def product(self, elems_ntt):
+        """impl Product for RqNTT (ntt_form.rs:656-670): `iter.fold(one(), |acc, x| acc * x)`, slot-wise; an empty slice gives one()."""
+        out = np.empty(self.words_per_elem, dtype=np.uint64)
+        src = elems_ntt if elems_ntt.size else np.zeros(1, dtype=np.uint64)
+        self._check(self._lib.sr_product_batch(self._ctx, _np_ptr(out), _np_ptr(src), self._batch_of(elems_ntt.size)))
+        return out
+
+    def product_poly(self, elems):
+        """impl Product for RqPoly (coeff_form.rs:523-537: `iter.fold(one(), |acc, x| acc * x)` with the ring product) as
+        icrt(product(crt(x_i))): the CRT is a ring isomorphism, so the slot-wise product of the transforms is the transform of the
+        product.  The input is not modified."""
+        t = self.elementwise_crt(elems.copy()) if elems.size else elems
+        return self.elementwise_icrt(self.product(t))
+
     def mul(self, a, b, out=None):
         """Coefficient-form product a * b (coeff_form.rs:250-258) via icrt(crt(a) * crt(b))."""
         if a.size != b.size:
@@ -528,6 +550,29 @@ class CyclotomicRing:
         self._check(self._lib.sr_mul_elem_batch_dev(self._ctx, p, pe, self._batch_of(n), self._stream(stream)))
         return t
 
+    def sum_dev(self, out, elems, stream=None):
+        """Sum over a device-resident slice (see sum): out = one ring element, must not overlap elems."""
+        if out.numel() != self.words_per_elem:
+            raise RingError("sum: out is not one ring element")
+        n = self._batch_of(elems.numel())
+        self._check(self._lib.sr_sum_batch_dev(self._ctx, self._dev(out), self._dev(elems) if n else self._dev(out), n, self._stream(stream)))
+        return out
+
+    def product_dev(self, out, elems_ntt, stream=None):
+        """Product over a device-resident slice in CRT/NTT form (see product)."""
+        if out.numel() != self.words_per_elem:
+            raise RingError("product: out is not one ring element")
+        n = self._batch_of(elems_ntt.numel())
+        self._check(self._lib.sr_product_batch_dev(self._ctx, self._dev(out), self._dev(elems_ntt) if n else self._dev(out), n, self._stream(stream)))
+        return out
+
+    def product_poly_dev(self, out, elems, stream=None):
+        """Product of coefficient-form elements (see product_poly); `elems` is transformed IN PLACE (it holds crt(elems) afterwards)."""
+        if elems.numel():
+            self.elementwise_crt_dev(elems, stream=stream)
+        self.product_dev(out, elems, stream=stream)
+        return self.elementwise_icrt_dev(out, stream=stream)
+
     def add_scalar_dev(self, t, scalar, ntt_form, stream=None):
         p, n = self._dev(t)
         s = self._scalar(scalar)
@@ -723,10 +768,14 @@ class CyclotomicRing:
 
     # -- per-kernel timing --------------------------------------------------------------------
     def profile_enable(self, on=True):
-        self._check(self._lib.sr_ctx_profile_enable(self._ctx, 1 if on else 0))
+        """on: False / True (every launch bracketed by HIP events) or an int N >= 2 (every N-th launch only: leaves a two-lane step as
+        it runs, see sr_ctx_profile_enable)"""
+        self._check(self._lib.sr_ctx_profile_enable(self._ctx, int(on)))
 
     def profile_read(self):
+        """per tag: ms and launches of the BRACKETED launches, seen = every launch that went by since the last read"""
         ms = (ctypes.c_double * len(PROF_TAGS))()
         n = (ctypes.c_uint64 * len(PROF_TAGS))()
-        self._check(self._lib.sr_ctx_profile_read(self._ctx, ms, n))
-        return {t: {"ms": ms[i], "launches": int(n[i])} for i, t in enumerate(PROF_TAGS)}
+        seen = (ctypes.c_uint64 * len(PROF_TAGS))()
+        self._check(self._lib.sr_ctx_profile_read_sampled(self._ctx, ms, n, seen))
+        return {t: {"ms": ms[i], "launches": int(n[i]), "seen": int(seen[i])} for i, t in enumerate(PROF_TAGS)}

@@ -19,6 +19,20 @@ def shard_range(batch, world, rank):
     return first, q + (1 if rank < r else 0)
 
 
+def group_device_ids(device_count, cap=8):
+    """Device ids for a single-process context group (sr_ctx_create_group) on a box with `device_count` visible GPUs: every visible
+    device up to `cap`, DISTINCT ids (the peer copy of the twiddle block then really crosses xGMI); with one GPU -- or none visible --
+    two contexts on device 0, the one-GPU form of the same call path."""
+    n = min(int(device_count), int(cap))
+    return list(range(n)) if n >= 2 else [0, 0]
+
+
+def rehearsal_backend(device_count):
+    """(backend, ranks) for the self-launched multi-rank rehearsal of bench.py on this box: RCCL ("nccl") over distinct devices as
+    soon as there are two -- two ranks, a real inter-GPU broadcast -- otherwise two gloo ranks folded onto the one GPU."""
+    return ("nccl", 2) if int(device_count) >= 2 else ("gloo", 2)
+
+
 def env_world():
     """(rank, local_rank, world) from the torchrun environment; (0, 0, 1) when run stand-alone."""
     return (int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")),

@@ -250,6 +250,31 @@ static void linalg_suite(sr_ring ring, int field, int log2d) {
         }
         EXPECT(threw);
     }
+    // impl Sum / Product for RqNTT and RqPoly (ntt_form.rs:640-670, coeff_form.rs:507-537): the reference's left folds, element by element
+    {
+        RqNTTVec all(cfg, A);
+        RqNTTVec acc(cfg, elem(A, 0)), prod(cfg, elem(A, 0));
+        for (size_t i = 1; i < n * m; i++) {
+            acc += RqNTTVec(cfg, elem(A, i));
+            prod *= RqNTTVec(cfg, elem(A, i));
+        }
+        EXPECT(all.sum() == acc);
+        EXPECT(all.product() == prod);
+        RqNTTVec none(cfg, std::vector<uint64_t>());
+        EXPECT(none.sum().words() == std::vector<uint64_t>(w, 0));
+        RqNTTVec one_times(cfg, elem(A, 2));
+        one_times *= none.product();   // one() is the multiplicative identity
+        EXPECT(one_times.words() == elem(A, 2));
+        RqPolyVec polys(cfg, std::vector<uint64_t>(A.begin(), A.begin() + 3 * w));
+        RqPolyVec pacc(cfg, elem(A, 0));
+        pacc *= RqPolyVec(cfg, elem(A, 1));
+        pacc *= RqPolyVec(cfg, elem(A, 2));
+        EXPECT(polys.product() == pacc);
+        RqPolyVec sacc(cfg, elem(A, 0));
+        sacc += RqPolyVec(cfg, elem(A, 1));
+        sacc += RqPolyVec(cfg, elem(A, 2));
+        EXPECT(polys.sum() == sacc);
+    }
     rows[1] = {{elem(A, 3), m}};  // column out of range: the reference panics on v[col]
     threw = false;
     try {

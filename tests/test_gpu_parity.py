@@ -1425,37 +1425,63 @@ def test_matrix_and_sparse_matrix_gadget_decompose(torch_cuda, name, k, basis, p
 
 
 def test_context_group_shares_one_twiddle_block(torch_cuda):
-    """sr_ctx_create_group: n contexts whose tables are peer copies of the first one's (here both on device 0: the copy path is the
-    same call), and sr_shard_range == sharding.shard_range.  The second context computes with the COPIED tables."""
+    """sr_ctx_create_group: n contexts whose tables are peer copies of the first one's, and sr_shard_range == sharding.shard_range.
+    The test widens itself: on a box with several visible GPUs the group spans min(count, 8) DISTINCT devices -- the
+    twiddle block then really crosses xGMI (hipMemcpyPeer between two devices), every context computes on ITS device's buffers from
+    a host thread of its own (contexts on different devices run concurrently; what a single-process Rust host with one rayon worker
+    per GPU does), and every shard is checked against the oracle.  With one GPU the ids are {0, 0}: the same call
+    path, both contexts on device 0.  The id selection itself is unit-tested on the CPU (tests/test_sharding_gloo.py)."""
     import ctypes
+    import threading
 
     torch = torch_cuda
     from stark_rings_amd import _lib
-    from stark_rings_amd.sharding import shard_range
+    from stark_rings_amd.sharding import group_device_ids, shard_range
 
     lib = _lib.load()
-    ids = (ctypes.c_int * 2)(0, 0)
-    ctxs = (ctypes.c_void_p * 2)()
-    k, batch = 13, 5
-    assert lib.sr_ctx_create_group(0, k, ids, 2, None, ctxs) == 0, _lib.last_error()
+    dev_ids = group_device_ids(torch.cuda.device_count())
+    n = len(dev_ids)
+    ids = (ctypes.c_int * n)(*dev_ids)
+    ctxs = (ctypes.c_void_p * n)()
+    k, batch = 13, 5 if n == 2 else 3 * n + 1
+    assert lib.sr_ctx_create_group(0, k, ids, n, None, ctxs) == 0, _lib.last_error()
     try:
         F = O.GOLDILOCKS
         a = O.fill_uniform(F, 3, 0, batch << k)
         b = O.fill_uniform(F, 4, 0, batch << k)
         want = O.pow2_ring_mul(F, a, b, k, batch, 4)
-        ta, tb = torch.from_numpy(a.view(np.int64)).cuda(), torch.from_numpy(b.view(np.int64)).cuda()
-        out = torch.empty_like(ta)
+        got, errors = [None] * n, []
+
+        def work(i):
+            try:
+                first, count = ctypes.c_size_t(), ctypes.c_size_t()
+                assert lib.sr_shard_range(batch, n, i, ctypes.byref(first), ctypes.byref(count)) == 0
+                assert (first.value, count.value) == shard_range(batch, n, i)
+                lo, hi = first.value << k, (first.value + count.value) << k
+                dev = torch.device("cuda", dev_ids[i])
+                with torch.cuda.device(dev):
+                    ta = torch.from_numpy(a[lo:hi].copy().view(np.int64)).to(dev)
+                    tb = torch.from_numpy(b[lo:hi].copy().view(np.int64)).to(dev)
+                    out = torch.empty_like(ta)
+                    st = torch.cuda.current_stream(dev)
+                    rc = lib.sr_ring_mul_batch_dev(ctxs[i], ctypes.c_void_p(out.data_ptr()), ctypes.c_void_p(ta.data_ptr()),
+                                                   ctypes.c_void_p(tb.data_ptr()), count.value, ctypes.c_void_p(st.cuda_stream))
+                    assert rc == 0, _lib.last_error()
+                    st.synchronize()
+                    got[i] = (lo, hi, out.cpu().numpy().view(np.uint64))
+            except BaseException as e:  # noqa: BLE001 -- reported by the main thread
+                errors.append((i, repr(e)))
+
+        threads = [threading.Thread(target=work, args=(i,)) for i in range(n)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        assert not errors, errors
+        for i, (lo, hi, part) in enumerate(got):
+            assert np.array_equal(part, want[lo:hi]), "shard %d (device %d)" % (i, dev_ids[i])
+        assert sum(hi - lo for lo, hi, _ in got) == batch << k
         first, count = ctypes.c_size_t(), ctypes.c_size_t()
-        for i in range(2):
-            assert lib.sr_shard_range(batch, 2, i, ctypes.byref(first), ctypes.byref(count)) == 0
-            assert (first.value, count.value) == shard_range(batch, 2, i)
-            off = first.value << k
-            rc = lib.sr_ring_mul_batch_dev(ctxs[i], ctypes.c_void_p(out.data_ptr() + off * 8), ctypes.c_void_p(ta.data_ptr() + off * 8),
-                                           ctypes.c_void_p(tb.data_ptr() + off * 8), count.value,
-                                           ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
-            assert rc == 0, _lib.last_error()
-        torch.cuda.synchronize()
-        assert np.array_equal(out.cpu().numpy().view(np.uint64), want)
         assert lib.sr_shard_range(5, 2, 2, ctypes.byref(first), ctypes.byref(count)) != 0
     finally:
         for c in ctxs:
@@ -2346,3 +2372,178 @@ def test_primitive_ops_like_the_reference(torch_cuda, name, k):
         assert np.array_equal(lhs, rhs), v
         assert np.array_equal(ring.scale(ring.elementwise_crt(a.copy()), img(v)), ring.elementwise_crt(ring.scale(a.copy(), img(v))))
     assert np.array_equal(ring.neg(ring.elementwise_crt(a.copy())), ring.elementwise_crt(ring.neg(a.copy())))
+
+
+_FOLD_ORACLE = {"goldilocks24": "sro_g24_ntt_mul", "babybear72": "sro_bb72_ntt_mul", "frog16": "sro_frog16_ntt_mul"}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,k,sizes", [("goldilocks", 6, (0, 1, 2, 3, 31, 32, 33, 67, 1100)), ("goldilocks", 16, (3, 70)),
+                                          ("babybear", 5, (0, 1, 5, 40, 1063)), ("stark", 4, (0, 1, 2, 45, 1100)), ("stark", 9, (3, 37)),
+                                          ("goldilocks24", 0, (0, 1, 2, 3, 64, 65, 1001)), ("babybear72", 0, (0, 1, 7, 130)),
+                                          ("frog16", 0, (0, 1, 4, 9, 515))])
+def test_sum_and_product_over_a_slice_of_ring_elements(torch_cuda, name, k, sizes):
+    """`impl Sum` / `impl Product` of the element types rows a2 / a3 name: `iter.fold(zero(), |acc, x| acc + x)` for
+    RqPoly and RqNTT (coeff_form.rs:507-521, ntt_form.rs:640-654) and `iter.fold(one(), |acc, x| acc * x)` for RqNTT
+    (ntt_form.rs:656-670), every ring id, host and device entry points.  Sum against Python integers on the standard-form values;
+    Product against the oracle's slot product folded LEFT TO RIGHT exactly as the reference folds (the device uses a tree: same
+    value, the fold being associative and commutative on canonical results).  Empty slices give zero() / one(); slice lengths cover
+    one, two and three stages of the device fold, odd lengths of the halving tree, and an all-(p - 1) element."""
+    torch = torch_cuda
+    from stark_rings_amd import RingError
+
+    base = {"goldilocks24": "goldilocks", "babybear72": "babybear", "frog16": "frog"}.get(name, name)
+    F = O.FIELD_ID[base]
+    p = P.PRIMES[base][0] if base in P.PRIMES else P.FROG_P
+    ring = ring_for(name, k)
+    d, w = ring.degree, ring.words_per_elem
+    slot = {"goldilocks24": 3, "babybear72": 9, "frog16": 4}.get(name, 1)
+    one_std = [1 if i % slot == 0 else 0 for i in range(d)]
+
+    def slot_mul(x, y):
+        if name in _FOLD_ORACLE:
+            return O.small(_FOLD_ORACLE[name], x, y)
+        return O.pow2_pointwise(F, x, y)
+
+    for n in sizes:
+        a = O.fill_uniform(F, 0x900 + 7 * k + n, 0, max(n, 1) * d)[:n * w]
+        if n >= 2:
+            a[w:2 * w] = O.to_mont(F, [p - 1] * d)
+        std = O.from_mont(F, a) if n else []
+        want_sum = O.to_mont(F, [sum(std[e * d + i] for e in range(n)) % p for i in range(d)])
+        assert np.array_equal(ring.sum(a), want_sum), ("sum", n)
+        acc = O.to_mont(F, one_std)
+        for e in range(n):
+            acc = slot_mul(acc, a[e * w:(e + 1) * w])
+        assert np.array_equal(ring.product(a), acc), ("product", n)
+        ta = torch.from_numpy(a.copy().view(np.int64)).cuda() if n else torch.empty(0, dtype=torch.int64, device="cuda")
+        out = torch.full((w,), -1, dtype=torch.int64, device="cuda")
+        ring.sum_dev(out, ta)
+        torch.cuda.synchronize()
+        assert np.array_equal(out.cpu().numpy().view(np.uint64), want_sum), ("sum_dev", n)
+        out.fill_(-1)
+        ring.product_dev(out, ta)
+        torch.cuda.synchronize()
+        assert np.array_equal(out.cpu().numpy().view(np.uint64), acc), ("product_dev", n)
+        if n:
+            assert np.array_equal(ta.cpu().numpy().view(np.uint64), a), "the input slice was written"
+    # Product for RqPoly (coeff_form.rs:523-537: the fold of ring products) = icrt(product(crt(x_i))), against the oracle's ring product
+    if slot == 1 and k >= 1:
+        n = 5
+        a = O.fill_uniform(F, 0x9F0 + k, 0, n * d)
+        acc = a[:w].copy()
+        for e in range(1, n):
+            acc = O.pow2_ring_mul(F, acc, a[e * w:(e + 1) * w], k)
+        assert np.array_equal(ring.product_poly(a), acc)
+        ta = torch.from_numpy(a.copy().view(np.int64)).cuda()
+        out = torch.empty(w, dtype=torch.int64, device="cuda")
+        ring.product_poly_dev(out, ta)
+        torch.cuda.synchronize()
+        assert np.array_equal(out.cpu().numpy().view(np.uint64), acc)
+        one_poly = O.to_mont(F, [1] + [0] * (d - 1))
+        assert np.array_equal(ring.product_poly(np.zeros(0, dtype=np.uint64)), one_poly)   # one() of RqPoly: icrt of the all-ones slots
+    # out inside the slice is refused
+    ta = torch.from_numpy(O.fill_uniform(F, 1, 0, 3 * d).view(np.int64)).cuda()
+    with pytest.raises(RingError, match="overlap"):
+        ring.sum_dev(ta[w:2 * w], ta)
+    with pytest.raises(RingError, match="one ring element"):
+        ring.product_dev(ta[:2 * w], ta)
+
+
+@pytest.mark.gpu
+def test_reserve_covers_transforms_between_four_and_eight_lane_chunks(torch_cuda):
+    """sr_ctx_reserve_scratch sized the register-tiled scratch for the PRODUCT only (two lanes from 3.5 lane chunks
+    on: four chunk buffers), while a stand-alone transform takes the lanes from eight chunks on and below that runs on the caller's
+    stream through ONE buffer of the whole batch -- so at BabyBear D = 2^16, batch 1025 .. 2047, the first transform after reserve
+    synchronised the device and reallocated.  Here: batch 1500 (5.9 chunks of 256), reserve, then crt, product and icrt are captured
+    into a graph WITHOUT any eager warm-up -- a capture tolerates neither an allocation nor a synchronisation -- and the replay equals
+    what a second, eager context computes."""
+    torch = torch_cuda
+    from stark_rings_amd import CyclotomicRing
+
+    batch, k = 1500, 16
+    ring = CyclotomicRing("babybear", k, device=0)
+    n = batch * ring.words_per_elem
+    a = torch.empty(n, dtype=torch.int64, device="cuda")
+    b = torch.empty(n, dtype=torch.int64, device="cuda")
+    ring.fill_uniform_dev(a, 0x51, 0)
+    ring.fill_uniform_dev(b, 0x52, 0)
+    ring.reserve_scratch(batch)
+    fa, out = a.clone(), torch.empty_like(a)
+    torch.cuda.synchronize()
+    s = torch.cuda.Stream()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=s):
+        cur = torch.cuda.current_stream()
+        ring.elementwise_crt_dev(fa, stream=cur)       # one stream, whole-batch packed scratch: must already be there
+        ring.mul_dev(out, a, b, stream=cur)            # two lanes, four chunk buffers
+        ring.elementwise_icrt_dev(fa, stream=cur)
+    g.replay()
+    torch.cuda.synchronize()
+    ref = CyclotomicRing("babybear", k, device=0)
+    want = torch.empty_like(a)
+    ref.mul_dev(want, a, b)
+    torch.cuda.synchronize()
+    assert torch.equal(out, want) and torch.equal(fa, a)
+    # the packed-u32 twins share the scratch and the rule
+    a32 = torch.empty(n, dtype=torch.int32, device="cuda")
+    ring.pack32_dev(a32, a)
+    f32 = a32.clone()
+    torch.cuda.synchronize()
+    g2 = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g2, stream=s):
+        cur = torch.cuda.current_stream()
+        ring.elementwise_crt_packed32_dev(f32, stream=cur)
+        ring.elementwise_icrt_packed32_dev(f32, stream=cur)
+    g2.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(f32, a32)
+    ring.close()
+    ref.close()
+
+
+@pytest.mark.gpu
+def test_captured_graph_freezes_the_scratch(torch_cuda):
+    """ADVICE r4 (medium), the limits of the graph-capture guarantee made enforceable: a captured graph holds the context's scratch
+    addresses, so once a `_dev` call has been seen on a capturing stream no `_dev` call moves a context buffer any more -- a larger
+    batch that would have to grow the scratch is refused (SR_E_INVALID, "reserve") instead of freeing memory the graph still writes
+    to; sr_ctx_reserve_scratch remains the one, explicit way to grow.  A capture on a context that never reserved is refused the
+    same way (the growth would have to synchronise the device in the middle of the capture)."""
+    torch = torch_cuda
+    from stark_rings_amd import CyclotomicRing, RingError
+
+    k, small, big = 13, 8, 96
+    F = O.GOLDILOCKS
+    ring = CyclotomicRing("goldilocks", k, device=0)
+    w = ring.words_per_elem
+    a = torch.from_numpy(O.fill_uniform(F, 0x31, 0, big << k).view(np.int64)).cuda()
+    b = torch.from_numpy(O.fill_uniform(F, 0x32, 0, big << k).view(np.int64)).cuda()
+    out = torch.empty_like(a)
+    ring.reserve_scratch(small)
+    s = torch.cuda.Stream()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=s):
+        ring.mul_dev(out[:small * w], a[:small * w], b[:small * w], stream=torch.cuda.current_stream())
+    g.replay()
+    torch.cuda.synchronize()
+    want = O.pow2_ring_mul(F, a[:small * w].cpu().numpy().view(np.uint64), b[:small * w].cpu().numpy().view(np.uint64), k, small, 4)
+    assert np.array_equal(out[:small * w].cpu().numpy().view(np.uint64), want)
+    with pytest.raises(RingError, match="reserve"):
+        ring.mul_dev(out, a, b)                       # 96 elements need a larger operand scratch: refused, nothing freed
+    g.replay()                                        # the graph still runs on intact memory
+    torch.cuda.synchronize()
+    assert np.array_equal(out[:small * w].cpu().numpy().view(np.uint64), want)
+    del g
+    ring.reserve_scratch(big)                         # the explicit way to grow (graphs captured before are invalid from here on)
+    ring.mul_dev(out, a, b)
+    torch.cuda.synchronize()
+    e = big - 1
+    assert np.array_equal(out[e * w:].cpu().numpy().view(np.uint64),
+                          O.pow2_ring_mul(F, a[e * w:].cpu().numpy().view(np.uint64), b[e * w:].cpu().numpy().view(np.uint64), k, 1))
+    fresh = CyclotomicRing("goldilocks", k, device=0)  # never reserved: its first product under capture would have to allocate
+    g3 = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g3, stream=s):
+        with pytest.raises(RingError, match="reserve"):
+            fresh.mul_dev(out[:small * w], a[:small * w], b[:small * w], stream=torch.cuda.current_stream())
+    ring.close()
+    fresh.close()

@@ -29,6 +29,21 @@ def test_shard_range_partitions_exactly():
         shard_range(10, 2, 2)
 
 
+def test_multi_gpu_selection_widens_with_the_device_count():
+    """what the GPU suite does on a box with more than one device is decided by two small functions -- checked here on
+    the CPU for every device count, so that the branches a one-GPU box never takes are at least exercised as logic."""
+    from stark_rings_amd.sharding import group_device_ids, rehearsal_backend
+
+    assert group_device_ids(0) == [0, 0] and group_device_ids(1) == [0, 0]      # the one-GPU form: two contexts on device 0
+    assert group_device_ids(2) == [0, 1] and group_device_ids(4) == [0, 1, 2, 3]
+    assert group_device_ids(8) == list(range(8)) and group_device_ids(16) == list(range(8))
+    for n in range(2, 17):
+        ids = group_device_ids(n)
+        assert len(set(ids)) == len(ids) == min(n, 8)                            # distinct devices: the peer copy crosses xGMI
+    assert rehearsal_backend(0) == ("gloo", 2) and rehearsal_backend(1) == ("gloo", 2)
+    assert rehearsal_backend(2) == ("nccl", 2) and rehearsal_backend(8) == ("nccl", 2)
+
+
 def _worker(rank, world, port, k, batch, tmp):
     for p in (ROOT, os.path.join(ROOT, "oracle")):
         if p not in sys.path:
@@ -102,6 +117,33 @@ def test_bench_launches_its_own_ranks_and_checks_every_shard():
 
 
 @pytest.mark.gpu
+def test_bench_ranks_over_rccl_when_the_box_has_two_gpus():
+    """The sibling that widens itself: on a box with two or more visible GPUs the same self-launched two-rank run goes
+    over `nccl` (= RCCL) with one rank per DISTINCT device -- the first multi-rank RCCL broadcast of the twiddle block, a real
+    inter-GPU transfer -- each rank checking its shard against the oracle.  On the one-GPU box of the round's driver the selection
+    (stark_rings_amd.sharding.rehearsal_backend; unit-tested on the CPU above) says gloo, which the test above already runs: skipped.
+    The ranks are CHILDREN of a child (bench.py's own torch.distributed.run), nothing re-execs a process that holds the GPU."""
+    import json
+    import subprocess
+
+    from stark_rings_amd.sharding import rehearsal_backend
+
+    backend, ranks = rehearsal_backend(torch.cuda.device_count())   # device_count() does not initialise HIP on this image
+    if backend != "nccl":
+        pytest.skip("one visible GPU: the gloo rehearsal above is the form of this test that applies")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(ranks), "--backend", "nccl", "--batch", "300", "--steps", "2",
+           "--warmup", "1", "--parity-sample", "6", "--cpu-seconds", "0.5"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert d["n_gpus"] == ranks and d["multi_gpu"]["backend"].startswith("nccl") and d["multi_gpu"]["ranks_seen"] == ranks
+    assert d["multi_gpu"]["devices_visible"] >= 2 and d["multi_gpu"]["data_path_collectives"] == 0
+    assert "6 sampled elements per rank (%d ranks)" % ranks in d["parity"]
+
+
+@pytest.mark.gpu
 def test_sharded_path_at_config_4_degree_every_shard_sampled():
     """BASELINE config 4's degree (D = 2^20, 42 MB of tables to broadcast) through the sharded path before an 8-GPU
     node ever runs it: `bench.py --gpus 2 --workload goldilocks_d1048576_b8192 --batch 16` launches its two ranks itself (children,
@@ -149,9 +191,28 @@ def test_bench_single_rank_reports_the_plan_the_library_chose():
     assert 0 < roof["frac"] < 1 and 0 < roof["whole_step_frac"] < 1
     # every kernel tag of the step carries its own per-launch fraction; the reported one is the subject kernel's
     assert set(roof["by_kernel"]) == {"fwd_cols", "rows", "inv_cols"}
-    assert abs(roof["by_kernel"][roof["kernel"]]["frac"] - roof["frac"]) < 1e-9
+    assert abs(roof["by_kernel"][roof["kernel"]]["frac"] - roof["frac_events"]) < 1e-9
     assert roof["launches_per_step_by_kernel"]["fwd_cols"] == roof["launches_per_step_by_kernel"]["rows"]  # both operands: one launch
     assert "multi_gpu" not in d
+    # the line itself says why the whole step is where it is -- the reported fraction is the lower of the event-sampled
+    # and the rocprof-replayed figure, the events bracket a sparse sample (the profiled steps run like the timed ones), clock and
+    # power were sampled during the timed steps, and the whole-step VALU issue fraction is there whenever profiles/ holds PMC
+    # counters of this very build
+    assert roof["frac"] <= roof["frac_events"] + 1e-12 and roof["limiter"]
+    assert roof["events"]["bracketed"].startswith("every 7") and roof["events"]["sampled_launches"] > 0
+    assert abs(roof["events"]["profiled_step_ms"] / roof["events"]["timed_step_ms"] - 1) < 0.15
+    if "clock_power" in d:   # (a box without readable amdgpu hwmon files has none)
+        assert 400 < d["clock_power"]["sclk_mhz"] < 2600 and 100 < d["clock_power"]["socket_w"] < 1500 and d["clock_power"]["samples"] >= 3
+    if "replayed" in roof.get("rocprof_source", "") or "dropped: " in roof["traffic_source"]:
+        import bench
+
+        pj = [os.path.join(ROOT, "profiles", r, "pmc_goldilocks_d65536_b16384.json") for r in sorted(os.listdir(os.path.join(ROOT, "profiles")))]
+        pj = [q for q in pj if os.path.exists(q)][-1]
+        if json.load(open(pj)).get("source_sha256") == bench.source_hash():
+            ws = d["integer_valu"]["whole_step"]
+            assert 0.3 < ws["frac_at_nominal_2400_mhz"] < 1.0 and ws["valu_wave_instructions_per_step"] > 0
+            if "clock_power" in d:
+                assert 0.3 < ws["frac"] < 1.05 and ws["issue_floor_ms_at_sampled_clock"] < roof["events"]["timed_step_ms"] * 1.05
     if "two lanes --" in plan and "overlap" in roof:
         assert roof["overlap"]["internal_streams"] == 2 and roof["overlap"]["factor"] > 1.2
         assert roof["single_stream"]["frac"] > roof["frac"]  # the same kernel alone is faster per launch than beside the other lane
