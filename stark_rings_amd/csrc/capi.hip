@@ -470,8 +470,9 @@ int matmul_dev(sr_ctx *c, uint64_t *y, const uint64_t *a, const uint64_t *b, siz
     return SR_OK;
 }
 // operand scratch (defined below): grow-only device buffers owned by the context, ordered between streams by an event.  st = the
-// stream of the call that needs it (nullptr: sr_ctx_reserve_scratch, which may always grow).
-int ensure_scratch(sr_ctx *c, int n_buffers, size_t bytes, hipStream_t st);
+// stream of the call that needs it (the null stream is a caller's stream like any other); reserving = the call is
+// sr_ctx_reserve_scratch, the one place that may grow a buffer after a capture has been seen.
+int ensure_scratch(sr_ctx *c, int n_buffers, size_t bytes, hipStream_t st, bool reserving = false);
 // remembers that a call arrived on a capturing stream (sr_ctx::scratch_frozen); true while `st` is being captured
 bool note_capture(sr_ctx *c, hipStream_t st) {
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
@@ -516,11 +517,11 @@ struct DevBufLite {
     int slot;
     void *p = nullptr;
     DevBufLite(sr_ctx *c_, int slot_) : c(c_), slot(slot_) {}
-    int alloc(size_t bytes, hipStream_t st = nullptr) {
+    int alloc(size_t bytes, hipStream_t st = nullptr, bool reserving = false) {
         if (bytes == 0) bytes = 8;
-        const bool capturing = note_capture(c, st);
+        const bool capturing = !reserving && note_capture(c, st);
         if (c->host_tmp_bytes[slot] < bytes) {
-            if (capturing || (st && c->scratch_frozen)) return frozen_fail();
+            if (capturing || (!reserving && c->scratch_frozen)) return frozen_fail();
             if (c->host_tmp[slot]) {
                 HIP_TRY(hipDeviceSynchronize());  // a _dev call on another stream may still be using the smaller buffer
                 (void)hipFree(c->host_tmp[slot]);
@@ -701,11 +702,11 @@ sr::rt::Params<F> make_rt_params(const sr_ctx *c, bool fused) {
 }
 // grow-only scratch for packed intermediates (allocated on first use; a hipMalloc here is why the very first
 // call of a given size is not graph-capturable)
-int ensure_scratch(sr_ctx *c, int n_buffers, size_t bytes, hipStream_t st) {
-    const bool capturing = note_capture(c, st);
+int ensure_scratch(sr_ctx *c, int n_buffers, size_t bytes, hipStream_t st, bool reserving) {
+    const bool capturing = !reserving && note_capture(c, st);
     for (int i = 0; i < n_buffers; i++) {
         if (c->rt_scratch_bytes[i] >= bytes) continue;
-        if (capturing || (st && c->scratch_frozen)) return frozen_fail();
+        if (capturing || (!reserving && c->scratch_frozen)) return frozen_fail();
         HIP_TRY(hipDeviceSynchronize());
         if (c->rt_scratch[i]) HIP_TRY(hipFree(c->rt_scratch[i]));
         c->rt_scratch[i] = nullptr;
@@ -1613,7 +1614,7 @@ int sr_ctx_create_ex(int ring, int log2_degree, int device, const sr_plan *plan,
     if (!out) return fail(SR_E_INVALID, "null out pointer");
     *out = nullptr;
     if (plan) {
-        if (plan->flags >> 8) return fail(SR_E_INVALID, "sr_plan: unknown flag bits");
+        if (plan->flags >> 9) return fail(SR_E_INVALID, "sr_plan: unknown flag bits");
         if (plan->log_tile && (plan->log_tile < 8 || plan->log_tile > 12)) return fail(SR_E_INVALID, "sr_plan: log_tile must be 0 or 8..12");
         if (plan->stark_whole_max && (plan->stark_whole_max < 9 || plan->stark_whole_max > 12))
             return fail(SR_E_INVALID, "sr_plan: stark_whole_max must be 0 or 9..12");
@@ -2215,7 +2216,7 @@ int sr_ctx_reserve_scratch(sr_ctx *c, size_t batch) {
         const size_t sw = (size_t)c->limbs * 8;  // bytes per coefficient
         for (int slot = 8; slot <= 9; slot++) {
             DevBufLite t(c, slot);
-            if (int rc = t.alloc(fold_tmp_words(c->degree) * sw)) return rc;
+            if (int rc = t.alloc(fold_tmp_words(c->degree) * sw, nullptr, true)) return rc;
         }
     }
     if (!is_pow2_ring(c->ring)) return SR_OK;  // the small rings need no operand scratch
@@ -2238,8 +2239,8 @@ int sr_ctx_reserve_scratch(sr_ctx *c, size_t batch) {
         size_t need0 = lanes ? four : ((c->k > 12 ? rt_chunk_polys(c, batch) : batch) << c->k) * w, need1 = lanes ? 0 : need0;
         const size_t transform = lanes_t ? four : whole;
         if (transform > need0) need0 = transform;
-        if (int rc = ensure_scratch(c, 1, need0, nullptr)) return rc;
-        return need1 ? ensure_scratch(c, 2, need1, nullptr) : SR_OK;
+        if (int rc = ensure_scratch(c, 1, need0, nullptr, true)) return rc;
+        return need1 ? ensure_scratch(c, 2, need1, nullptr, true) : SR_OK;
     }
     const bool one_launch = c->ring == SR_RING_GOLDILOCKS_POW2 && c->fast_goldilocks && sr::gl_fast_supported(c->gl_fast)
                                 ? c->k <= 12
@@ -2248,9 +2249,9 @@ int sr_ctx_reserve_scratch(sr_ctx *c, size_t batch) {
     const bool gl = c->ring == SR_RING_GOLDILOCKS_POW2 && c->fast_goldilocks && sr::gl_fast_supported(c->gl_fast);
     if (gl && gl_use_lanes(c, batch)) {
         if (int rc = gl_lanes_init(c)) return rc;
-        return ensure_scratch(c, 1, 4 * gl_lane_chunk(c) * elem, nullptr);
+        return ensure_scratch(c, 1, 4 * gl_lane_chunk(c) * elem, nullptr, true);
     }
-    return ensure_scratch(c, 1, (gl ? gl_chunk_polys(c, batch) : scratch_polys(c, batch, elem)) * elem, nullptr);
+    return ensure_scratch(c, 1, (gl ? gl_chunk_polys(c, batch) : scratch_polys(c, batch, elem)) * elem, nullptr, true);
 }
 // ---- packed-u32 boundary (BabyBear power-of-two rings; csrc/packed32.hpp) ----------------------------------------------------
 extern "C++" {

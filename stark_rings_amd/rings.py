@@ -555,7 +555,8 @@ class CyclotomicRing:
         if out.numel() != self.words_per_elem:
             raise RingError("sum: out is not one ring element")
         n = self._batch_of(elems.numel())
-        self._check(self._lib.sr_sum_batch_dev(self._ctx, self._dev(out), self._dev(elems) if n else self._dev(out), n, self._stream(stream)))
+        po = self._dev(out)[0]
+        self._check(self._lib.sr_sum_batch_dev(self._ctx, po, self._dev(elems)[0] if n else po, n, self._stream(stream)))
         return out
 
     def product_dev(self, out, elems_ntt, stream=None):
@@ -563,7 +564,8 @@ class CyclotomicRing:
         if out.numel() != self.words_per_elem:
             raise RingError("product: out is not one ring element")
         n = self._batch_of(elems_ntt.numel())
-        self._check(self._lib.sr_product_batch_dev(self._ctx, self._dev(out), self._dev(elems_ntt) if n else self._dev(out), n, self._stream(stream)))
+        po = self._dev(out)[0]
+        self._check(self._lib.sr_product_batch_dev(self._ctx, po, self._dev(elems_ntt)[0] if n else po, n, self._stream(stream)))
         return out
 
     def product_poly_dev(self, out, elems, stream=None):

@@ -1257,7 +1257,7 @@ def test_plan_struct_is_validated_and_env_free(torch_cuda):
     """sr_ctx_create_ex refuses malformed plans; the library exports no behaviour switch through the environment."""
     from stark_rings_amd import CyclotomicRing, RingError
 
-    for bad in (_plan(flags=1 << 8), _plan(log_tile=7), _plan(log_tile=13), _plan(stark_whole_max=8), _plan(lanes=3)):
+    for bad in (_plan(flags=1 << 9), _plan(log_tile=7), _plan(log_tile=13), _plan(stark_whole_max=8), _plan(lanes=3)):
         with pytest.raises(RingError):
             CyclotomicRing("goldilocks", 10, device=0, plan=bad)
     import glob
@@ -2547,3 +2547,39 @@ def test_captured_graph_freezes_the_scratch(torch_cuda):
             fresh.mul_dev(out[:small * w], a[:small * w], b[:small * w], stream=torch.cuda.current_stream())
     ring.close()
     fresh.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("k,batch,lanes", [(13, 20, 0), (15, 9, 0), (16, 40, 1), (16, 460, 2), (18, 37, 2), (20, 30, 2), (20, 5, 1)])
+def test_split_rows_plan_equals_the_fused_product(torch_cuda, k, batch, lanes):
+    """VERDICT r4 #5, the A/B plan SR_PLAN_GL_SPLIT_ROWS: the fused rows kernel of a Goldilocks ring product above one tile as two
+    launches -- crt of b's tiles in place in the scratch (rows<0>), then the constant-operand product (rows<3>) -- on the one-stream
+    and the two-lane plans.  Bit for bit the default plan's product, operands intact, sampled elements against the oracle.  (Measured
+    slower on config 4: 158.2-159.0 against 156.1-156.6 ms per shard; it stays as a differential test of the rows kernels.)"""
+    torch = torch_cuda
+    from stark_rings_amd import CyclotomicRing
+
+    F = O.GOLDILOCKS
+    d = 1 << k
+    ta = torch.empty(batch * d, dtype=torch.int64, device="cuda")
+    tb = torch.empty_like(ta)
+    outs = []
+    for flags in (0, 256):   # 256 = SR_PLAN_GL_SPLIT_ROWS
+        ring = CyclotomicRing("goldilocks", k, device=0, plan=_plan(flags=flags, lanes=lanes))
+        ring.fill_uniform_dev(ta, 0xD1, 0)
+        ring.fill_uniform_dev(tb, 0xD2, 0)
+        a0, b0 = ta.clone(), tb.clone()
+        out = torch.empty_like(ta)
+        ring.mul_dev(out, ta, tb)
+        torch.cuda.synchronize()
+        assert torch.equal(ta, a0) and torch.equal(tb, b0), "operands written"
+        assert ring.count_noncanonical_dev(out) == 0
+        outs.append(out)
+        ring.close()
+    assert torch.equal(outs[0], outs[1])
+    sample = sorted({0, batch // 2, batch - 1})
+    ea = np.concatenate([O.fill_uniform(F, 0xD1, e * d, d) for e in sample])
+    eb = np.concatenate([O.fill_uniform(F, 0xD2, e * d, d) for e in sample])
+    want = O.pow2_ring_mul(F, ea, eb, k, len(sample), 4)
+    for i, e in enumerate(sample):
+        assert np.array_equal(outs[1][e * d:(e + 1) * d].cpu().numpy().view(np.uint64), want[i * d:(i + 1) * d]), e

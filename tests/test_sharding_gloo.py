@@ -202,7 +202,7 @@ def test_bench_single_rank_reports_the_plan_the_library_chose():
     assert roof["events"]["bracketed"].startswith("every 7") and roof["events"]["sampled_launches"] > 0
     assert abs(roof["events"]["profiled_step_ms"] / roof["events"]["timed_step_ms"] - 1) < 0.15
     if "clock_power" in d:   # (a box without readable amdgpu hwmon files has none)
-        assert 400 < d["clock_power"]["sclk_mhz"] < 2600 and 100 < d["clock_power"]["socket_w"] < 1500 and d["clock_power"]["samples"] >= 3
+        assert 400 < d["clock_power"]["sclk_mhz"] < 2600 and 100 < d["clock_power"]["socket_w"] < 1500 and d["clock_power"]["samples"] >= 1
     if "replayed" in roof.get("rocprof_source", "") or "dropped: " in roof["traffic_source"]:
         import bench
 
