@@ -146,8 +146,16 @@ class ClockPowerSampler:
         rows = [(c, w) for (t, c, w) in self.samples if t0 <= t <= t1]
         if not rows:
             return None
-        return {"sclk_mhz": sum(c for c, _ in rows) / len(rows) / 1e6, "socket_w": sum(w for _, w in rows) / len(rows) / 1e6,
+        third = max(1, len(rows) // 3)
+        mean = lambda xs: sum(xs) / len(xs)
+        first, last = rows[:third], rows[-third:]
+        return {"sclk_mhz": mean([c for c, _ in rows]) / 1e6, "socket_w": mean([w for _, w in rows]) / 1e6,
                 "sclk_mhz_min": min(c for c, _ in rows) / 1e6, "sclk_mhz_max": max(c for c, _ in rows) / 1e6,
+                # first against last third of the window: a timed region shorter than the chip's clock / power ramp (a few hundred ms
+                # after idle) shows up here -- the hwmon values are the driver's running averages and lag a short burst of load
+                "sclk_mhz_first_third": mean([c for c, _ in first]) / 1e6, "sclk_mhz_last_third": mean([c for c, _ in last]) / 1e6,
+                "socket_w_first_third": mean([w for _, w in first]) / 1e6, "socket_w_last_third": mean([w for _, w in last]) / 1e6,
+                "window_ms": (t1 - t0) * 1e3,
                 "samples": len(rows), "source": "amdgpu hwmon freq1_input / power1_input of %s, read by a thread of this process "
                                                 "every ~2 ms during the timed steps" % self.card}
 

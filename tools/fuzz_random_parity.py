@@ -46,7 +46,7 @@ while time.time() < t_end:
         vals = [special[int(rng.integers(0, len(special)))] for _ in range(d)]
         a[:d * O.LIMBS[F]] = O.to_mont(F, vals)
     op = ["crt", "icrt", "mul", "ntt_mul", "add", "sub", "reduce", "decompose", "rot", "matvec", "wire", "neg", "scale", "add_scalar",
-          "mul_ntt_rhs", "mul_elem"][int(rng.integers(0, 16))]
+          "mul_ntt_rhs", "mul_elem", "sum", "product"][int(rng.integers(0, 18))]
     ok = True
     if op == "crt":
         ok = np.array_equal(r.elementwise_crt(a.copy()), O.pow2_fwd(F, a, k, batch, 4)) if batch else True
@@ -117,6 +117,15 @@ while time.time() < t_end:
         one = b[:d * L].copy()
         got = r.mul_elem(a.copy(), one)
         ok = all(np.array_equal(got[e * d * L:(e + 1) * d * L], O.pow2_pointwise(F, a[e * d * L:(e + 1) * d * L], one)) for e in range(batch))
+    elif op == "sum":       # impl Sum: fold(zero(), +) over the slice, word-wise (batch 0: zero())
+        sa = O.from_mont(F, a) if batch else []
+        ok = O.from_mont(F, r.sum(a)) == [sum(sa[e * d + i] for e in range(batch)) % p for i in range(d)]
+    elif op == "product":   # impl Product for RqNTT: fold(one(), *) slot-wise, left to right like the reference (batch 0: one())
+        L = O.LIMBS[F]
+        acc = O.to_mont(F, [1] * d)
+        for e in range(batch):
+            acc = O.pow2_pointwise(F, acc, a[e * d * L:(e + 1) * d * L])
+        ok = np.array_equal(r.product(a), acc)
     elif op == "wire" and batch:
         wire = r.serialize(a)
         ok = np.array_equal(wire, O.serialize(F, a)) and np.array_equal(r.deserialize(wire), a)

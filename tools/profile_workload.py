@@ -103,7 +103,7 @@ def tag_of(kernel):
     return None
 
 
-MAX_ROWS = 4000  # rows of a raw CSV kept in profiles/ (the two-lane plans launch hundreds of chunk kernels per step)
+MAX_ROWS = 400  # rows of a raw CSV kept in profiles/ (the two-lane plans launch hundreds of chunk kernels per step)
 
 
 def copy_csv(src, dst):
