@@ -2442,6 +2442,15 @@ def test_sum_and_product_over_a_slice_of_ring_elements(torch_cuda, name, k, size
         assert np.array_equal(out.cpu().numpy().view(np.uint64), acc)
         one_poly = O.to_mont(F, [1] + [0] * (d - 1))
         assert np.array_equal(ring.product_poly(np.zeros(0, dtype=np.uint64)), one_poly)   # one() of RqPoly: icrt of the all-ones slots
+    if slot > 1:   # the reference's own rings: Product for RqPoly against the fold of the ring's fused product (pinned to the oracle above)
+        n = 4
+        a = O.fill_uniform(F, 0x9E0 + slot, 0, n * d)
+        acc = a[:w].copy()
+        for e in range(1, n):
+            acc = ring.mul(acc, a[e * w:(e + 1) * w].copy())
+        assert np.array_equal(ring.product_poly(a), acc)
+        one_poly = O.to_mont(F, [1] + [0] * (d - 1))
+        assert np.array_equal(ring.product_poly(np.zeros(0, dtype=np.uint64)), one_poly)
     # out inside the slice is refused
     ta = torch.from_numpy(O.fill_uniform(F, 1, 0, 3 * d).view(np.int64)).cuda()
     with pytest.raises(RingError, match="overlap"):
