@@ -2,6 +2,10 @@
 // D = 4096 ring products).  Junk data and junk tables: the instruction stream does not depend on the values (the 2^-25 slow path of
 // StarkL::canonical aside).  Build variants with -D flags and compare; correctness is checked through the library, never here.
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 [-DSR_ST_XCHG=n] -o build_tmp/st_bench tools/ubench/st_bench.hip && build_tmp/st_bench [batch] [reps]
+// The variants of round 5 (profiles/r05/st_bench.txt, st_bench_wave_local.txt) were one-line edits of st::Tile::exchange in a scratch copy
+// of csrc/ntt_stark.hpp, never committed to the product: xchg=1 = `return;` as the first statement of exchange() (no LDS traffic at
+// all: wrong results, timing only); "st_bench2" = the two __syncthreads() of the nine wave-local steps (neighbouring layouts whose
+// exchanged lane bits are both below 6) replaced by wavefront-scope fences, a leading __syncthreads() on the three steps that cross waves.
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
