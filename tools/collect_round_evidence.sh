@@ -1,5 +1,5 @@
 #!/bin/bash
-# round-5 final GPU call B (after profiles/r05 holds the PMC / kernel-stats collection of THIS build, so that bench.py replays it):
+# Second GPU call of a round's final collection (after tools/collect_profiles.sh; run once profiles/rNN holds the PMC / kernel-stats collection of THIS build, so that bench.py replays it):
 # bench lines, Stark stall counters and harness, clock ramp, random soaks, the full GPU suite.  Output: gpurun_out/profiles_r05b/
 set -o pipefail
 O=gpurun_out/profiles_r05b
