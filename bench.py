@@ -244,7 +244,10 @@ def main():
     assert world == args.gpus, "WORLD_SIZE (%d) != --gpus (%d)" % (world, args.gpus)
     ndev = torch.cuda.device_count()
     assert ndev > 0, "bench.py needs a GPU"
-    dev_index = local_rank % ndev  # one rank per GPU on a full node; a 1-GPU rehearsal folds ranks onto device 0
+    if world > ndev and args.backend == "nccl" and world > 1:
+        raise SystemExit("bench.py: %d ranks over RCCL need %d GPUs, %d visible (RCCL refuses two ranks on one device; "
+                         "rehearse with --backend gloo)" % (world, world, ndev))
+    dev_index = local_rank % ndev  # one rank per GPU on a full node; a 1-GPU rehearsal (gloo) folds ranks onto device 0
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
     sampler = None
