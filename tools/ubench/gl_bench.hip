@@ -13,7 +13,16 @@
 #if defined(MIXED) || defined(PIPE)
 #include "mixed256_experiment.hpp"
 #endif
-#ifdef KEEP
+#ifdef KEEPPF
+// round-5 experiment: the persistent column pass with the next element's loads in flight during pass B (cols_keep_prefetch.hpp);
+// KEEPPF = ring-element groups per XCD and column chunk (4 = 512 workgroups at D = 2^16: two per CU)
+#include "cols_keep_prefetch.hpp"
+static inline unsigned keeppf_groups(size_t np) { size_t g = np / 8; if (g < 1) g = 1; if (g > KEEPPF) g = KEEPPF; return (unsigned)g; }
+#define KEEP 8
+#define KEEP_LAUNCH(DIRV, st_, buf, srcbuf, np, wcp, twp)                                                                                         \
+    hipLaunchKernelGGL((sr::gl::cols256_keep_pf_kernel<DIRV>), dim3(8u * (1u << (k - 12)) * keeppf_groups(np)), dim3(256), 0, st_, buf, srcbuf, (u64 *)nullptr, \
+                       (const u64 *)nullptr, k, wcp, twp, (unsigned)(np), keeppf_groups(np))
+#elif defined(KEEP)
 // the lane plans' column pass (gl::cols256_keep_kernel, in the library since round 4) against the plain one
 // KEEP = ring-element groups per XCD and column chunk (8 = 1024 workgroups at D = 2^16: one round of resident workgroups)
 static inline unsigned keep_groups(size_t np) { size_t g = np / 8; if (g < 1) g = 1; if (g > KEEP) g = KEEP; return (unsigned)g; }
