@@ -2592,3 +2592,61 @@ def test_split_rows_plan_equals_the_fused_product(torch_cuda, k, batch, lanes):
     want = O.pow2_ring_mul(F, ea, eb, k, len(sample), 4)
     for i, e in enumerate(sample):
         assert np.array_equal(outs[1][e * d:(e + 1) * d].cpu().numpy().view(np.uint64), want[i * d:(i + 1) * d]), e
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,k,n", [("goldilocks", 16, 16384), ("babybear", 16, 4099), ("stark", 12, 4096), ("goldilocks24", 0, 1 << 17)])
+def test_sum_and_product_at_batch_sizes_of_the_baseline_configs(torch_cuda, name, k, n):
+    """Sum / Product over slices as long as the BASELINE batches (config 2: 16 384 elements of degree 2^16 = 8 GiB; a ragged BabyBear
+    slice; config 5; 2^17 elements of the reference's own Goldilocks-24 ring): the device fold runs its full ladder of stages (and the
+    halving tree of the small ring seventeen levels deep).  Checked on 64 sampled word positions -- gathered on the device, summed as Python
+    integers, multiplied left to right by the oracle's slot product -- and, for the sum, by linearity on the whole element:
+    sum(a) + sum(a) == sum over the slice of (a + a)."""
+    torch = torch_cuda
+    base = {"goldilocks24": "goldilocks"}.get(name, name)
+    F = O.FIELD_ID[base]
+    p = P.PRIMES[base][0]
+    L = O.LIMBS[F]
+    ring = ring_for(name, k)
+    d, w = ring.degree, ring.words_per_elem
+    a = torch.empty(n * w, dtype=torch.int64, device="cuda")
+    ring.fill_uniform_dev(a, 0xF00D + k, 0)
+    s = torch.empty(w, dtype=torch.int64, device="cuda")
+    ring.sum_dev(s, a)
+    torch.cuda.synchronize()
+    slot = 3 if name == "goldilocks24" else 1
+    rng = np.random.default_rng(7)
+    pos = sorted({0, d - 1} | {int(x) for x in rng.integers(0, d, 62)})
+    if slot > 1:   # whole slots, so that the slot product can be folded on the sample
+        pos = sorted({q - q % slot + j for q in pos for j in range(slot)})
+    idx = torch.tensor([q * L + l for q in pos for l in range(L)], dtype=torch.int64, device="cuda")
+    cols = a.view(n, w)[:, idx].contiguous().cpu().numpy().view(np.uint64)          # (n, len(pos) * L) memory images
+    std = O.from_mont(F, cols.reshape(-1))
+    m = len(pos)
+    want = O.to_mont(F, [sum(std[e * m + i] for e in range(n)) % p for i in range(m)])
+    got = s[idx].cpu().numpy().view(np.uint64)
+    assert np.array_equal(got, want), "sum"
+    if name != "goldilocks24":   # linearity on every word: sum(a) + sum(a) == sum(a + a)
+        twice = s.clone()
+        ring.add_dev(twice, s)
+        ring.add_dev(a, a)   # a += a: the kernel reads both operands of a word before it writes that word
+        s2 = torch.empty_like(s)
+        ring.sum_dev(s2, a)
+        torch.cuda.synchronize()
+        assert torch.equal(s2, twice), "linearity"
+        ring.fill_uniform_dev(a, 0xF00D + k, 0)
+    prod = torch.empty(w, dtype=torch.int64, device="cuda")
+    ring.product_dev(prod, a)
+    torch.cuda.synchronize()
+    if slot == 1:
+        acc = cols[0].copy()
+        for e in range(1, n):
+            acc = O.pow2_pointwise(F, acc, cols[e])
+    else:   # 24-word blocks of whole slots: pad the sample to whole ring elements for the oracle's 8-slot product
+        pad = (-m) % 24
+        blk = np.concatenate([cols, np.tile(O.to_mont(F, [1, 0, 0] * (pad // 3)), (n, 1))], axis=1) if pad else cols
+        acc = blk[0].copy()
+        for e in range(1, n):
+            acc = O.small("sro_g24_ntt_mul", acc, blk[e])
+        acc = acc[:m]
+    assert np.array_equal(prod[idx].cpu().numpy().view(np.uint64), acc), "product"
